@@ -1,0 +1,164 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of the MI355X-native LSeg forward (BASELINE.json metric).
+
+Workload (config.workload): BASELINE.json configs[1] -- ViT-L/16 + DPT head + CLIP text tower,
+480x480, K=150 ADE20K labels, bf16 MFMA inference -- `--batch` images per GPU per step
+(default 8), synthetic seeded weights and images (no network: no checkpoints/datasets).
+One "step" = one LSegNet.forward call on one batch, INCLUDING the CLIP text tower, which the
+reference re-runs on every forward (modules/models/lseg_net.py:183); `--cache-text` reports the
+cached variant in an extra field but never changes `value`.
+
+Launch:  python bench.py --gpus 1 --steps K --warmup W
+   or:   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+             --master-port P bench.py --gpus N --steps K --warmup W
+Multi-GPU = config 3: the image batch is sharded across ranks, weights replicated, NO data-path
+collective (weak scaling: per-GPU batch fixed); only the timing barrier/all-reduce(max) uses RCCL.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "lang-seg_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+GF_IMAGE = lambda K: 799.4 + 0.05898 * K        # image tower GF / image
+GF_TEXT = lambda K: 5.959 * K                   # CLIP text tower GF / forward call
+PEAK_BF16_TFLOPS = 2500.0                       # MI355X_MICROARCH.md dense bf16 MFMA peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--labels", type=int, default=150)
+    ap.add_argument("--backbone", default="clip_vitl16_384")
+    ap.add_argument("--size", type=int, default=480)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-forwards", type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, sd, tok, size, n_forwards):
+    """The CPU oracle (a port of the reference forward, oracle/lseg_oracle.py) timed on this
+    box's host cores: B=1, text tower recomputed per call (reference semantics)."""
+    from oracle.lseg_oracle import lseg_forward
+    from lseg_hip.synth import synthetic_images
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    x = synthetic_images(1, size, size, seed=0)
+    with torch.no_grad():
+        lseg_forward(sd, x, tok, cfg)           # warm-up
+        t0 = time.time()
+        for _ in range(n_forwards):
+            lseg_forward(sd, x, tok, cfg)
+        dt = (time.time() - t0) / n_forwards
+    return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": f"{n_forwards} timed B=1 forwards of the same workload (fp32 torch-CPU oracle, "
+                      f"text tower recomputed per call), {dt:.2f} s each"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the LSeg HIP engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from lseg_hip.config import get_config
+    from lseg_hip.engine import HipEngine
+    from lseg_hip.synth import synthetic_state_dict, synthetic_tokens, synthetic_images, read_labels
+
+    cfg = get_config(args.backbone)
+    sd = synthetic_state_dict(cfg, seed=0)
+    labels = read_labels(os.path.join(ROOT, "lang-seg_amd", "label_files", "ade20k_objectInfo150.txt"))
+    if args.labels > len(labels):
+        extra = read_labels(os.path.join(ROOT, "lang-seg_amd", "label_files", "fewshot_fss.txt"), skip_header=False)
+        labels = (labels + extra)[: args.labels]
+    labels = labels[: args.labels]
+    tok = synthetic_tokens(labels, cfg.text.vocab, cfg.text.ctx)
+    K, B = len(labels), args.batch
+    eng = HipEngine(cfg, args.size, args.size, max_batch=B, max_labels=K, image_dtype=args.dtype)
+    eng.load_state_dict(sd)
+    eng.set_tokens(tok)
+    # every rank gets its own shard of the global batch (different seed = different images)
+    x = synthetic_images(B, args.size, args.size, seed=rank).cuda()
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = eng.forward(x)
+    eng.set_profiling(True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = eng.forward(x)
+    sync()
+    dt = time.perf_counter() - t0
+    eng.set_profiling(False)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(out).all(), "non-finite logits"
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        ips = world * B * args.steps / dt
+        fc1 = eng.profile("mlp_fc1")
+        fwd = eng.profile("forward")
+        roof = None
+        if fc1["launches"]:
+            avg_ms = fc1["total_ms"] / fc1["launches"]
+            ach = fc1["flops_per_launch"] / (avg_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": "lseg_gemm_kernel<bf16,128,128,tag=1> (ViT MLP fc1 + bias + GELU)",
+                    "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 5), "launches": fc1["launches"],
+                    "flops_per_launch": fc1["flops_per_launch"]}
+        # whole-path figures (reference-algorithm FLOP convention)
+        gf_step = B * GF_IMAGE(K) + GF_TEXT(K)
+        line = {
+            "metric": "images/sec at 480x480, ViT-L/16 + 150 ADE20K labels",
+            "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: {args.backbone} LSegNet.forward, {args.size}x{args.size}, "
+                                   f"K={K} ADE20K labels, text tower recomputed every call",
+                       "per_gpu_batch": B, "global_batch": B * world, "labels": K,
+                       "parallelism": f"dp{world} (batch sharded, no collectives)"},
+            "path_tflops": round(world * gf_step / (ms * 1e-3) / 1e3, 2),
+            "path_frac_of_mfma_peak": round(gf_step / (ms * 1e-3) / 1e3 / PEAK_BF16_TFLOPS, 4),
+            "engine_forward_ms_hip_events": round(fwd["total_ms"] / max(1, fwd["launches"]), 4),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, sd, tok, args.size, args.cpu_baseline_forwards)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,180 @@
+/*
+ * lseg_hip.h -- C ABI of the MI355X-native LSeg forward engine (liblseg_hip.so).
+ *
+ * Drop-in boundary for ONE hot path of isl-org/lang-seg: LSegNet.forward()
+ * (modules/models/lseg_net.py:160-205 and everything it calls).  The reference
+ * has no FFI layer -- the path sits behind a Python class API -- so these
+ * entry points are what a ctypes binding inside the reference's
+ * modules/models/lseg_net.py would call.  Every function
+ * cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, ints.  No torch / C++ types cross the boundary.
+ *   - every pointer named dev_* / d_* is DEVICE memory (HBM) owned by the caller;
+ *     host pointers are named host_* .
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work
+ *     is stream-ordered, nothing synchronises the host unless documented.
+ *   - one handle per device, not thread-safe per handle (the reference runs one
+ *     Python thread per GPU replica: additional_utils/models.py:229-238).
+ *   - return value: LSEG_OK (0) or a negative lseg_status; lseg_last_error()
+ *     gives a message.  No C++ exception crosses the boundary.
+ *   - there is NO CPU fallback: without a gfx950 device every compute entry
+ *     point returns LSEG_ERR_NO_DEVICE.
+ */
+#ifndef LSEG_HIP_H
+#define LSEG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSEG_ABI_VERSION 1
+
+typedef enum {
+    LSEG_OK = 0,
+    LSEG_ERR_INVALID = -1,     /* bad argument / shape */
+    LSEG_ERR_NO_DEVICE = -2,   /* no HIP device / wrong arch */
+    LSEG_ERR_HIP = -3,         /* a HIP runtime call failed */
+    LSEG_ERR_STATE = -4,       /* call order (params not finalised, tokens not set...) */
+    LSEG_ERR_UNSUPPORTED = -5, /* configuration outside what the engine implements */
+    LSEG_ERR_MISSING_PARAM = -6
+} lseg_status;
+
+typedef enum { LSEG_F32 = 0, LSEG_F16 = 1, LSEG_BF16 = 2, LSEG_I64 = 3 } lseg_dtype;
+
+/* Resample op that follows the 1x1 conv of act_postprocessK
+ * (modules/models/lseg_vit.py:446-523 / 315-396). */
+typedef enum { LSEG_RS_IDENTITY = 0, LSEG_RS_CONVT = 1, LSEG_RS_CONV_S2 = 2 } lseg_resample;
+
+/* Shape description of one network variant; mirrors the constants hard-coded at
+ * lseg_net.py:119-123,142-146, lseg_vit.py:221-272, lseg_blocks.py:24-52 and the
+ * [3P] timm / CLIP model dims.  Filled by the Python shim from `--backbone`. */
+typedef struct {
+    int32_t abi_version;      /* = LSEG_ABI_VERSION */
+    /* image tower (timm VisionTransformer) */
+    int32_t patch;            /* 16 | 32 */
+    int32_t dim;              /* 1024 | 768 */
+    int32_t depth;            /* 24 | 12 */
+    int32_t heads;            /* 16 | 12 ; head_dim must be 64 */
+    int32_t hooks[4];         /* lseg_net.py:119-123 */
+    int32_t pos_grid;         /* pretrained pos-embed grid side (384/patch) */
+    /* reassemble + DPT head */
+    int32_t reassemble_ch[4]; /* channels after the 1x1 conv */
+    int32_t resample_kind[4]; /* lseg_resample */
+    int32_t resample_k[4];    /* ConvTranspose kernel=stride, or 3 for conv_s2 */
+    int32_t features;         /* --num_features (256) */
+    int32_t out_c;            /* 512 (768 for clipRN50x16_vitl16_384) */
+    int32_t arch_option;      /* 0 | 1 (bottleneck_block) | 2 (depthwise_block), lseg_net.py:148-154 */
+    int32_t block_depth;
+    int32_t activation;       /* 0 relu, 1 lrelu, 2 tanh (lseg_net.py:47-52) */
+    /* CLIP text tower */
+    int32_t text_vocab, text_ctx, text_width, text_heads, text_layers;
+    /* execution plan */
+    int32_t img_h, img_w;     /* input size, multiples of 2*patch */
+    int32_t max_batch;        /* workspace is sized for this many images per call */
+    int32_t max_labels;       /* workspace is sized for this many labels (K) */
+    int32_t image_dtype;      /* LSEG_BF16 (default) or LSEG_F16: MFMA operand type of the image tower */
+    int32_t flags;            /* reserved, 0 */
+} lseg_config;
+
+typedef struct lseg_engine* lseg_handle;
+
+/* ---- life cycle ------------------------------------------------------------------
+ * replaces: LSegNet.__init__ / LSeg.__init__ (lseg_net.py:104-158,208-226) as far as
+ * device-side state is concerned (module construction itself stays in Python). */
+int lseg_abi_version(void);
+int lseg_device_count(void);
+int lseg_create(const lseg_config* cfg, int device, lseg_handle* out);
+int lseg_destroy(lseg_handle h);
+const char* lseg_last_error(lseg_handle h);   /* h may be NULL: last error of this thread */
+
+/* ---- parameters ------------------------------------------------------------------
+ * replaces: nn.Module.load_state_dict / BaseModel.load (lseg_net.py:81-92).  `key` is a
+ * state-dict key relative to `net.`, e.g.
+ * "pretrained.model.blocks.3.attn.qkv.weight".  The engine converts/repacks into its
+ * own HBM copies (bf16/fp16 tiles, BN folded into the conv weights, ConvTranspose
+ * re-laid as a GEMM) during lseg_finalize_params; the caller's tensor is only read.
+ * Re-bind + finalize again after the weights change (e.g. after an optimizer step). */
+int lseg_bind_param(lseg_handle h, const char* key, const void* dev_ptr, int dtype,
+                    const int64_t* shape, int ndim);
+int lseg_finalize_params(lseg_handle h, void* stream);
+
+/* ---- text --------------------------------------------------------------------------
+ * replaces: `text = clip.tokenize(labels)` being handed to
+ * `clip_pretrained.encode_text(text)` (lseg_net.py:158,163-164,181-183) and the fp16
+ * L2 normalisation (lseg_net.py:192).  Tokens are what clip.tokenize returns: int64
+ * [K, ctx] on the HOST.  lseg_encode_text runs the 12-layer tower and leaves the
+ * normalised fp16 features [K, out_c] in the engine.  lseg_forward re-runs it on every
+ * call (reference semantics) unless text caching is switched on. */
+int lseg_set_text_tokens(lseg_handle h, const int64_t* host_tokens, int K, int ctx);
+int lseg_encode_text(lseg_handle h, void* stream);
+int lseg_set_text_cache(lseg_handle h, int enabled);   /* 0 (default) = re-encode per forward */
+int lseg_get_text_features(lseg_handle h, void* dev_out_f16 /* [K,out_c] fp16 */, void* stream);
+
+/* ---- forward -----------------------------------------------------------------------
+ * replaces: LSeg.forward(x, labelset) (lseg_net.py:160-205).
+ *   dev_x          fp32 [B,3,img_h,img_w] NCHW, normalised like lseg_module.py:37-50
+ *   dev_logits_out fp32 [B,K,img_h,img_w], caller-allocated, freshly written (the caller
+ *                  may mutate it afterwards: encoding_models.py:138).  May be NULL.
+ *   dev_argmax_out uint8 [B,img_h/2,img_w/2] argmax over K of the low-resolution
+ *                  logits (before the x2 upsample); optional, may be NULL. */
+int lseg_forward(lseg_handle h, const float* dev_x, int B, float* dev_logits_out,
+                 uint8_t* dev_argmax_out, void* stream);
+
+/* Intermediate taps for parity tests (names: "act1".."act4", "layer1".."layer4",
+ * "rn1".."rn4", "path1".."path4", "image_features", "lowres").  Copies the tensor in the oracle's layout
+ * ([B,N,D] / NCHW fp32) into dev_out; *n_elems gets the element count. */
+int lseg_get_intermediate(lseg_handle h, const char* name, float* dev_out, size_t cap_elems,
+                          size_t* n_elems, void* stream);
+/* Debug mode keeps fp32 snapshots of the 4 hooked block outputs ("act1".."act4", the
+ * reference's forward hooks at lseg_vit.py:12-16,421-424) during lseg_forward. */
+int lseg_set_debug(lseg_handle h, int enabled);
+
+/* ---- measurement -------------------------------------------------------------------
+ * Per-kernel-family HIP-event timing on the engine's stream (bench.py roofline leg).
+ * family names: "mlp_fc1" (the dominant GEMM), "forward". */
+int lseg_set_profiling(lseg_handle h, int enabled);
+int lseg_get_profile(lseg_handle h, const char* family, double* total_ms, int64_t* launches,
+                     double* flops_per_launch);
+
+/* ---- single-operator entry points (unit parity tests call these through the ABI) --
+ * All tensors are device pointers; dtype codes are lseg_dtype. */
+
+/* C[M,N] = act(A[M,K] @ W[N,K]^T + bias) (+ residual); A,W: bf16 or fp16 (`ab_dtype`),
+ * bias fp32 [N] or NULL, residual fp32 [M,N] or NULL, C: out_dtype.  act: 0 none,
+ * 1 GELU(erf), 2 QuickGELU, 3 ReLU.   (timm Linear / CLIP Linear / 1x1 conv) */
+int lseg_op_gemm(const void* d_A, const void* d_W, const float* d_bias, const float* d_residual,
+                 void* d_C, int M, int N, int K, int ab_dtype, int out_dtype, int act, void* stream);
+/* LayerNorm over the last dim: in fp32|fp16 [M,D] -> out bf16|fp16 [M,D] */
+int lseg_op_layernorm(const void* d_in, int in_dtype, const float* d_gamma, const float* d_beta,
+                      void* d_out, int out_dtype, int M, int D, float eps, void* stream);
+/* softmax(Q K^T * scale [+causal]) V for head_dim 64.
+ * q,k: [BH, Npad, 64]; vt: [BH, 64, Npad] (V transposed); out: [B, Ntok, H*64]. */
+int lseg_op_attention(const void* d_q, const void* d_k, const void* d_vt, void* d_out,
+                      int B, int H, int Ntok, int Npad, int dtype, int causal, float scale,
+                      void* stream);
+/* 3x3 conv, NHWC, zero-padded borders: in [B,H+2,W+2,Cin] (bf16, border = 0) ->
+ * out [B,Ho+2,Wo+2,Cout] interior written; w_packed [Cout, 9*Cin] bf16 (tap-major).
+ * stride 1|2, relu_in / relu_out flags, bias fp32 [Cout] or NULL, residual (same
+ * geometry as out, bf16) or NULL. */
+int lseg_op_conv3x3(const void* d_in, const void* d_w_packed, const float* d_bias,
+                    const void* d_residual, void* d_out, int B, int H, int W, int Cin, int Cout,
+                    int stride, int relu_in, int relu_out, void* stream);
+/* bilinear x2, align_corners=True, NHWC bf16: in [B,H+2,W+2,C] (padded) -> out [B,2H,2W,C] */
+int lseg_op_upsample2x_nhwc(const void* d_in, void* d_out, int B, int H, int W, int C, void* stream);
+/* bilinear x2, align_corners=True, NCHW fp32 planes: in [P,H,W] -> out [P,2H,2W]
+ * (scratch.output_conv, lseg_net.py:203,219-221) */
+int lseg_op_upsample2x_planes(const float* d_in, float* d_out, int P, int H, int W, void* stream);
+/* pixel x text correlation (lseg_net.py:187-196): feat fp32 [M,C]; text fp16 [K,C]
+ * (already L2-normalised); logits fp32 [B,K,P] with M = B*P.  Internally:
+ * a = fp16(scale * fp16(feat/||feat||)); logits = fp16(a @ text^T). */
+int lseg_op_correlation(const float* d_feat, const void* d_text_f16, float* d_logits,
+                        int B, int P, int C, int K, float logit_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSEG_HIP_H */

@@ -1,0 +1,210 @@
+// attention.hip -- fused softmax(Q K^T * scale [+ causal mask]) V for head_dim 64 on gfx950.
+//
+// Replaces the materialised attention of
+//   [3P] timm 0.4.12 Attention.forward (invoked from lseg_vit.py:196-197; restated by the
+//        reference's own hook at lseg_vit.py:24-40): 901 tokens, 16 heads, fp32 scores
+//   [3P] CLIP nn.MultiheadAttention with the causal -inf mask (clip/model.py), 77 tokens
+// with a flash-style single pass: scores never touch HBM.
+//
+// Layout: q,k [BH, Npad, 64]; v TRANSPOSED vt [BH, 64, Npad] (the QKV GEMM epilogue writes
+// these directly); out [B, Ntok, H*64] row-major = the A operand of the projection GEMM.
+// One workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 rows.
+// K / V^T tiles of 64 keys stream HBM -> LDS with direct-to-LDS loads (double-buffered).
+//
+// Both products use v_mfma_f32_32x32x16 in the "transposed" orientation so that the query
+// index lives on the lane (col = lane&31) for S^T = K Q^T AND for O^T = V^T P^T:
+//   * row max / row sum are lane-local (plus one exchange with lane^32),
+//   * the online-softmax rescale of O is a per-lane scalar multiply,
+//   * the exponentiated scores feed the second MFMA straight from registers: the k-slot
+//     <-> key assignment of the second product is chosen to be exactly the accumulator
+//     layout of the first (key = 16*s + 4*(lane>>5) + (j&3) + 8*(j>>2)), and V^T is read
+//     from LDS with the same assignment (two 8-byte reads), so no cross-lane shuffle or
+//     LDS round trip of P is needed.
+#include "common.h"
+#include "../../include/lseg_hip.h"
+
+namespace lseg {
+
+struct AttnArgs {
+    const uint16_t* q; const uint16_t* k; const uint16_t* vt;
+    uint16_t* out;
+    int B, H, ntok, npad, causal;
+    float scale_log2e;     // softmax scale * log2(e)
+};
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void lseg_attention_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (K 8 KB + Vt 8 KB)
+    constexpr int TILE = 8192, STAGE = 2 * TILE;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int hi = lane >> 5, ql = lane & 31;
+    const int bh = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + w) * 32;
+    const uint16_t* Q = a.q + (size_t)bh * a.npad * 64;
+    const uint16_t* K = a.k + (size_t)bh * a.npad * 64;
+    const uint16_t* Vt = a.vt + (size_t)bh * 64 * a.npad;
+
+    // Q fragments: B operand of S^T = K Q^T; lane -> col q, k-slots d = ks*16 + hi*8 + j
+    i32x4_t qf[4];
+    {
+        int qr = q0 + ql;
+        if (qr > a.npad - 1) qr = a.npad - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qf[ks] = *reinterpret_cast<const i32x4_t*>(Q + (size_t)qr * 64 + ks * 16 + hi * 8);
+    }
+
+    int kv_end = a.ntok;
+    if (a.causal) {
+        const int qend = (blockIdx.x + 1) * 128;
+        kv_end = qend < a.ntok ? qend : a.ntok;
+    }
+    const int n_tiles = (kv_end + 63) >> 6;
+
+    auto issue = [&](int t, int stage) {
+        char* sk = smem + stage * STAGE;
+        char* sv = sk + TILE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int slab = s * 4 + w;
+            const int r = slab * 8 + (lane >> 3);
+            glds_slab_row(K + (size_t)(t * 64 + r) * 64, r, lane, sk + slab * 1024);
+            glds_slab_row(Vt + (size_t)r * a.npad + t * 64, r, lane, sv + slab * 1024);
+        }
+    };
+
+    f32x16_t o[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    const int qrow = q0 + ql;
+
+    issue(0, 0);
+    for (int t = 0; t < n_tiles; ++t) {
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (t + 1 < n_tiles) issue(t + 1, (t + 1) & 1);
+        const char* sk = smem + (t & 1) * STAGE;
+        const char* sv = sk + TILE;
+
+        // ---- S^T[key][q] for 64 keys: 2 sub-tiles x 4 k-steps ---------------------------------
+        f32x16_t s[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const i32x4_t kf = *reinterpret_cast<const i32x4_t*>(sk + tile_off(sub * 32 + ql, ks * 2 + hi));
+                s[sub] = mfma32<T>(kf, qf[ks], s[sub]);
+            }
+        }
+        // ---- scale, mask, online softmax --------------------------------------------------------
+        const bool need_mask = a.causal || (t * 64 + 64 > a.ntok);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = s[sub][r] * a.scale_log2e;
+                if (need_mask) {
+                    const int key = t * 64 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const bool ok = key < a.ntok && (!a.causal || key <= qrow);
+                    v = ok ? v : -INFINITY;
+                }
+                s[sub][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float lsum = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[sub][r] - m_new);
+                s[sub][r] = p;
+                lsum += p;
+            }
+        l_run = l_run * alpha + lsum;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+
+        // ---- P^T fragments (B operand), straight from the accumulator layout -----------------
+        i32x4_t pf[2][2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int wd = 0; wd < 4; ++wd) {
+                    const uint32_t lo = from_f32<T>(s[sub][8 * s2 + 2 * wd]);
+                    const uint32_t hi16 = from_f32<T>(s[sub][8 * s2 + 2 * wd + 1]);
+                    pf[sub][s2][wd] = (int)(lo | (hi16 << 16));
+                }
+        // ---- O^T[d][q] += V^T[d][keys] P^T[keys][q] -----------------------------------------------
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const int row = d * 32 + ql;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int c = sub * 4 + s2 * 2;
+                    const uint2 v0 = *reinterpret_cast<const uint2*>(sv + tile_off(row, c) + hi * 8);
+                    const uint2 v1 = *reinterpret_cast<const uint2*>(sv + tile_off(row, c + 1) + hi * 8);
+                    i32x4_t vf;
+                    vf[0] = (int)v0.x; vf[1] = (int)v0.y; vf[2] = (int)v1.x; vf[3] = (int)v1.y;
+                    o[d] = mfma32<T>(vf, pf[sub][s2], o[d]);
+                }
+        }
+    }
+
+    // ---- normalise and store: lane holds O[q][d = dblk*32 + 8g + 4hi + 0..3] -------------------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    if (qrow < a.ntok) {
+        const int b = bh / a.H, h = bh - b * a.H;
+        uint16_t* orow = a.out + ((size_t)b * a.ntok + qrow) * (a.H * 64) + h * 64;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint16_t hv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) hv[e] = from_f32<T>(o[d][g * 4 + e] * inv);
+                uint2 pk;
+                pk.x = (uint32_t)hv[0] | ((uint32_t)hv[1] << 16);
+                pk.y = (uint32_t)hv[2] | ((uint32_t)hv[3] << 16);
+                *reinterpret_cast<uint2*>(orow + d * 32 + g * 8 + hi * 4) = pk;
+            }
+    }
+}
+
+}  // namespace
+
+int launch_attention(const void* q, const void* k, const void* vt, void* out, int B, int H, int ntok,
+                     int npad, int dtype, int causal, float scale, hipStream_t stream) {
+    if (npad % 128 != 0 || npad < ntok) return set_error(LSEG_ERR_INVALID, "attention: npad=%d must be a multiple of 128 and >= ntok=%d", npad, ntok);
+    AttnArgs a;
+    a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.vt = (const uint16_t*)vt; a.out = (uint16_t*)out;
+    a.B = B; a.H = H; a.ntok = ntok; a.npad = npad; a.causal = causal;
+    a.scale_log2e = scale * 1.4426950408889634f;
+    dim3 grid((ntok + 127) / 128, B * H);
+    const size_t lds = 2 * 2 * 8192;
+    if (dtype == DT_BF16) hipLaunchKernelGGL(lseg_attention_kernel<BF16>, grid, dim3(256), lds, stream, a);
+    else if (dtype == DT_F16) hipLaunchKernelGGL(lseg_attention_kernel<F16>, grid, dim3(256), lds, stream, a);
+    else return set_error(LSEG_ERR_INVALID, "attention: dtype %d", dtype);
+    LSEG_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace lseg

@@ -1,0 +1,179 @@
+// capi.hip -- extern "C" surface of liblseg_hip.so (declared in include/lseg_hip.h).
+#include <cstring>
+#include <new>
+
+#include "engine.h"
+
+using namespace lseg;
+
+struct lseg_engine { Engine* e; };
+
+#define GUARD(h) if (!(h) || !(h)->e) return set_error(LSEG_ERR_INVALID, "NULL handle")
+
+static int require_device() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1)
+        return set_error(LSEG_ERR_NO_DEVICE, "no HIP device visible: the LSeg engine has no CPU fallback");
+    return 0;
+}
+
+extern "C" {
+
+int lseg_abi_version(void) { return LSEG_ABI_VERSION; }
+
+int lseg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char* lseg_last_error(lseg_handle h) { (void)h; return last_error(); }
+
+int lseg_create(const lseg_config* cfg, int device, lseg_handle* out) {
+    if (!cfg || !out) return set_error(LSEG_ERR_INVALID, "lseg_create: NULL argument");
+    int r = require_device();
+    if (r) return r;
+    int n = lseg_device_count();
+    if (device < 0 || device >= n) return set_error(LSEG_ERR_NO_DEVICE, "device %d not in [0,%d)", device, n);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return set_error(LSEG_ERR_HIP, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_error(LSEG_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    Engine* e = new (std::nothrow) Engine(*cfg, device);
+    if (!e) return set_error(LSEG_ERR_HIP, "out of host memory");
+    r = e->init();
+    if (r) { delete e; return r; }
+    lseg_engine* h = new (std::nothrow) lseg_engine{e};
+    if (!h) { delete e; return set_error(LSEG_ERR_HIP, "out of host memory"); }
+    *out = h;
+    return LSEG_OK;
+}
+
+int lseg_destroy(lseg_handle h) {
+    if (!h) return LSEG_OK;
+    delete h->e;
+    delete h;
+    return LSEG_OK;
+}
+
+int lseg_bind_param(lseg_handle h, const char* key, const void* dev_ptr, int dtype, const int64_t* shape, int ndim) {
+    GUARD(h);
+    return h->e->bind(key, dev_ptr, dtype, shape, ndim);
+}
+int lseg_finalize_params(lseg_handle h, void* stream) { GUARD(h); return h->e->finalize((hipStream_t)stream); }
+
+int lseg_set_text_tokens(lseg_handle h, const int64_t* host_tokens, int K, int ctx) {
+    GUARD(h);
+    if (!host_tokens) return set_error(LSEG_ERR_INVALID, "tokens NULL");
+    return h->e->set_tokens(host_tokens, K, ctx);
+}
+int lseg_encode_text(lseg_handle h, void* stream) { GUARD(h); return h->e->encode_text((hipStream_t)stream); }
+int lseg_set_text_cache(lseg_handle h, int enabled) { GUARD(h); h->e->text_cache = enabled != 0; return LSEG_OK; }
+int lseg_get_text_features(lseg_handle h, void* dev_out, void* stream) {
+    GUARD(h);
+    if (!dev_out) return set_error(LSEG_ERR_INVALID, "out NULL");
+    return h->e->get_text_features(dev_out, (hipStream_t)stream);
+}
+
+int lseg_forward(lseg_handle h, const float* dev_x, int B, float* dev_logits_out, uint8_t* dev_argmax_out, void* stream) {
+    GUARD(h);
+    return h->e->forward(dev_x, B, dev_logits_out, dev_argmax_out, (hipStream_t)stream);
+}
+
+int lseg_set_debug(lseg_handle h, int enabled) { GUARD(h); h->e->debug = enabled != 0; return LSEG_OK; }
+int lseg_get_intermediate(lseg_handle h, const char* name, float* dev_out, size_t cap, size_t* n, void* stream) {
+    GUARD(h);
+    if (!name || !dev_out) return set_error(LSEG_ERR_INVALID, "NULL argument");
+    return h->e->get_intermediate(name, dev_out, cap, n, (hipStream_t)stream);
+}
+
+int lseg_set_profiling(lseg_handle h, int enabled) { GUARD(h); h->e->profiling = enabled != 0; return LSEG_OK; }
+int lseg_get_profile(lseg_handle h, const char* family, double* total_ms, int64_t* launches, double* flops) {
+    GUARD(h);
+    if (!family) return set_error(LSEG_ERR_INVALID, "family NULL");
+    return h->e->get_profile(family, total_ms, launches, flops);
+}
+
+// ---- single operators -----------------------------------------------------------------------------------
+static int op_dt(int lseg_dt, int* out) {
+    if (lseg_dt == LSEG_F32) { *out = DT_F32; return 0; }
+    if (lseg_dt == LSEG_F16) { *out = DT_F16; return 0; }
+    if (lseg_dt == LSEG_BF16) { *out = DT_BF16; return 0; }
+    return set_error(LSEG_ERR_INVALID, "dtype %d", lseg_dt);
+}
+
+int lseg_op_gemm(const void* A, const void* W, const float* bias, const float* residual, void* C, int M, int N, int K,
+                 int ab_dtype, int out_dtype, int act, void* stream) {
+    int r = require_device(); if (r) return r;
+    int ab, od;
+    if ((r = op_dt(ab_dtype, &ab)) || (r = op_dt(out_dtype, &od))) return r;
+    GemmArgs g;
+    gemm_args_init(g);
+    g.A = (const uint16_t*)A; g.W = (const uint16_t*)W; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K;
+    g.bias = bias; g.act = act;
+    if (residual) { g.res_mode = RES_DEST; g.res = residual; g.res_dtype = DT_F32; }
+    g.C = C; g.out_dtype = od; g.ldc = N; g.map_mode = MAP_LINEAR;
+    return launch_gemm(g, ab, (hipStream_t)stream);
+}
+
+int lseg_op_layernorm(const void* in, int in_dtype, const float* gamma, const float* beta, void* out, int out_dtype,
+                      int M, int D, float eps, void* stream) {
+    int r = require_device(); if (r) return r;
+    int id, od;
+    if ((r = op_dt(in_dtype, &id)) || (r = op_dt(out_dtype, &od))) return r;
+    return launch_layernorm(in, id, gamma, beta, out, od, M, D, eps, (hipStream_t)stream);
+}
+
+int lseg_op_attention(const void* q, const void* k, const void* vt, void* out, int B, int H, int Ntok, int Npad,
+                      int dtype, int causal, float scale, void* stream) {
+    int r = require_device(); if (r) return r;
+    int dt;
+    if ((r = op_dt(dtype, &dt))) return r;
+    return launch_attention(q, k, vt, out, B, H, Ntok, Npad, dt, causal, scale, (hipStream_t)stream);
+}
+
+int lseg_op_conv3x3(const void* in, const void* w_packed, const float* bias, const void* residual, void* out, int B,
+                    int H, int W, int Cin, int Cout, int stride, int relu_in, int relu_out, void* stream) {
+    int r = require_device(); if (r) return r;
+    GemmArgs g;
+    gemm_args_init(g);
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    g.A = (const uint16_t*)in; g.W = (const uint16_t*)w_packed; g.M = B * Ho * Wo; g.N = Cout; g.K = 9 * Cin;
+    g.lda = Cin; g.ldw = 9 * Cin;
+    g.conv = 1; g.cin = Cin; g.hp = H + 2; g.wp = W + 2; g.ho = Ho; g.wo = Wo; g.stride = stride; g.relu_in = relu_in;
+    g.bias = bias; g.act = relu_out ? ACT_RELU : ACT_NONE;
+    if (residual) { g.res_mode = RES_DEST; g.res = residual; g.res_dtype = DT_BF16; }
+    g.C = out; g.out_dtype = DT_BF16; g.ldc = Cout; g.map_mode = MAP_PADDED;
+    return launch_gemm(g, DT_BF16, (hipStream_t)stream);
+}
+
+int lseg_op_upsample2x_nhwc(const void* in, void* out, int B, int H, int W, int C, void* stream) {
+    int r = require_device(); if (r) return r;
+    return launch_upsample2x_nhwc(in, out, B, H, W, C, DT_BF16, (hipStream_t)stream);
+}
+
+int lseg_op_upsample2x_planes(const float* in, float* out, int P, int H, int W, void* stream) {
+    int r = require_device(); if (r) return r;
+    return launch_upsample2x_planes(in, out, P, H, W, (hipStream_t)stream);
+}
+
+int lseg_op_correlation(const float* feat, const void* text_f16, float* logits, int B, int P, int C, int K,
+                        float logit_scale, void* stream) {
+    int r = require_device(); if (r) return r;
+    if (C % 64) return set_error(LSEG_ERR_UNSUPPORTED, "correlation: C=%d must be a multiple of 64", C);
+    const size_t M = (size_t)B * P;
+    uint16_t* a = nullptr;
+    LSEG_HIP_TRY(hipMallocAsync((void**)&a, M * C * sizeof(uint16_t), (hipStream_t)stream));
+    r = launch_l2norm_scale_f16(feat, a, (int)M, C, logit_scale, (hipStream_t)stream);
+    if (!r) {
+        GemmArgs g;
+        gemm_args_init(g);
+        g.A = a; g.W = (const uint16_t*)text_f16; g.M = (int)M; g.N = K; g.K = C; g.lda = C; g.ldw = C;
+        g.round_mid = 1; g.C = logits; g.out_dtype = DT_F32; g.map_mode = MAP_NCHW; g.p_div = P;
+        r = launch_gemm(g, DT_F16, (hipStream_t)stream);
+    }
+    (void)hipFreeAsync(a, (hipStream_t)stream);
+    return r;
+}
+
+}  // extern "C"

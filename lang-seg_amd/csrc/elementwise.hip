@@ -1,0 +1,547 @@
+// elementwise.hip -- the HBM-bound kernels of the LSeg forward (gfx950): LayerNorm, im2col,
+// readout concat, bilinear x2 (NHWC bf16 and NCHW fp32 planes), the L2-norm/scale/fp16 cast
+// in front of the correlation GEMM, text embedding / pooling / normalisation, one-off weight
+// repacking.  All are coalesced 16-byte-per-lane streams (cdna_hip_programming.md G2/G13).
+#include "ops.h"
+#include "../../include/lseg_hip.h"
+
+namespace lseg {
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---- LayerNorm: one wave per row; row cached in registers (D <= 64*4*MAXV) --------------------------
+// [3P] timm norm1/norm2 (eps 1e-6, fp32 in) and CLIP's fp32-computing LayerNorm (eps 1e-5, fp16 in).
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const void* in, int in_dtype, const float* gamma,
+                                                        const float* beta, void* out, int out_dtype,
+                                                        int M, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = D >> 2;                      // float4 groups per row
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int g = lane + 64 * i;
+        if (g < nv) {
+            if (in_dtype == DT_F32) {
+                v[i] = reinterpret_cast<const float4*>((const float*)in + (size_t)row * D)[g];
+            } else {
+                const uint2 u = reinterpret_cast<const uint2*>((const uint16_t*)in + (size_t)row * D)[g];
+                v[i].x = load_as_f32(&u, 0, in_dtype); v[i].y = load_as_f32(&u, 1, in_dtype);
+                v[i].z = load_as_f32(&u, 2, in_dtype); v[i].w = load_as_f32(&u, 3, in_dtype);
+            }
+            s += v[i].x + v[i].y + v[i].z + v[i].w;
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int g = lane + 64 * i;
+        if (g < nv) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += a * a + b * b + c * c + d * d;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int g = lane + 64 * i;
+        if (g < nv) {
+            const float4 ga = reinterpret_cast<const float4*>(gamma)[g];
+            const float4 be = reinterpret_cast<const float4*>(beta)[g];
+            float y[4] = {(v[i].x - mean) * rstd * ga.x + be.x, (v[i].y - mean) * rstd * ga.y + be.y,
+                          (v[i].z - mean) * rstd * ga.z + be.z, (v[i].w - mean) * rstd * ga.w + be.w};
+            if (out_dtype == DT_F32) {
+                reinterpret_cast<float4*>((float*)out + (size_t)row * D)[g] = make_float4(y[0], y[1], y[2], y[3]);
+            } else {
+                uint16_t h[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = out_dtype == DT_F16 ? f32_to_f16(y[e]) : f32_to_bf16(y[e]);
+                uint2 pk;
+                pk.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+                pk.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+                reinterpret_cast<uint2*>((uint16_t*)out + (size_t)row * D)[g] = pk;
+            }
+        }
+    }
+}
+
+// ---- patch im2col: x fp32 NCHW -> A [B*gh*gw, 3*P*P] (k = c*P*P + i*P + j), lseg_vit.py:179 ------
+__global__ void im2col_patch_kernel(const float* x, uint16_t* A, int B, int H, int W, int P, int dtype) {
+    const int gh = H / P, gw = W / P, Kd = 3 * P * P;
+    const size_t total = (size_t)B * gh * gw * (Kd / 8);
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int k8 = (int)(idx % (Kd / 8));
+        const size_t m = idx / (Kd / 8);
+        const int k = k8 * 8;
+        const int c = k / (P * P), rem = k - c * P * P, i = rem / P, j = rem - i * P;
+        const int b = (int)(m / (gh * gw)), p = (int)(m - (size_t)b * gh * gw), py = p / gw, px = p - py * gw;
+        const float* src = x + (((size_t)b * 3 + c) * H + py * P + i) * W + px * P + j;
+        const float4 f0 = reinterpret_cast<const float4*>(src)[0];
+        const float4 f1 = reinterpret_cast<const float4*>(src)[1];
+        const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t lo = dtype == DT_F16 ? f32_to_f16(f[2 * e]) : f32_to_bf16(f[2 * e]);
+            const uint32_t hi = dtype == DT_F16 ? f32_to_f16(f[2 * e + 1]) : f32_to_bf16(f[2 * e + 1]);
+            o[e] = lo | (hi << 16);
+        }
+        reinterpret_cast<uint4*>(A + m * Kd + k)[0] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ---- pos-embed bilinear resize (align_corners=False), lseg_vit.py:149-163; run once per (H,W) ----
+__global__ void pos_resize_kernel(const float* pos, float* out, int g_old, int gh, int gw, int D) {
+    // pos [1 + g_old^2, D] -> out [1 + gh*gw, D]
+    const size_t total = (size_t)(1 + gh * gw) * D;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(idx % D);
+        const int t = (int)(idx / D);
+        if (t == 0) { out[idx] = pos[d]; continue; }
+        const int y = (t - 1) / gw, x = (t - 1) - y * gw;
+        // PyTorch upsample_bilinear2d, align_corners=False: src = max(0, (dst+0.5)*scale - 0.5)
+        const float sy = fmaxf(0.f, ((float)y + 0.5f) * ((float)g_old / (float)gh) - 0.5f);
+        const float sx = fmaxf(0.f, ((float)x + 0.5f) * ((float)g_old / (float)gw) - 0.5f);
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < g_old - 1), x1 = x0 + (x0 < g_old - 1);
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        const float* g = pos + D;   // grid part
+        const float v00 = g[((size_t)y0 * g_old + x0) * D + d], v01 = g[((size_t)y0 * g_old + x1) * D + d];
+        const float v10 = g[((size_t)y1 * g_old + x0) * D + d], v11 = g[((size_t)y1 * g_old + x1) * D + d];
+        out[idx] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+    }
+}
+
+// ---- cls token rows: x[b, 0, :] = cls + pos[0]  (lseg_vit.py:188-193) ---------------------------------
+__global__ void cls_rows_kernel(const float* cls, const float* pos, float* x, int B, int ntok, int D) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * D) return;
+    const int b = idx / D, d = idx - b * D;
+    x[(size_t)b * ntok * D + d] = cls[d] + pos[d];
+}
+
+// ---- ProjectReadout concat (lseg_vit.py:87-88): x fp32 [B,N,D] -> A [B*(N-1), 2D] -----------------------
+__global__ void readout_cat_kernel(const float* x, uint16_t* A, int B, int ntok, int D, int dtype) {
+    const int g8 = 2 * D / 8;
+    const size_t total = (size_t)B * (ntok - 1) * g8;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(idx % g8);
+        const size_t m = idx / g8;
+        const int b = (int)(m / (ntok - 1)), t = (int)(m - (size_t)b * (ntok - 1));
+        const int c = c8 * 8;
+        const float* src = c < D ? x + ((size_t)b * ntok + t + 1) * D + c : x + (size_t)b * ntok * D + (c - D);
+        const float4 f0 = reinterpret_cast<const float4*>(src)[0];
+        const float4 f1 = reinterpret_cast<const float4*>(src)[1];
+        const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t lo = dtype == DT_F16 ? f32_to_f16(f[2 * e]) : f32_to_bf16(f[2 * e]);
+            const uint32_t hi = dtype == DT_F16 ? f32_to_f16(f[2 * e + 1]) : f32_to_bf16(f[2 * e + 1]);
+            o[e] = lo | (hi << 16);
+        }
+        reinterpret_cast<uint4*>(A + m * (size_t)(2 * D) + c)[0] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ---- bilinear x2, align_corners=True, NHWC 16-bit: padded in [B,H+2,W+2,C] -> out [B,2H,2W,C] ------
+// (FeatureFusionBlock_custom.forward, lseg_blocks.py:352-354)
+__global__ void upsample2x_nhwc_kernel(const uint16_t* in, uint16_t* out, int B, int H, int W, int C, int dtype) {
+    const int c8n = C / 8, Ho = 2 * H, Wo = 2 * W;
+    const size_t total = (size_t)B * Ho * Wo * c8n;
+    const float ry = (float)(H - 1) / (float)(Ho - 1), rx = (float)(W - 1) / (float)(Wo - 1);
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(idx % c8n);
+        size_t p = idx / c8n;
+        const int xo = (int)(p % Wo); p /= Wo;
+        const int yo = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        const float sy = ry * (float)yo, sx = rx * (float)xo;
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        const size_t rowp = (size_t)(W + 2) * C;
+        const uint16_t* base = in + (size_t)b * (H + 2) * rowp + (size_t)c8 * 8;
+        const uint4 a00 = *reinterpret_cast<const uint4*>(base + (size_t)(y0 + 1) * rowp + (size_t)(x0 + 1) * C);
+        const uint4 a01 = *reinterpret_cast<const uint4*>(base + (size_t)(y0 + 1) * rowp + (size_t)(x1 + 1) * C);
+        const uint4 a10 = *reinterpret_cast<const uint4*>(base + (size_t)(y1 + 1) * rowp + (size_t)(x0 + 1) * C);
+        const uint4 a11 = *reinterpret_cast<const uint4*>(base + (size_t)(y1 + 1) * rowp + (size_t)(x1 + 1) * C);
+        const uint32_t* p00 = reinterpret_cast<const uint32_t*>(&a00);
+        const uint32_t* p01 = reinterpret_cast<const uint32_t*>(&a01);
+        const uint32_t* p10 = reinterpret_cast<const uint32_t*>(&a10);
+        const uint32_t* p11 = reinterpret_cast<const uint32_t*>(&a11);
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float r[2];
+#pragma unroll
+            for (int hlf = 0; hlf < 2; ++hlf) {
+                const int sh = hlf * 16;
+                const uint16_t u00 = (uint16_t)(p00[e] >> sh), u01 = (uint16_t)(p01[e] >> sh);
+                const uint16_t u10 = (uint16_t)(p10[e] >> sh), u11 = (uint16_t)(p11[e] >> sh);
+                const float v00 = load_as_f32(&u00, 0, dtype), v01 = load_as_f32(&u01, 0, dtype);
+                const float v10 = load_as_f32(&u10, 0, dtype), v11 = load_as_f32(&u11, 0, dtype);
+                r[hlf] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+            }
+            const uint32_t lo = dtype == DT_F16 ? f32_to_f16(r[0]) : f32_to_bf16(r[0]);
+            const uint32_t hi = dtype == DT_F16 ? f32_to_f16(r[1]) : f32_to_bf16(r[1]);
+            o[e] = lo | (hi << 16);
+        }
+        *reinterpret_cast<uint4*>(out + (((size_t)b * Ho + yo) * Wo + xo) * C + (size_t)c8 * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ---- bilinear x2, align_corners=True, fp32 planes [P,H,W] -> [P,2H,2W] (lseg_net.py:203) -----------
+// optional per-plane post-op none.  Each thread writes 4 consecutive outputs (16 B).
+__global__ void upsample2x_planes_kernel(const float* in, float* out, int P, int H, int W) {
+    const int Ho = 2 * H, Wo = 2 * W, w4 = Wo / 4;
+    const size_t total = (size_t)P * Ho * w4;
+    const float ry = (float)(H - 1) / (float)(Ho - 1), rx = (float)(W - 1) / (float)(Wo - 1);
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int x4 = (int)(idx % w4);
+        size_t p = idx / w4;
+        const int yo = (int)(p % Ho);
+        const size_t pl = p / Ho;
+        const float sy = ry * (float)yo;
+        const int y0 = (int)sy, y1 = y0 + (y0 < H - 1);
+        const float ly = sy - (float)y0;
+        const float* r0 = in + (pl * H + y0) * W;
+        const float* r1 = in + (pl * H + y1) * W;
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int xo = x4 * 4 + e;
+            const float sx = rx * (float)xo;
+            const int x0 = (int)sx, x1 = x0 + (x0 < W - 1);
+            const float lx = sx - (float)x0;
+            o[e] = (1.f - ly) * ((1.f - lx) * r0[x0] + lx * r0[x1]) + ly * ((1.f - lx) * r1[x0] + lx * r1[x1]);
+        }
+        reinterpret_cast<float4*>(out + (pl * Ho + yo) * Wo)[x4] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ---- pixel feature normalise + scale + fp16 casts (lseg_net.py:191,194) ----------------------------------
+// a[m,:] = fp16( scale * fp16( f[m,:] / ||f[m,:]||_2 ) )   (fp32 norm, two fp16 roundings).
+template <int MAXV>
+__global__ __launch_bounds__(256) void l2norm_scale_f16_kernel(const float* f, uint16_t* a, int M, int C, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = C >> 2;
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int g = lane + 64 * i;
+        if (g < nv) {
+            v[i] = reinterpret_cast<const float4*>(f + (size_t)row * C)[g];
+            s += v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+        }
+    }
+    const float nrm = sqrtf(wave_sum(s));
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int g = lane + 64 * i;
+        if (g < nv) {
+            const float y[4] = {v[i].x / nrm, v[i].y / nrm, v[i].z / nrm, v[i].w / nrm};
+            uint16_t h[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = f32_to_f16(scale * round_f16(y[e]));
+            uint2 pk;
+            pk.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+            pk.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+            reinterpret_cast<uint2*>(a + (size_t)row * C)[g] = pk;
+        }
+    }
+}
+
+// ---- text: token+positional embedding in fp16 steps ([3P] clip/model.py encode_text) ---------------
+__global__ void text_embed_kernel(const int64_t* tok, const float* emb, const float* pos, uint16_t* x,
+                                  int rows, int L, int W) {
+    const size_t total = (size_t)rows * W;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(idx % W);
+        const int r = (int)(idx / W);
+        const int l = r % L;
+        const float e = round_f16(emb[(size_t)tok[r] * W + d]);
+        const float p = round_f16(pos[(size_t)l * W + d]);
+        x[idx] = f32_to_f16(e + p);
+    }
+}
+// pooled[k,:] = x[k*L + eot[k], :]
+__global__ void text_pool_kernel(const uint16_t* x, const int* eot, uint16_t* pooled, int K, int L, int W) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= K * W) return;
+    const int k = idx / W, d = idx - k * W;
+    pooled[idx] = x[((size_t)k * L + eot[k]) * W + d];
+}
+// t / ||t|| on an fp16 tensor (lseg_net.py:192): norm accumulates in fp32, is rounded to fp16,
+// the quotient is rounded to fp16.  One wave per row.
+__global__ __launch_bounds__(256) void text_l2norm_kernel(const uint16_t* t, uint16_t* out, int K, int C) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= K) return;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) { const float v = f16_to_f32(t[(size_t)row * C + c]); s += v * v; }
+    const float nrm = round_f16(sqrtf(wave_sum(s)));
+    for (int c = lane; c < C; c += 64) out[(size_t)row * C + c] = f32_to_f16(f16_to_f32(t[(size_t)row * C + c]) / nrm);
+}
+
+// ---- one-off parameter repacking -----------------------------------------------------------------------
+// generic strided convert: out[i] = (T) in[i] (any of f32/f16/bf16 -> f32/f16/bf16)
+__global__ void convert_kernel(const void* in, int in_dtype, void* out, int out_dtype, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        store_from_f32(out, i, out_dtype, load_as_f32(in, i, in_dtype));
+}
+// transpose-convert: in [R, C] -> out [C, R]
+__global__ void transpose_convert_kernel(const void* in, int in_dtype, void* out, int out_dtype, int R, int C) {
+    const size_t n = (size_t)R * C;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i / R), r = (int)(i - (size_t)c * R);     // out index i = c*R + r
+        store_from_f32(out, i, out_dtype, load_as_f32(in, (size_t)r * C + c, in_dtype));
+    }
+}
+// conv3x3 weight [Co,Ci,3,3] (+ eval BatchNorm fold) -> [Co, 9*Ci] tap-major; bias_out = beta - mean*s
+// (ResidualConvUnit_custom conv+bn pairs, lseg_blocks.py:276-283)
+__global__ void pack_conv3x3_kernel(const float* w, const float* bn_w, const float* bn_b, const float* bn_m,
+                                    const float* bn_v, float bn_eps, const float* conv_bias, uint16_t* wp,
+                                    float* bias_out, int Co, int Ci, int dtype) {
+    const size_t n = (size_t)Co * 9 * Ci;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Ci);
+        const int tap = (int)((i / Ci) % 9);
+        const int co = (int)(i / ((size_t)9 * Ci));
+        const float s = bn_w ? bn_w[co] * rsqrtf(bn_v[co] + bn_eps) : 1.f;
+        const float v = w[((size_t)co * Ci + ci) * 9 + tap] * s;
+        wp[i] = dtype == DT_F16 ? f32_to_f16(v) : f32_to_bf16(v);
+        if (ci == 0 && tap == 0 && bias_out) {
+            float b = conv_bias ? conv_bias[co] * s : 0.f;
+            if (bn_w) b += bn_b[co] - bn_m[co] * s;
+            bias_out[co] = b;
+        }
+    }
+}
+// ConvTranspose2d(k = s) weight [Ci, Co, s, s] -> GEMM weight [(i*s + j)*Co + co, Ci]
+__global__ void pack_convT_kernel(const float* w, uint16_t* wp, int Ci, int Co, int s, int dtype) {
+    const size_t n = (size_t)s * s * Co * Ci;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(idx % Ci);
+        const size_t row = idx / Ci;
+        const int co = (int)(row % Co);
+        const int ij = (int)(row / Co);
+        const int i = ij / s, j = ij - i * s;
+        const float v = w[(((size_t)ci * Co + co) * s + i) * s + j];
+        wp[idx] = dtype == DT_F16 ? f32_to_f16(v) : f32_to_bf16(v);
+    }
+}
+
+// ---- test taps: NHWC 16-bit (optionally padded) -> NCHW fp32 -------------------------------------------------
+__global__ void nhwc_to_nchw_f32_kernel(const uint16_t* in, float* out, int B, int H, int W, int C, int pad, int dtype) {
+    const size_t n = (size_t)B * C * H * W;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const int c = (int)((i / ((size_t)W * H)) % C);
+        const int b = (int)(i / ((size_t)W * H * C));
+        const size_t src = (((size_t)b * (H + 2 * pad) + y + pad) * (W + 2 * pad) + x + pad) * C + c;
+        out[i] = load_as_f32(in, src, dtype);
+    }
+}
+// fp32 [M, C] rows (pixel-major) -> NCHW fp32
+__global__ void rows_to_nchw_f32_kernel(const float* in, float* out, int B, int HW, int C) {
+    const size_t n = (size_t)B * C * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i % HW);
+        const int c = (int)((i / HW) % C);
+        const int b = (int)(i / ((size_t)HW * C));
+        out[i] = in[((size_t)b * HW + p) * C + c];
+    }
+}
+
+// ---- arch_option 1/2 head blocks on label planes (lseg_net.py:29-79) ----------------------------------------
+// out[b,k,y,x] = act( conv3x3_1ch(in[b,k]) (+ max_k in[b,:,y,x] for the bottleneck) )
+__global__ void head_block_kernel(const float* in, float* out, const float* w9, const float* bias, int B, int K,
+                                  int H, int W, int bottleneck, int act, int apply_act) {
+    const size_t n = (size_t)B * H * W;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const int b = (int)(i / ((size_t)W * H));
+        float mx = -INFINITY;
+        if (bottleneck)
+            for (int k = 0; k < K; ++k) mx = fmaxf(mx, in[(((size_t)b * K + k) * H + y) * W + x]);
+        for (int k = 0; k < K; ++k) {
+            const float* pl = in + ((size_t)b * K + k) * H * W;
+            float acc = bias[0];
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int yy = y + dy, xx = x + dx;
+                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) acc += w9[(dy + 1) * 3 + dx + 1] * pl[(size_t)yy * W + xx];
+                }
+            if (bottleneck) acc += mx;
+            if (apply_act) {
+                if (act == 0) acc = fmaxf(acc, 0.f);
+                else if (act == 1) acc = acc > 0.f ? acc : 0.01f * acc;
+                else acc = tanhf(acc);
+            }
+            out[(((size_t)b * K + k) * H + y) * W + x] = acc;
+        }
+    }
+}
+
+// ---- argmax over K label planes: in fp32 [B,K,HW] -> uint8 [B,HW] (first max wins, like torch.max) ---------
+__global__ void argmax_planes_kernel(const float* in, uint8_t* out, int B, int K, int HW) {
+    const size_t n = (size_t)B * HW;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i % HW);
+        const int b = (int)(i / HW);
+        float best = -INFINITY; int bi = 0;
+        for (int k = 0; k < K; ++k) {
+            const float v = in[((size_t)b * K + k) * HW + p];
+            if (v > best) { best = v; bi = k; }
+        }
+        out[i] = (uint8_t)bi;
+    }
+}
+
+inline int grid_for(size_t total, int block = 256) {
+    size_t g = (total + block - 1) / block;
+    if (g > 256 * 16) g = 256 * 16;      // cap + grid-stride (cdna guide G11)
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+#define CHECK_LAUNCH() LSEG_HIP_TRY(hipGetLastError())
+
+int launch_layernorm(const void* in, int in_dtype, const float* gamma, const float* beta, void* out, int out_dtype,
+                     int M, int D, float eps, hipStream_t st) {
+    if (D % 4 != 0 || D > 64 * 4 * 8) return set_error(LSEG_ERR_UNSUPPORTED, "layernorm: D=%d", D);
+    const int blocks = (M + 3) / 4;
+    if (D <= 256) hipLaunchKernelGGL(layernorm_kernel<1>, dim3(blocks), dim3(256), 0, st, in, in_dtype, gamma, beta, out, out_dtype, M, D, eps);
+    else if (D <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(256), 0, st, in, in_dtype, gamma, beta, out, out_dtype, M, D, eps);
+    else if (D <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, dim3(blocks), dim3(256), 0, st, in, in_dtype, gamma, beta, out, out_dtype, M, D, eps);
+    else hipLaunchKernelGGL(layernorm_kernel<8>, dim3(blocks), dim3(256), 0, st, in, in_dtype, gamma, beta, out, out_dtype, M, D, eps);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_im2col_patch(const float* x, void* A, int B, int H, int W, int P, int dtype, hipStream_t st) {
+    const size_t total = (size_t)B * (H / P) * (W / P) * (3 * P * P / 8);
+    hipLaunchKernelGGL(im2col_patch_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, (uint16_t*)A, B, H, W, P, dtype);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_pos_resize(const float* pos, float* out, int g_old, int gh, int gw, int D, hipStream_t st) {
+    hipLaunchKernelGGL(pos_resize_kernel, dim3(grid_for((size_t)(1 + gh * gw) * D)), dim3(256), 0, st, pos, out, g_old, gh, gw, D);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_cls_rows(const float* cls, const float* pos, float* x, int B, int ntok, int D, hipStream_t st) {
+    hipLaunchKernelGGL(cls_rows_kernel, dim3((B * D + 255) / 256), dim3(256), 0, st, cls, pos, x, B, ntok, D);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_readout_cat(const float* x, void* A, int B, int ntok, int D, int dtype, hipStream_t st) {
+    const size_t total = (size_t)B * (ntok - 1) * (2 * D / 8);
+    hipLaunchKernelGGL(readout_cat_kernel, dim3(grid_for(total)), dim3(256), 0, st, x, (uint16_t*)A, B, ntok, D, dtype);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_upsample2x_nhwc(const void* in, void* out, int B, int H, int W, int C, int dtype, hipStream_t st) {
+    if (C % 8) return set_error(LSEG_ERR_UNSUPPORTED, "upsample2x_nhwc: C=%d", C);
+    const size_t total = (size_t)B * 4 * H * W * (C / 8);
+    hipLaunchKernelGGL(upsample2x_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, st, (const uint16_t*)in, (uint16_t*)out, B, H, W, C, dtype);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_upsample2x_planes(const float* in, float* out, int P, int H, int W, hipStream_t st) {
+    if ((2 * W) % 4) return set_error(LSEG_ERR_UNSUPPORTED, "upsample2x_planes: W=%d", W);
+    const size_t total = (size_t)P * 2 * H * (2 * W / 4);
+    hipLaunchKernelGGL(upsample2x_planes_kernel, dim3(grid_for(total)), dim3(256), 0, st, in, out, P, H, W);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_l2norm_scale_f16(const float* f, void* a, int M, int C, float scale, hipStream_t st) {
+    if (C % 4 != 0 || C > 64 * 4 * 4) return set_error(LSEG_ERR_UNSUPPORTED, "l2norm: C=%d", C);
+    const int blocks = (M + 3) / 4;
+    if (C <= 256) hipLaunchKernelGGL(l2norm_scale_f16_kernel<1>, dim3(blocks), dim3(256), 0, st, f, (uint16_t*)a, M, C, scale);
+    else if (C <= 512) hipLaunchKernelGGL(l2norm_scale_f16_kernel<2>, dim3(blocks), dim3(256), 0, st, f, (uint16_t*)a, M, C, scale);
+    else hipLaunchKernelGGL(l2norm_scale_f16_kernel<4>, dim3(blocks), dim3(256), 0, st, f, (uint16_t*)a, M, C, scale);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_text_embed(const int64_t* tok, const float* emb, const float* pos, void* x, int rows, int L, int W, hipStream_t st) {
+    hipLaunchKernelGGL(text_embed_kernel, dim3(grid_for((size_t)rows * W)), dim3(256), 0, st, tok, emb, pos, (uint16_t*)x, rows, L, W);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_text_pool(const void* x, const int* eot, void* pooled, int K, int L, int W, hipStream_t st) {
+    hipLaunchKernelGGL(text_pool_kernel, dim3((K * W + 255) / 256), dim3(256), 0, st, (const uint16_t*)x, eot, (uint16_t*)pooled, K, L, W);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_text_l2norm(const void* t, void* out, int K, int C, hipStream_t st) {
+    hipLaunchKernelGGL(text_l2norm_kernel, dim3((K + 3) / 4), dim3(256), 0, st, (const uint16_t*)t, (uint16_t*)out, K, C);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_convert(const void* in, int in_dtype, void* out, int out_dtype, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(convert_kernel, dim3(grid_for(n)), dim3(256), 0, st, in, in_dtype, out, out_dtype, n);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_transpose_convert(const void* in, int in_dtype, void* out, int out_dtype, int R, int C, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_convert_kernel, dim3(grid_for((size_t)R * C)), dim3(256), 0, st, in, in_dtype, out, out_dtype, R, C);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_pack_conv3x3(const float* w, const float* bn_w, const float* bn_b, const float* bn_m, const float* bn_v,
+                        float bn_eps, const float* conv_bias, void* wp, float* bias_out, int Co, int Ci, int dtype,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid_for((size_t)Co * 9 * Ci)), dim3(256), 0, st, w, bn_w, bn_b, bn_m, bn_v,
+                       bn_eps, conv_bias, (uint16_t*)wp, bias_out, Co, Ci, dtype);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_pack_convT(const float* w, void* wp, int Ci, int Co, int s, int dtype, hipStream_t st) {
+    hipLaunchKernelGGL(pack_convT_kernel, dim3(grid_for((size_t)s * s * Co * Ci)), dim3(256), 0, st, w, (uint16_t*)wp, Ci, Co, s, dtype);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_nhwc_to_nchw_f32(const void* in, float* out, int B, int H, int W, int C, int pad, int dtype, hipStream_t st) {
+    hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3(grid_for((size_t)B * C * H * W)), dim3(256), 0, st, (const uint16_t*)in, out, B, H, W, C, pad, dtype);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_rows_to_nchw_f32(const float* in, float* out, int B, int HW, int C, hipStream_t st) {
+    hipLaunchKernelGGL(rows_to_nchw_f32_kernel, dim3(grid_for((size_t)B * C * HW)), dim3(256), 0, st, in, out, B, HW, C);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_head_block(const float* in, float* out, const float* w9, const float* bias, int B, int K, int H, int W,
+                      int bottleneck, int act, int apply_act, hipStream_t st) {
+    hipLaunchKernelGGL(head_block_kernel, dim3(grid_for((size_t)B * H * W)), dim3(256), 0, st, in, out, w9, bias, B, K, H, W, bottleneck, act, apply_act);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_argmax_planes(const float* in, uint8_t* out, int B, int K, int HW, hipStream_t st) {
+    hipLaunchKernelGGL(argmax_planes_kernel, dim3(grid_for((size_t)B * HW)), dim3(256), 0, st, in, out, B, K, HW);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace lseg

@@ -1,0 +1,632 @@
+// engine.hip -- whole-forward plan: LSeg.forward (modules/models/lseg_net.py:160-205) as a fixed
+// sequence of gfx950 kernels over engine-owned HBM buffers.
+//
+// Data layout in HBM:
+//   residual stream x      fp32 [B*ntok, D]                    (timm blocks keep fp32 semantics)
+//   MFMA operands          bf16 (image tower) / fp16 (CLIP tower, as the reference runs it)
+//   q,k                    [B*H, Npad, 64] ; v transposed [B*H, 64, Npad]  (written by the QKV GEMM)
+//   DPT feature maps       NHWC 16-bit with a 1-pixel ZERO border ("padded NHWC"): the implicit-
+//                          GEMM 3x3 conv reads its 9 taps with pure address arithmetic, no bounds
+//                          checks; borders are zeroed once at allocation and never written.
+//   pixel features         fp32 [B*h*w, out_c] -> fp16 operand a = fp16(s*fp16(f/|f|)) -> logits
+//                          fp32 [B, K, h*w] (label-major planes) -> x2 bilinear -> [B,K,H,W]
+#include "engine.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace lseg {
+
+// ---- thread-local error string ------------------------------------------------------------------
+static thread_local char g_err[1024] = "";
+int set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+int set_error_hip(hipError_t e, const char* what, const char* file, int line) {
+    snprintf(g_err, sizeof(g_err), "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+    return LSEG_ERR_HIP;
+}
+const char* last_error() { return g_err; }
+
+#define TRY(expr) do { int _r = (expr); if (_r != 0) return _r; } while (0)
+
+static inline int T_code(int lseg_dt) { return lseg_dt == LSEG_F16 ? DT_F16 : DT_BF16; }
+
+Engine::Engine(const lseg_config& c, int dev) : cfg(c), device(dev) {}
+
+Engine::~Engine() {
+    (void)hipSetDevice(device);
+    for (void* p : allocs_) (void)hipFree(p);
+    for (auto e : ev_pool_) (void)hipEventDestroy(e);
+}
+
+void* Engine::dalloc(size_t bytes, bool zero) {
+    void* p = nullptr;
+    if (bytes == 0) bytes = 16;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    if (zero && hipMemset(p, 0, bytes) != hipSuccess) { (void)hipFree(p); return nullptr; }
+    allocs_.push_back(p);
+    return p;
+}
+
+#define ALLOC(ptr, type, count)                                                                  \
+    do {                                                                                         \
+        ptr = (type*)dalloc((size_t)(count) * sizeof(type));                                      \
+        if (!ptr) return set_error(LSEG_ERR_HIP, "hipMalloc of %zu bytes failed (" #ptr ")",     \
+                                   (size_t)(count) * sizeof(type));                              \
+    } while (0)
+
+int Engine::init() {
+    const lseg_config& c = cfg;
+    if (c.abi_version != LSEG_ABI_VERSION) return set_error(LSEG_ERR_INVALID, "config abi_version %d != %d", c.abi_version, LSEG_ABI_VERSION);
+    if (c.dim % c.heads || c.dim / c.heads != 64) return set_error(LSEG_ERR_UNSUPPORTED, "image head_dim must be 64 (dim %d / heads %d)", c.dim, c.heads);
+    if (c.text_width % c.text_heads || c.text_width / c.text_heads != 64) return set_error(LSEG_ERR_UNSUPPORTED, "text head_dim must be 64");
+    if (c.img_h % (2 * c.patch) || c.img_w % (2 * c.patch)) return set_error(LSEG_ERR_INVALID, "image size %dx%d must be a multiple of 2*patch", c.img_h, c.img_w);
+    if (c.dim % 64 || c.features % 64 || c.out_c % 64 || c.text_width % 64 || (3 * c.patch * c.patch) % 64)
+        return set_error(LSEG_ERR_UNSUPPORTED, "dim/features/out_c/text_width must be multiples of 64");
+    for (int l = 0; l < 4; ++l)
+        if (c.reassemble_ch[l] % 64) return set_error(LSEG_ERR_UNSUPPORTED, "reassemble channels %d (level %d) must be a multiple of 64 in this build", c.reassemble_ch[l], l + 1);
+    if (c.max_batch < 1 || c.max_labels < 1) return set_error(LSEG_ERR_INVALID, "max_batch/max_labels");
+    LSEG_HIP_TRY(hipSetDevice(device));
+
+    img_dt_ = T_code(c.image_dtype);
+    gh_ = c.img_h / c.patch; gw_ = c.img_w / c.patch; np_ = gh_ * gw_; ntok_ = np_ + 1;
+    npad_ = ((ntok_ + 127) / 128) * 128;
+    tnpad_ = ((c.text_ctx + 127) / 128) * 128;
+    for (int l = 0; l < 4; ++l) {
+        if (c.resample_kind[l] == LSEG_RS_CONVT) { lh_[l] = gh_ * c.resample_k[l]; lw_[l] = gw_ * c.resample_k[l]; }
+        else if (c.resample_kind[l] == LSEG_RS_IDENTITY) { lh_[l] = gh_; lw_[l] = gw_; }
+        else { lh_[l] = (gh_ - 1) / 2 + 1; lw_[l] = (gw_ - 1) / 2 + 1; }
+    }
+    // the fusion pyramid needs level l to be exactly 2x level l+1 (lseg_blocks.py:345-354)
+    for (int l = 0; l < 3; ++l)
+        if (lh_[l] != 2 * lh_[l + 1] || lw_[l] != 2 * lw_[l + 1])
+            return set_error(LSEG_ERR_UNSUPPORTED, "reassemble pyramid is not a x2 ladder at level %d (%dx%d vs %dx%d)", l + 1, lh_[l], lw_[l], lh_[l + 1], lw_[l + 1]);
+    if (2 * lh_[0] * 2 != c.img_h || 2 * lw_[0] * 2 != c.img_w)
+        return set_error(LSEG_ERR_UNSUPPORTED, "head resolution %dx%d is not img/2", 2 * lh_[0], 2 * lw_[0]);
+
+    const size_t B = c.max_batch, D = c.dim, F = c.features;
+    const size_t M = B * ntok_;
+    ALLOC(x_, float, M * D);
+    ALLOC(ln_, uint16_t, M * D);
+    ALLOC(q_, uint16_t, B * c.heads * npad_ * 64);
+    ALLOC(k_, uint16_t, B * c.heads * npad_ * 64);
+    ALLOC(vt_, uint16_t, B * c.heads * 64 * npad_);
+    ALLOC(att_, uint16_t, M * D);
+    ALLOC(mlp_, uint16_t, M * 4 * D);
+    ALLOC(patchA_, uint16_t, B * np_ * 3 * c.patch * c.patch);
+    ALLOC(catA_, uint16_t, B * np_ * 2 * D);
+    ALLOC(ro_, uint16_t, B * np_ * D);
+    size_t r1max = 0;
+    for (int l = 0; l < 4; ++l) r1max = std::max(r1max, (size_t)c.reassemble_ch[l]);
+    ALLOC(r1_, uint16_t, B * np_ * r1max);
+    ALLOC(tmp_pad_, uint16_t, B * (gh_ + 2) * (gw_ + 2) * r1max);
+    for (int l = 0; l < 4; ++l) {
+        const size_t pp = B * (lh_[l] + 2) * (lw_[l] + 2);
+        ALLOC(L_[l], uint16_t, pp * c.reassemble_ch[l]);
+        ALLOC(rn_[l], uint16_t, pp * F);
+        ALLOC(t1_[l], uint16_t, pp * F);
+        ALLOC(sum_[l], uint16_t, pp * F);
+        ALLOC(t2_[l], uint16_t, pp * F);
+        ALLOC(up_[l], uint16_t, B * 4 * lh_[l] * lw_[l] * F);
+        if (l > 0) ALLOC(path_[l], uint16_t, B * (2 * lh_[l] + 2) * (2 * lw_[l] + 2) * F);   // padded, feeds level l-1
+        else ALLOC(path_[l], uint16_t, B * 4 * lh_[0] * lw_[0] * F);                         // path_1: plain rows
+    }
+    const size_t hw1 = (size_t)4 * lh_[0] * lw_[0];
+    ALLOC(feat_, float, B * hw1 * c.out_c);
+    ALLOC(a16_, uint16_t, B * hw1 * c.out_c);
+    ALLOC(low_, float, B * c.max_labels * hw1);
+    if (c.arch_option == 1 || c.arch_option == 2) {
+        ALLOC(low2_, float, B * c.max_labels * hw1);
+        ALLOC(low3_, float, B * c.max_labels * hw1);
+    }
+    // text
+    const size_t Kl = c.max_labels, L = c.text_ctx, W = c.text_width;
+    ALLOC(d_tok_, int64_t, Kl * L);
+    ALLOC(d_eot_, int, Kl);
+    ALLOC(tx_, uint16_t, Kl * L * W);
+    ALLOC(tln_, uint16_t, Kl * L * W);
+    ALLOC(tq_, uint16_t, Kl * c.text_heads * tnpad_ * 64);
+    ALLOC(tk_, uint16_t, Kl * c.text_heads * tnpad_ * 64);
+    ALLOC(tvt_, uint16_t, Kl * c.text_heads * 64 * tnpad_);
+    ALLOC(tatt_, uint16_t, Kl * L * W);
+    ALLOC(tmlp_, uint16_t, Kl * L * 4 * W);
+    ALLOC(tpool_, uint16_t, Kl * W);
+    ALLOC(tfeat_, uint16_t, Kl * c.out_c);
+    ALLOC(tnorm_, uint16_t, Kl * c.out_c);
+    LSEG_HIP_TRY(hipDeviceSynchronize());
+    inited_ = true;
+    return 0;
+}
+
+int Engine::bind(const char* key, const void* p, int dtype, const int64_t* shape, int ndim) {
+    if (!key || !p || ndim < 0 || ndim > 8) return set_error(LSEG_ERR_INVALID, "bind_param: bad arguments");
+    if (dtype != LSEG_F32 && dtype != LSEG_F16 && dtype != LSEG_BF16 && dtype != LSEG_I64) return set_error(LSEG_ERR_INVALID, "bind_param(%s): dtype %d", key, dtype);
+    BoundParam b;
+    b.ptr = p; b.dtype = dtype;
+    b.shape.assign(shape, shape + ndim);
+    bound_[key] = b;
+    finalized_ = false;
+    return 0;
+}
+
+int Engine::need(const std::string& key, BoundParam& out, std::initializer_list<int64_t> shape) {
+    auto it = bound_.find(key);
+    if (it == bound_.end()) return set_error(LSEG_ERR_MISSING_PARAM, "parameter '%s' was never bound", key.c_str());
+    out = it->second;
+    size_t want = 1;
+    for (auto s : shape) want *= (size_t)s;
+    if (out.numel() != want) return set_error(LSEG_ERR_INVALID, "parameter '%s' has %zu elements, expected %zu", key.c_str(), out.numel(), want);
+    if (out.dtype == LSEG_I64) return set_error(LSEG_ERR_INVALID, "parameter '%s' is int64", key.c_str());
+    return 0;
+}
+
+int Engine::pack_f32(const std::string& key, size_t n, float*& out, hipStream_t st) {
+    BoundParam p;
+    TRY(need(key, p, {(int64_t)n}));
+    if (!out) ALLOC(out, float, n);
+    return launch_convert(p.ptr, p.dtype, out, DT_F32, n, st);
+}
+
+int Engine::pack_linear(const std::string& wkey, const std::string& bkey, int n, int k, int dt, Lin& out, hipStream_t st) {
+    BoundParam w;
+    TRY(need(wkey, w, {n, k}));
+    if (!out.w) ALLOC(out.w, uint16_t, (size_t)n * k);
+    out.n = n; out.k = k;
+    TRY(launch_convert(w.ptr, w.dtype, out.w, dt, (size_t)n * k, st));
+    if (!bkey.empty()) TRY(pack_f32(bkey, n, out.b, st));
+    return 0;
+}
+
+int Engine::pack_conv3(const std::string& wkey, const std::string& bnp, const std::string& bias_key, int co, int ci,
+                       Lin& out, hipStream_t st) {
+    BoundParam w;
+    TRY(need(wkey, w, {co, ci, 3, 3}));
+    if (w.dtype != LSEG_F32) return set_error(LSEG_ERR_UNSUPPORTED, "'%s' must be fp32", wkey.c_str());
+    const float *bw = nullptr, *bb = nullptr, *bm = nullptr, *bv = nullptr, *cb = nullptr;
+    if (!bnp.empty()) {
+        BoundParam a, b, m, v;
+        TRY(need(bnp + ".weight", a, {co})); TRY(need(bnp + ".bias", b, {co}));
+        TRY(need(bnp + ".running_mean", m, {co})); TRY(need(bnp + ".running_var", v, {co}));
+        if (a.dtype != LSEG_F32 || b.dtype != LSEG_F32 || m.dtype != LSEG_F32 || v.dtype != LSEG_F32)
+            return set_error(LSEG_ERR_UNSUPPORTED, "BatchNorm '%s' must be fp32", bnp.c_str());
+        bw = (const float*)a.ptr; bb = (const float*)b.ptr; bm = (const float*)m.ptr; bv = (const float*)v.ptr;
+    }
+    if (!bias_key.empty()) {
+        BoundParam b;
+        TRY(need(bias_key, b, {co}));
+        if (b.dtype != LSEG_F32) return set_error(LSEG_ERR_UNSUPPORTED, "'%s' must be fp32", bias_key.c_str());
+        cb = (const float*)b.ptr;
+    }
+    if (!out.w) ALLOC(out.w, uint16_t, (size_t)co * 9 * ci);
+    const bool has_bias = bw || cb;
+    if (has_bias && !out.b) ALLOC(out.b, float, co);
+    out.n = co; out.k = 9 * ci;
+    return launch_pack_conv3x3((const float*)w.ptr, bw, bb, bm, bv, 1e-5f, cb, out.w, has_bias ? out.b : nullptr, co, ci, img_dt_, st);
+}
+
+int Engine::finalize(hipStream_t st) {
+    if (!inited_) return set_error(LSEG_ERR_STATE, "engine not initialised");
+    LSEG_HIP_TRY(hipSetDevice(device));
+    const lseg_config& c = cfg;
+    const int D = c.dim, F = c.features, P = c.patch;
+    char buf[256];
+    const std::string vm = "pretrained.model.";
+    // ---- ViT --------------------------------------------------------------------------------------------
+    TRY(pack_linear(vm + "patch_embed.proj.weight", vm + "patch_embed.proj.bias", D, 3 * P * P, img_dt_, patch_, st));
+    TRY(pack_f32(vm + "cls_token", D, cls_, st));
+    TRY(pack_f32(vm + "pos_embed", (size_t)(1 + c.pos_grid * c.pos_grid) * D, pos_raw_, st));
+    if (!pos_) ALLOC(pos_, float, (size_t)ntok_ * D);
+    TRY(launch_pos_resize(pos_raw_, pos_, c.pos_grid, gh_, gw_, D, st));     // lseg_vit.py:149-163, once
+    blocks_.resize(c.depth);
+    for (int i = 0; i < c.depth; ++i) {
+        snprintf(buf, sizeof(buf), "%sblocks.%d.", vm.c_str(), i);
+        const std::string b = buf;
+        VitBlock& k = blocks_[i];
+        TRY(pack_f32(b + "norm1.weight", D, k.g1, st)); TRY(pack_f32(b + "norm1.bias", D, k.b1, st));
+        TRY(pack_f32(b + "norm2.weight", D, k.g2, st)); TRY(pack_f32(b + "norm2.bias", D, k.b2, st));
+        TRY(pack_linear(b + "attn.qkv.weight", b + "attn.qkv.bias", 3 * D, D, img_dt_, k.qkv, st));
+        TRY(pack_linear(b + "attn.proj.weight", b + "attn.proj.bias", D, D, img_dt_, k.proj, st));
+        TRY(pack_linear(b + "mlp.fc1.weight", b + "mlp.fc1.bias", 4 * D, D, img_dt_, k.fc1, st));
+        TRY(pack_linear(b + "mlp.fc2.weight", b + "mlp.fc2.bias", D, 4 * D, img_dt_, k.fc2, st));
+    }
+    // ---- readout / reassemble / layer_rn -------------------------------------------------------------
+    for (int l = 0; l < 4; ++l) {
+        snprintf(buf, sizeof(buf), "pretrained.act_postprocess%d.", l + 1);
+        const std::string a = buf;
+        const int C = c.reassemble_ch[l];
+        TRY(pack_linear(a + "0.project.0.weight", a + "0.project.0.bias", D, 2 * D, img_dt_, readout_[l], st));
+        TRY(pack_linear(a + "3.weight", a + "3.bias", C, D, img_dt_, r1x1_[l], st));
+        if (c.resample_kind[l] == LSEG_RS_CONVT) {
+            const int s = c.resample_k[l];
+            BoundParam w;
+            TRY(need(a + "4.weight", w, {C, C, s, s}));
+            if (w.dtype != LSEG_F32) return set_error(LSEG_ERR_UNSUPPORTED, "'%s4.weight' must be fp32", a.c_str());
+            if (!rsmp_[l].w) ALLOC(rsmp_[l].w, uint16_t, (size_t)s * s * C * C);
+            rsmp_[l].n = s * s * C; rsmp_[l].k = C;
+            TRY(launch_pack_convT((const float*)w.ptr, rsmp_[l].w, C, C, s, img_dt_, st));
+            TRY(pack_f32(a + "4.bias", C, rsmp_[l].b, st));
+        } else if (c.resample_kind[l] == LSEG_RS_CONV_S2) {
+            TRY(pack_conv3(a + "4.weight", "", a + "4.bias", C, C, rsmp_[l], st));
+        }
+        snprintf(buf, sizeof(buf), "scratch.layer%d_rn.weight", l + 1);
+        TRY(pack_conv3(buf, "", "", F, C, layer_rn_[l], st));
+    }
+    // ---- refinenets + head ------------------------------------------------------------------------------
+    for (int r = 1; r <= 4; ++r) {
+        snprintf(buf, sizeof(buf), "scratch.refinenet%d.", r);
+        const std::string p = buf;
+        Refine& R = refine_[r - 1];
+        TRY(pack_linear(p + "out_conv.weight", p + "out_conv.bias", F, F, img_dt_, R.out_conv, st));
+        for (int u = 1; u <= 2; ++u) {
+            if (u == 1 && r == 4) continue;      // refinenet4.resConfUnit1 never runs (lseg_net.py:176)
+            const std::string q = p + "resConfUnit" + std::to_string(u) + ".";
+            Rcu& U = u == 1 ? R.u1 : R.u2;
+            TRY(pack_conv3(q + "conv1.weight", q + "bn1", "", F, F, U.c1, st));
+            TRY(pack_conv3(q + "conv2.weight", q + "bn2", "", F, F, U.c2, st));
+        }
+        R.has_u1 = r != 4;
+    }
+    TRY(pack_linear("scratch.head1.weight", "scratch.head1.bias", c.out_c, F, img_dt_, head1_, st));
+    if (c.arch_option == 1 || c.arch_option == 2) {
+        TRY(pack_f32("scratch.head_block.depthwise.depthwise.weight", 9, hb_w_, st));
+        TRY(pack_f32("scratch.head_block.depthwise.depthwise.bias", 1, hb_b_, st));
+    }
+    // ---- CLIP text tower ([3P] clip/model.py) -----------------------------------------------------------
+    const std::string cp = "clip_pretrained.";
+    const int W = c.text_width;
+    TRY(pack_f32(cp + "token_embedding.weight", (size_t)c.text_vocab * W, tok_emb_, st));
+    TRY(pack_f32(cp + "positional_embedding", (size_t)c.text_ctx * W, tpos_, st));
+    tblocks_.resize(c.text_layers);
+    for (int i = 0; i < c.text_layers; ++i) {
+        snprintf(buf, sizeof(buf), "%stransformer.resblocks.%d.", cp.c_str(), i);
+        const std::string b = buf;
+        TextBlock& k = tblocks_[i];
+        TRY(pack_f32(b + "ln_1.weight", W, k.g1, st)); TRY(pack_f32(b + "ln_1.bias", W, k.b1, st));
+        TRY(pack_f32(b + "ln_2.weight", W, k.g2, st)); TRY(pack_f32(b + "ln_2.bias", W, k.b2, st));
+        TRY(pack_linear(b + "attn.in_proj_weight", b + "attn.in_proj_bias", 3 * W, W, DT_F16, k.qkv, st));
+        TRY(pack_linear(b + "attn.out_proj.weight", b + "attn.out_proj.bias", W, W, DT_F16, k.out, st));
+        TRY(pack_linear(b + "mlp.c_fc.weight", b + "mlp.c_fc.bias", 4 * W, W, DT_F16, k.fc, st));
+        TRY(pack_linear(b + "mlp.c_proj.weight", b + "mlp.c_proj.bias", W, 4 * W, DT_F16, k.proj, st));
+    }
+    TRY(pack_f32(cp + "ln_final.weight", W, tlnf_g_, st));
+    TRY(pack_f32(cp + "ln_final.bias", W, tlnf_b_, st));
+    {
+        BoundParam tp;
+        TRY(need(cp + "text_projection", tp, {W, c.out_c}));
+        if (!tproj_.w) ALLOC(tproj_.w, uint16_t, (size_t)W * c.out_c);
+        tproj_.n = c.out_c; tproj_.k = W;
+        TRY(launch_transpose_convert(tp.ptr, tp.dtype, tproj_.w, DT_F16, W, c.out_c, st));   // x @ P == x @ (P^T)^T
+    }
+    LSEG_HIP_TRY(hipStreamSynchronize(st));      // the caller may now free/modify its tensors
+    finalized_ = true;
+    text_valid = false;
+    return 0;
+}
+
+int Engine::set_tokens(const int64_t* tok, int K, int ctx) {
+    if (!inited_) return set_error(LSEG_ERR_STATE, "engine not initialised");
+    if (K < 1 || K > cfg.max_labels) return set_error(LSEG_ERR_INVALID, "K=%d outside [1, max_labels=%d]", K, cfg.max_labels);
+    if (ctx != cfg.text_ctx) return set_error(LSEG_ERR_INVALID, "token context %d != %d", ctx, cfg.text_ctx);
+    LSEG_HIP_TRY(hipSetDevice(device));
+    std::vector<int> eot(K);
+    for (int k = 0; k < K; ++k) {
+        // text.argmax(dim=-1): first occurrence of the row maximum ([3P] clip/model.py encode_text)
+        int best = 0;
+        for (int l = 0; l < ctx; ++l) {
+            const int64_t v = tok[(size_t)k * ctx + l];
+            if (v < 0 || v >= cfg.text_vocab) return set_error(LSEG_ERR_INVALID, "token id %lld out of range at [%d,%d]", (long long)v, k, l);
+            if (v > tok[(size_t)k * ctx + best]) best = l;
+        }
+        eot[k] = best;
+    }
+    LSEG_HIP_TRY(hipMemcpy(d_tok_, tok, (size_t)K * ctx * sizeof(int64_t), hipMemcpyHostToDevice));
+    LSEG_HIP_TRY(hipMemcpy(d_eot_, eot.data(), (size_t)K * sizeof(int), hipMemcpyHostToDevice));
+    K_ = K;
+    text_valid = false;
+    return 0;
+}
+
+// clip_pretrained.encode_text(text) + the fp16 L2 normalisation (lseg_net.py:183,192)
+int Engine::encode_text(hipStream_t st) {
+    if (!finalized_) return set_error(LSEG_ERR_STATE, "parameters not finalised");
+    if (K_ < 1) return set_error(LSEG_ERR_STATE, "no text tokens set");
+    const lseg_config& c = cfg;
+    const int L = c.text_ctx, W = c.text_width, H = c.text_heads, M = K_ * L;
+    TRY(launch_text_embed(d_tok_, tok_emb_, tpos_, tx_, M, L, W, st));
+    GemmArgs g;
+    for (int i = 0; i < c.text_layers; ++i) {
+        TextBlock& b = tblocks_[i];
+        TRY(launch_layernorm(tx_, DT_F16, b.g1, b.b1, tln_, DT_F16, M, W, 1e-5f, st));
+        gemm_args_init(g);
+        g.A = tln_; g.W = b.qkv.w; g.M = M; g.N = 3 * W; g.K = W; g.lda = W; g.ldw = W;
+        g.bias = b.qkv.b; g.out_dtype = DT_F16; g.map_mode = MAP_QKV;
+        g.C = tq_; g.Ck = tk_; g.Cv = tvt_; g.qkv_dim = W; g.qkv_ntok = L; g.qkv_npad = tnpad_; g.qkv_heads = H;
+        TRY(launch_gemm(g, DT_F16, st));
+        TRY(launch_attention(tq_, tk_, tvt_, tatt_, K_, H, L, tnpad_, DT_F16, 1, 0.125f, st));
+        gemm_args_init(g);
+        g.A = tatt_; g.W = b.out.w; g.M = M; g.N = W; g.K = W; g.lda = W; g.ldw = W;
+        g.bias = b.out.b; g.round_mid = 1; g.res_mode = RES_DEST; g.res = tx_; g.res_dtype = DT_F16;
+        g.C = tx_; g.out_dtype = DT_F16; g.ldc = W; g.map_mode = MAP_LINEAR;
+        TRY(launch_gemm(g, DT_F16, st));
+        TRY(launch_layernorm(tx_, DT_F16, b.g2, b.b2, tln_, DT_F16, M, W, 1e-5f, st));
+        gemm_args_init(g);
+        g.A = tln_; g.W = b.fc.w; g.M = M; g.N = 4 * W; g.K = W; g.lda = W; g.ldw = W;
+        g.bias = b.fc.b; g.round_mid = 1; g.act = ACT_QUICKGELU;
+        g.C = tmlp_; g.out_dtype = DT_F16; g.ldc = 4 * W; g.map_mode = MAP_LINEAR;
+        TRY(launch_gemm(g, DT_F16, st));
+        gemm_args_init(g);
+        g.A = tmlp_; g.W = b.proj.w; g.M = M; g.N = W; g.K = 4 * W; g.lda = 4 * W; g.ldw = 4 * W;
+        g.bias = b.proj.b; g.round_mid = 1; g.res_mode = RES_DEST; g.res = tx_; g.res_dtype = DT_F16;
+        g.C = tx_; g.out_dtype = DT_F16; g.ldc = W; g.map_mode = MAP_LINEAR;
+        TRY(launch_gemm(g, DT_F16, st));
+    }
+    TRY(launch_layernorm(tx_, DT_F16, tlnf_g_, tlnf_b_, tln_, DT_F16, M, W, 1e-5f, st));
+    TRY(launch_text_pool(tln_, d_eot_, tpool_, K_, L, W, st));
+    gemm_args_init(g);
+    g.A = tpool_; g.W = tproj_.w; g.M = K_; g.N = c.out_c; g.K = W; g.lda = W; g.ldw = W;
+    g.C = tfeat_; g.out_dtype = DT_F16; g.ldc = c.out_c; g.map_mode = MAP_LINEAR;
+    TRY(launch_gemm(g, DT_F16, st));
+    TRY(launch_text_l2norm(tfeat_, tnorm_, K_, c.out_c, st));
+    text_valid = true;
+    return 0;
+}
+
+int Engine::conv3x3(const void* in, const Lin& w, const void* res, const void* res2, void* out, int B, int H, int W,
+                    int stride, int relu_in, int relu_out, hipStream_t st) {
+    // in: padded NHWC [B,H+2,W+2,Cin]; out: padded NHWC [B,Ho+2,Wo+2,Cout]
+    GemmArgs g;
+    gemm_args_init(g);
+    const int Cin = w.k / 9, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    g.A = (const uint16_t*)in; g.W = w.w; g.M = B * Ho * Wo; g.N = w.n; g.K = w.k; g.lda = Cin; g.ldw = w.k;
+    g.conv = 1; g.cin = Cin; g.hp = H + 2; g.wp = W + 2; g.ho = Ho; g.wo = Wo; g.stride = stride; g.relu_in = relu_in;
+    g.bias = w.b; g.act = relu_out ? ACT_RELU : ACT_NONE;
+    if (res) { g.res_mode = RES_DEST; g.res = res; g.res_dtype = img_dt_; g.res2 = res2; }
+    g.C = out; g.out_dtype = img_dt_; g.ldc = w.n; g.map_mode = MAP_PADDED;
+    return launch_gemm(g, img_dt_, st);
+}
+
+// FeatureFusionBlock_custom.forward (lseg_blocks.py:337-358) for refinenet r (4..1)
+int Engine::refine(int r, int B, hipStream_t st) {
+    const int l = r - 1, H = lh_[l], W = lw_[l], F = cfg.features;
+    Refine& R = refine_[l];
+    const uint16_t* rcu2_in;
+    if (R.has_u1) {
+        // output = path_{r+1} + resConfUnit1(layer_r_rn)   (:345-347), RCU: lseg_blocks.py:265-288
+        TRY(conv3x3(rn_[l], R.u1.c1, nullptr, nullptr, t1_[l], B, H, W, 1, 1, 1, st));
+        TRY(conv3x3(t1_[l], R.u1.c2, rn_[l], path_[l + 1], sum_[l], B, H, W, 1, 0, 0, st));
+        rcu2_in = sum_[l];
+    } else {
+        rcu2_in = rn_[l];
+    }
+    TRY(conv3x3(rcu2_in, R.u2.c1, nullptr, nullptr, t1_[l], B, H, W, 1, 1, 1, st));
+    TRY(conv3x3(t1_[l], R.u2.c2, rcu2_in, nullptr, t2_[l], B, H, W, 1, 0, 0, st));
+    TRY(launch_upsample2x_nhwc(t2_[l], up_[l], B, H, W, F, img_dt_, st));               // :352-354
+    GemmArgs g;
+    gemm_args_init(g);                                                                 // out_conv :356
+    g.A = up_[l]; g.W = R.out_conv.w; g.M = B * 4 * H * W; g.N = F; g.K = F; g.lda = F; g.ldw = F;
+    g.bias = R.out_conv.b; g.C = path_[l]; g.out_dtype = img_dt_; g.ldc = F;
+    if (l > 0) { g.map_mode = MAP_PADDED; g.ho = 2 * H; g.wo = 2 * W; }
+    else g.map_mode = MAP_LINEAR;
+    return launch_gemm(g, img_dt_, st);
+}
+
+hipEvent_t Engine::get_event() {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    ev_pool_.push_back(e);
+    return e;
+}
+
+int Engine::flush_events() {
+    auto drain = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, ProfileSlot& s) -> int {
+        for (auto& p : v) {
+            LSEG_HIP_TRY(hipEventSynchronize(p.second));
+            float ms = 0.f;
+            LSEG_HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
+            s.total_ms += ms; s.launches += 1;
+        }
+        v.clear();
+        return 0;
+    };
+    TRY(drain(ev_fc1_, prof_fc1_));
+    TRY(drain(ev_fwd_, prof_fwd_));
+    for (auto e : ev_pool_) (void)hipEventDestroy(e);
+    ev_pool_.clear();
+    return 0;
+}
+
+int Engine::get_profile(const char* family, double* ms, int64_t* launches, double* flops) {
+    TRY(flush_events());
+    ProfileSlot* s = nullptr;
+    if (!strcmp(family, "mlp_fc1")) s = &prof_fc1_;
+    else if (!strcmp(family, "forward")) s = &prof_fwd_;
+    else return set_error(LSEG_ERR_INVALID, "unknown profile family '%s'", family);
+    if (ms) *ms = s->total_ms;
+    if (launches) *launches = s->launches;
+    if (flops) *flops = s->flops;
+    return 0;
+}
+
+int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out, hipStream_t st) {
+    if (!finalized_) return set_error(LSEG_ERR_STATE, "parameters not finalised (call lseg_finalize_params)");
+    if (K_ < 1) return set_error(LSEG_ERR_STATE, "no text tokens set (call lseg_set_text_tokens)");
+    if (B < 1 || B > cfg.max_batch) return set_error(LSEG_ERR_INVALID, "B=%d outside [1, max_batch=%d]", B, cfg.max_batch);
+    if (!x_in) return set_error(LSEG_ERR_INVALID, "x is NULL");
+    LSEG_HIP_TRY(hipSetDevice(device));
+    const lseg_config& c = cfg;
+    const int D = c.dim, H = c.heads, F = c.features, M = B * ntok_;
+    last_B_ = B;
+    hipEvent_t fwd0 = nullptr, fwd1 = nullptr;
+    if (profiling) { fwd0 = get_event(); fwd1 = get_event(); if (fwd0) (void)hipEventRecord(fwd0, st); }
+
+    // ---- forward_flex (lseg_vit.py:166-201): patch embed + cls + pos -------------------------------------
+    TRY(launch_im2col_patch(x_in, patchA_, B, c.img_h, c.img_w, c.patch, img_dt_, st));
+    GemmArgs g;
+    gemm_args_init(g);
+    g.A = patchA_; g.W = patch_.w; g.M = B * np_; g.N = D; g.K = patch_.k; g.lda = patch_.k; g.ldw = patch_.k;
+    g.bias = patch_.b; g.res_mode = RES_PERIODIC; g.res = pos_; g.res_dtype = DT_F32; g.ldr = D;
+    g.C = x_; g.out_dtype = DT_F32; g.ldc = D; g.map_mode = MAP_PERIODIC; g.p_div = np_; g.p_mul = ntok_; g.p_off = 1;
+    TRY(launch_gemm(g, img_dt_, st));
+    TRY(launch_cls_rows(cls_, pos_, x_, B, ntok_, D, st));
+
+    // ---- 24 x timm Block; hooks feed readout/reassemble/layer_rn immediately ------------------------------
+    for (int i = 0; i < c.depth; ++i) {
+        VitBlock& b = blocks_[i];
+        TRY(launch_layernorm(x_, DT_F32, b.g1, b.b1, ln_, img_dt_, M, D, 1e-6f, st));
+        gemm_args_init(g);
+        g.A = ln_; g.W = b.qkv.w; g.M = M; g.N = 3 * D; g.K = D; g.lda = D; g.ldw = D;
+        g.bias = b.qkv.b; g.out_dtype = img_dt_; g.map_mode = MAP_QKV;
+        g.C = q_; g.Ck = k_; g.Cv = vt_; g.qkv_dim = D; g.qkv_ntok = ntok_; g.qkv_npad = npad_; g.qkv_heads = H;
+        TRY(launch_gemm(g, img_dt_, st));
+        TRY(launch_attention(q_, k_, vt_, att_, B, H, ntok_, npad_, img_dt_, 0, 0.125f, st));
+        gemm_args_init(g);
+        g.A = att_; g.W = b.proj.w; g.M = M; g.N = D; g.K = D; g.lda = D; g.ldw = D;
+        g.bias = b.proj.b; g.res_mode = RES_DEST; g.res = x_; g.res_dtype = DT_F32;
+        g.C = x_; g.out_dtype = DT_F32; g.ldc = D; g.map_mode = MAP_LINEAR;
+        TRY(launch_gemm(g, img_dt_, st));
+        TRY(launch_layernorm(x_, DT_F32, b.g2, b.b2, ln_, img_dt_, M, D, 1e-6f, st));
+        gemm_args_init(g);
+        g.A = ln_; g.W = b.fc1.w; g.M = M; g.N = 4 * D; g.K = D; g.lda = D; g.ldw = D;
+        g.bias = b.fc1.b; g.act = ACT_GELU; g.C = mlp_; g.out_dtype = img_dt_; g.ldc = 4 * D; g.map_mode = MAP_LINEAR;
+        g.tag = 1;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (profiling) { e0 = get_event(); e1 = get_event(); if (e0) (void)hipEventRecord(e0, st); }
+        TRY(launch_gemm(g, img_dt_, st));
+        if (profiling && e0 && e1) { (void)hipEventRecord(e1, st); ev_fc1_.push_back({e0, e1}); prof_fc1_.flops = 2.0 * M * 4.0 * D * D; }
+        gemm_args_init(g);
+        g.A = mlp_; g.W = b.fc2.w; g.M = M; g.N = D; g.K = 4 * D; g.lda = 4 * D; g.ldw = 4 * D;
+        g.bias = b.fc2.b; g.res_mode = RES_DEST; g.res = x_; g.res_dtype = DT_F32;
+        g.C = x_; g.out_dtype = DT_F32; g.ldc = D; g.map_mode = MAP_LINEAR;
+        TRY(launch_gemm(g, img_dt_, st));
+
+        for (int l = 0; l < 4; ++l) {
+            if (c.hooks[l] != i) continue;
+            if (debug) {
+                if (!acts_[l]) ALLOC(acts_[l], float, (size_t)c.max_batch * ntok_ * D);
+                LSEG_HIP_TRY(hipMemcpyAsync(acts_[l], x_, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+            }
+            const int C = c.reassemble_ch[l];
+            // ProjectReadout (lseg_vit.py:86-90)
+            TRY(launch_readout_cat(x_, catA_, B, ntok_, D, img_dt_, st));
+            gemm_args_init(g);
+            g.A = catA_; g.W = readout_[l].w; g.M = B * np_; g.N = D; g.K = 2 * D; g.lda = 2 * D; g.ldw = 2 * D;
+            g.bias = readout_[l].b; g.act = ACT_GELU; g.C = ro_; g.out_dtype = img_dt_; g.ldc = D; g.map_mode = MAP_LINEAR;
+            TRY(launch_gemm(g, img_dt_, st));
+            // act_postprocess[3]: 1x1 conv (token-major rows == NHWC pixels, the Transpose/Unflatten are free)
+            gemm_args_init(g);
+            g.A = ro_; g.W = r1x1_[l].w; g.M = B * np_; g.N = C; g.K = D; g.lda = D; g.ldw = D;
+            g.bias = r1x1_[l].b; g.out_dtype = img_dt_; g.ldc = C;
+            if (c.resample_kind[l] == LSEG_RS_CONVT) { g.C = r1_; g.map_mode = MAP_LINEAR; }
+            else if (c.resample_kind[l] == LSEG_RS_IDENTITY) { g.C = L_[l]; g.map_mode = MAP_PADDED; g.ho = gh_; g.wo = gw_; }
+            else { g.C = tmp_pad_; g.map_mode = MAP_PADDED; g.ho = gh_; g.wo = gw_; }
+            TRY(launch_gemm(g, img_dt_, st));
+            if (c.resample_kind[l] == LSEG_RS_CONVT) {
+                // ConvTranspose2d(k = s = stride) as a GEMM with a pixel-shuffle scatter epilogue
+                const int s = c.resample_k[l];
+                gemm_args_init(g);
+                g.A = r1_; g.W = rsmp_[l].w; g.M = B * np_; g.N = s * s * C; g.K = C; g.lda = C; g.ldw = C;
+                g.bias = rsmp_[l].b; g.bias_mod = C; g.C = L_[l]; g.out_dtype = img_dt_; g.ldc = C;
+                g.map_mode = MAP_PIXSHUF; g.ho = gh_; g.wo = gw_; g.ps_s = s; g.ps_C = C;
+                TRY(launch_gemm(g, img_dt_, st));
+            } else if (c.resample_kind[l] == LSEG_RS_CONV_S2) {
+                TRY(conv3x3(tmp_pad_, rsmp_[l], nullptr, nullptr, L_[l], B, gh_, gw_, 2, 0, 0, st));
+            }
+            // scratch.layerN_rn (lseg_net.py:171-174)
+            TRY(conv3x3(L_[l], layer_rn_[l], nullptr, nullptr, rn_[l], B, lh_[l], lw_[l], 1, 0, 0, st));
+        }
+    }
+
+    // ---- refinenet4..1 (lseg_net.py:176-179) ---------------------------------------------------------------
+    for (int r = 4; r >= 1; --r) TRY(refine(r, B, st));
+
+    // ---- text tower (lseg_net.py:181-183): re-run every call unless caching is on --------------------------
+    if (!text_cache || !text_valid) TRY(encode_text(st));
+
+    // ---- head1 + normalise + correlation (lseg_net.py:185-196) ------------------------------------------------
+    const int h1 = 2 * lh_[0], w1 = 2 * lw_[0], hw1 = h1 * w1, Mp = B * hw1;
+    gemm_args_init(g);
+    g.A = path_[0]; g.W = head1_.w; g.M = Mp; g.N = c.out_c; g.K = F; g.lda = F; g.ldw = F;
+    g.bias = head1_.b; g.C = feat_; g.out_dtype = DT_F32; g.ldc = c.out_c; g.map_mode = MAP_LINEAR;
+    TRY(launch_gemm(g, img_dt_, st));
+    const float logit_scale = expf(logf(1.0f / 0.07f));                // lseg_net.py:141
+    TRY(launch_l2norm_scale_f16(feat_, a16_, Mp, c.out_c, logit_scale, st));
+    gemm_args_init(g);
+    g.A = a16_; g.W = tnorm_; g.M = Mp; g.N = K_; g.K = c.out_c; g.lda = c.out_c; g.ldw = c.out_c;
+    g.round_mid = 1; g.C = low_; g.out_dtype = DT_F32; g.map_mode = MAP_NCHW; g.p_div = hw1;
+    TRY(launch_gemm(g, DT_F16, st));
+    float* low = low_;
+    if (c.arch_option == 1 || c.arch_option == 2) {                    // lseg_net.py:198-201
+        const int bott = c.arch_option == 1;
+        float* src = low_; float* dst = low2_;           // low_ stays intact (the "lowres" tap)
+        for (int d = 0; d < c.block_depth - 1; ++d) {
+            TRY(launch_head_block(src, dst, hb_w_, hb_b_, B, K_, h1, w1, bott, c.activation, 1, st));
+            src = dst; dst = (dst == low2_) ? low3_ : low2_;
+        }
+        TRY(launch_head_block(src, dst, hb_w_, hb_b_, B, K_, h1, w1, bott, c.activation, 0, st));
+        low = dst;
+    }
+    if (argmax_out && K_ > 256) return set_error(LSEG_ERR_UNSUPPORTED, "uint8 argmax needs K <= 256 (K=%d)", K_);
+    if (argmax_out) TRY(launch_argmax_planes(low, argmax_out, B, K_, hw1, st));
+    // ---- scratch.output_conv: bilinear x2, align_corners=True (lseg_net.py:203) ----------------------------------
+    if (logits) TRY(launch_upsample2x_planes(low, logits, B * K_, h1, w1, st));
+    if (profiling && fwd0 && fwd1) { (void)hipEventRecord(fwd1, st); ev_fwd_.push_back({fwd0, fwd1}); }
+    return 0;
+}
+
+int Engine::get_text_features(void* out, hipStream_t st) {
+    if (!text_valid) return set_error(LSEG_ERR_STATE, "text features not computed yet");
+    LSEG_HIP_TRY(hipMemcpyAsync(out, tnorm_, (size_t)K_ * cfg.out_c * 2, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+int Engine::get_intermediate(const char* name, float* out, size_t cap, size_t* n, hipStream_t st) {
+    if (last_B_ < 1) return set_error(LSEG_ERR_STATE, "no forward has run");
+    const int B = last_B_, F = cfg.features;
+    size_t need_n = 0;
+    if (!strncmp(name, "act", 3) && name[3] >= '1' && name[3] <= '4' && !name[4]) {
+        const int l = name[3] - '1';
+        if (!acts_[l]) return set_error(LSEG_ERR_STATE, "activation taps need lseg debug mode on before forward");
+        need_n = (size_t)B * ntok_ * cfg.dim;
+        if (cap < need_n) return set_error(LSEG_ERR_INVALID, "buffer too small: %zu < %zu", cap, need_n);
+        LSEG_HIP_TRY(hipMemcpyAsync(out, acts_[l], need_n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else if (!strncmp(name, "path", 4) && name[4] >= '1' && name[4] <= '4' && !name[5]) {
+        const int l = name[4] - '1';
+        const int H = 2 * lh_[l], W = 2 * lw_[l];
+        need_n = (size_t)B * F * H * W;
+        if (cap < need_n) return set_error(LSEG_ERR_INVALID, "buffer too small: %zu < %zu", cap, need_n);
+        TRY(launch_nhwc_to_nchw_f32(path_[l], out, B, H, W, F, l > 0 ? 1 : 0, img_dt_, st));
+    } else if (!strncmp(name, "rn", 2) && name[2] >= '1' && name[2] <= '4' && !name[3]) {
+        const int l = name[2] - '1';
+        need_n = (size_t)B * F * lh_[l] * lw_[l];
+        if (cap < need_n) return set_error(LSEG_ERR_INVALID, "buffer too small: %zu < %zu", cap, need_n);
+        TRY(launch_nhwc_to_nchw_f32(rn_[l], out, B, lh_[l], lw_[l], F, 1, img_dt_, st));
+    } else if (!strncmp(name, "layer", 5) && name[5] >= '1' && name[5] <= '4' && !name[6]) {
+        const int l = name[5] - '1';
+        need_n = (size_t)B * cfg.reassemble_ch[l] * lh_[l] * lw_[l];
+        if (cap < need_n) return set_error(LSEG_ERR_INVALID, "buffer too small: %zu < %zu", cap, need_n);
+        TRY(launch_nhwc_to_nchw_f32(L_[l], out, B, lh_[l], lw_[l], cfg.reassemble_ch[l], 1, img_dt_, st));
+    } else if (!strcmp(name, "image_features")) {
+        const int hw1 = 4 * lh_[0] * lw_[0];
+        need_n = (size_t)B * cfg.out_c * hw1;
+        if (cap < need_n) return set_error(LSEG_ERR_INVALID, "buffer too small: %zu < %zu", cap, need_n);
+        TRY(launch_rows_to_nchw_f32(feat_, out, B, hw1, cfg.out_c, st));
+    } else if (!strcmp(name, "lowres")) {
+        const int hw1 = 4 * lh_[0] * lw_[0];
+        need_n = (size_t)B * K_ * hw1;
+        if (cap < need_n) return set_error(LSEG_ERR_INVALID, "buffer too small: %zu < %zu", cap, need_n);
+        LSEG_HIP_TRY(hipMemcpyAsync(out, low_, need_n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else {
+        return set_error(LSEG_ERR_INVALID, "unknown intermediate '%s'", name);
+    }
+    if (n) *n = need_n;
+    return 0;
+}
+
+}  // namespace lseg

@@ -1,0 +1,55 @@
+// gemm.h -- argument block of the MFMA GEMM / implicit-GEMM-conv kernel family.
+#pragma once
+#include "common.h"
+
+namespace lseg {
+
+enum Act { ACT_NONE = 0, ACT_GELU = 1, ACT_QUICKGELU = 2, ACT_RELU = 3 };
+
+// Where output element (m, n) goes.
+enum MapMode {
+    MAP_LINEAR = 0,   // C[m*ldc + n]
+    MAP_PERIODIC = 1, // row' = (m / p_div) * p_mul + (m % p_div) + p_off ; C[row'*ldc + n]
+    MAP_PADDED = 2,   // m=(b,y,x) on (Ho,Wo): NHWC with a 1-pixel zero border, C channels = ldc
+    MAP_PIXSHUF = 3,  // ConvTranspose k=s: m=(b,y,x) on (Ho,Wo); n=(i*s+j)*ps_C+co -> padded NHWC
+                      // [b, y*s+i+1, x*s+j+1, co] of a (Ho*s+2, Wo*s+2) map
+    MAP_QKV = 4,      // n=(which, head, d), m=(b,t): q,k -> [b,head,t,d] ; v -> [b,head,d,t]
+    MAP_NCHW = 5,     // m=(b,p), P=p_div pixels: C[(b*N + n)*P + p]  (label-major logits planes)
+};
+enum ResMode { RES_NONE = 0, RES_DEST = 1, RES_PERIODIC = 2 };
+
+struct GemmArgs {
+    // operands: A activations, W weights [N, K] row-major (PyTorch Linear layout)
+    const uint16_t* A;
+    const uint16_t* W;
+    int M, N, K;
+    int lda, ldw;
+    // implicit-GEMM conv (A is padded NHWC [B, Hp, Wp, Cin]); K = taps * Cin
+    int conv;               // 0 plain, 1 conv
+    int cin, hp, wp;        // padded input geometry
+    int ho, wo;             // output spatial size (also used by MAP_PADDED / MAP_PIXSHUF)
+    int stride;             // conv stride (1|2)
+    int relu_in;            // apply ReLU to A fragments (bf16 only)
+    // epilogue
+    const float* bias;      // fp32 [N] (or [bias_mod]) or null
+    int bias_mod;           // 0: bias[n]; else bias[n % bias_mod]
+    int round_mid;          // round (acc + bias) to the operand type before act/residual
+                            // (reproduces CLIP's fp16 Linear -> fp16 add, [3P] clip/model.py)
+    int act;
+    int res_mode;
+    const void* res;  int res_dtype; int ldr;   // residual tensor
+    const void* res2;                            // optional second residual (RES_DEST, same dtype/geometry)
+    void* C;  int out_dtype; int ldc;
+    int map_mode;
+    int p_div, p_mul, p_off;    // MAP_PERIODIC / RES_PERIODIC / MAP_NCHW(P)
+    int ps_s, ps_C;             // MAP_PIXSHUF
+    // MAP_QKV
+    void* Ck; void* Cv; int qkv_dim, qkv_ntok, qkv_npad, qkv_heads;
+    int tag;                    // 0 generic, 1 = the profiled dominant instance (distinct symbol)
+};
+
+void gemm_args_init(GemmArgs& g);
+// ab_dtype: DT_BF16 | DT_F16.  Returns 0 or a negative lseg_status.
+int launch_gemm(const GemmArgs& g, int ab_dtype, hipStream_t stream);
+
+}  // namespace lseg

@@ -1,0 +1,35 @@
+// ops.h -- host-side launchers of every kernel in the engine (all stream-ordered, return 0 or <0).
+#pragma once
+#include "common.h"
+#include "gemm.h"
+
+namespace lseg {
+
+int launch_attention(const void* q, const void* k, const void* vt, void* out, int B, int H, int ntok,
+                     int npad, int dtype, int causal, float scale, hipStream_t stream);
+
+int launch_layernorm(const void* in, int in_dtype, const float* gamma, const float* beta, void* out, int out_dtype,
+                     int M, int D, float eps, hipStream_t st);
+int launch_im2col_patch(const float* x, void* A, int B, int H, int W, int P, int dtype, hipStream_t st);
+int launch_pos_resize(const float* pos, float* out, int g_old, int gh, int gw, int D, hipStream_t st);
+int launch_cls_rows(const float* cls, const float* pos, float* x, int B, int ntok, int D, hipStream_t st);
+int launch_readout_cat(const float* x, void* A, int B, int ntok, int D, int dtype, hipStream_t st);
+int launch_upsample2x_nhwc(const void* in, void* out, int B, int H, int W, int C, int dtype, hipStream_t st);
+int launch_upsample2x_planes(const float* in, float* out, int P, int H, int W, hipStream_t st);
+int launch_l2norm_scale_f16(const float* f, void* a, int M, int C, float scale, hipStream_t st);
+int launch_text_embed(const int64_t* tok, const float* emb, const float* pos, void* x, int rows, int L, int W, hipStream_t st);
+int launch_text_pool(const void* x, const int* eot, void* pooled, int K, int L, int W, hipStream_t st);
+int launch_text_l2norm(const void* t, void* out, int K, int C, hipStream_t st);
+int launch_convert(const void* in, int in_dtype, void* out, int out_dtype, size_t n, hipStream_t st);
+int launch_transpose_convert(const void* in, int in_dtype, void* out, int out_dtype, int R, int C, hipStream_t st);
+int launch_pack_conv3x3(const float* w, const float* bn_w, const float* bn_b, const float* bn_m, const float* bn_v,
+                        float bn_eps, const float* conv_bias, void* wp, float* bias_out, int Co, int Ci, int dtype,
+                        hipStream_t st);
+int launch_pack_convT(const float* w, void* wp, int Ci, int Co, int s, int dtype, hipStream_t st);
+int launch_nhwc_to_nchw_f32(const void* in, float* out, int B, int H, int W, int C, int pad, int dtype, hipStream_t st);
+int launch_rows_to_nchw_f32(const float* in, float* out, int B, int HW, int C, hipStream_t st);
+int launch_head_block(const float* in, float* out, const float* w9, const float* bias, int B, int K, int H, int W,
+                      int bottleneck, int act, int apply_act, hipStream_t st);
+int launch_argmax_planes(const float* in, uint8_t* out, int B, int K, int HW, hipStream_t st);
+
+}  // namespace lseg

@@ -1,0 +1,209 @@
+"""Per-kernel parity through the C ABI (liblseg_hip.so) against plain fp32 torch on the
+same inputs.  Operands are rounded to the kernel's operand type first, so the only
+difference left is accumulation order (fp32) and the output rounding."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from lseg_hip import _lib  # noqa: E402
+
+DT = {torch.float32: _lib.LSEG_F32, torch.float16: _lib.LSEG_F16, torch.bfloat16: _lib.LSEG_BF16}
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return _lib.load()
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).cuda()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K", [(901, 1024, 1024), (256, 128, 64), (130, 192, 128), (3604, 3072, 1024),
+                                   (77, 512, 2048), (5, 64, 64)])
+def test_gemm_plain(lib, dtype, M, N, K):
+    A = rnd((M, K), dtype, 1)
+    W = rnd((N, K), dtype, 2, 1 / math.sqrt(K))
+    out = torch.full((M, N), float("nan"), dtype=torch.float32).cuda()
+    _lib.check(lib.lseg_op_gemm(P(A), P(W), None, None, P(out), M, N, K, DT[dtype], _lib.LSEG_F32, 0, stream()))
+    torch.cuda.synchronize()
+    ref = A.float() @ W.float().t()
+    err = (out - ref).abs().max().item()
+    assert err < 2e-3 * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("act", [0, 1, 2, 3])
+def test_gemm_epilogues(lib, act):
+    M, N, K = 333, 256, 192
+    dtype = torch.bfloat16
+    A = rnd((M, K), dtype, 3)
+    W = rnd((N, K), dtype, 4, 1 / math.sqrt(K))
+    bias = rnd((N,), torch.float32, 5)
+    res = rnd((M, N), torch.float32, 6)
+    ref = A.float() @ W.float().t() + bias
+    if act == 1:
+        ref = F.gelu(ref)
+    elif act == 2:
+        ref = ref * torch.sigmoid(1.702 * ref)
+    elif act == 3:
+        ref = F.relu(ref)
+    ref = ref + res
+    for od, tol in ((torch.float32, 2e-3), (torch.bfloat16, 2e-2), (torch.float16, 4e-3)):
+        out = torch.zeros((M, N), dtype=od).cuda()
+        _lib.check(lib.lseg_op_gemm(P(A), P(W), P(bias), P(res), P(out), M, N, K, DT[dtype], DT[od], act, stream()))
+        torch.cuda.synchronize()
+        err = (out.float() - ref).abs().max().item()
+        assert err < tol * max(1.0, ref.abs().max().item()), (od, err)
+
+
+def test_gemm_transpose_detecting(lib):
+    """A = I (padded), asymmetric W: catches a swapped C layout (cdna guide G9)."""
+    M = N = K = 64
+    A = torch.eye(M, K).to(torch.bfloat16).cuda()
+    W = (torch.arange(N * K).reshape(N, K).float() % 251 / 16).to(torch.bfloat16).cuda()
+    out = torch.zeros((M, N), dtype=torch.float32).cuda()
+    _lib.check(lib.lseg_op_gemm(P(A), P(W), None, None, P(out), M, N, K, _lib.LSEG_BF16, _lib.LSEG_F32, 0, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out, W.float().t())
+
+
+@pytest.mark.parametrize("in_dt,out_dt,D,eps", [(torch.float32, torch.bfloat16, 1024, 1e-6),
+                                                (torch.float16, torch.float16, 512, 1e-5),
+                                                (torch.float32, torch.float16, 128, 1e-6),
+                                                (torch.float32, torch.bfloat16, 768, 1e-6)])
+def test_layernorm(lib, in_dt, out_dt, D, eps):
+    M = 515
+    x = rnd((M, D), in_dt, 7, 2.0) + 0.5
+    g = (1 + 0.1 * rnd((D,), torch.float32, 8)).contiguous()
+    b = (0.1 * rnd((D,), torch.float32, 9)).contiguous()
+    out = torch.zeros((M, D), dtype=out_dt).cuda()
+    _lib.check(lib.lseg_op_layernorm(P(x), DT[in_dt], P(g), P(b), P(out), DT[out_dt], M, D, eps, stream()))
+    torch.cuda.synchronize()
+    ref = F.layer_norm(x.float(), (D,), g, b, eps)
+    tol = 2e-2 if out_dt == torch.bfloat16 else 3e-3
+    assert (out.float() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+
+
+def _attention_case(lib, dtype, B, H, N, causal, seed, spike=False):
+    Npad = ((N + 127) // 128) * 128
+    q = rnd((B, H, N, 64), dtype, seed)
+    k = rnd((B, H, N, 64), dtype, seed + 1)
+    v = rnd((B, H, N, 64), dtype, seed + 2)
+    if spike:   # one key dominates one query late in the sequence -> running max jumps (online-softmax rescale)
+        k[:, :, N - 3] = q[:, :, 5] * 4.0
+    qp = torch.zeros((B * H, Npad, 64), dtype=dtype).cuda(); qp[:, :N] = q.reshape(B * H, N, 64)
+    kp = torch.zeros((B * H, Npad, 64), dtype=dtype).cuda(); kp[:, :N] = k.reshape(B * H, N, 64)
+    vt = torch.zeros((B * H, 64, Npad), dtype=dtype).cuda(); vt[:, :, :N] = v.reshape(B * H, N, 64).transpose(1, 2)
+    out = torch.full((B, N, H * 64), float("nan"), dtype=dtype).cuda()
+    _lib.check(lib.lseg_op_attention(P(qp), P(kp), P(vt), P(out), B, H, N, Npad, DT[dtype], int(causal), 0.125, stream()))
+    torch.cuda.synchronize()
+    s = (q.float() @ k.float().transpose(-1, -2)) * 0.125
+    if causal:
+        s = s + torch.full((N, N), float("-inf"), device=s.device).triu_(1)
+    ref = (s.softmax(-1) @ v.float()).transpose(1, 2).reshape(B, N, H * 64)
+    err = (out.float() - ref).abs().max().item()
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    assert math.isfinite(err) and err < tol * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,N,causal", [(1, 2, 901, False), (2, 3, 77, True), (1, 1, 64, False),
+                                          (1, 2, 130, True), (3, 16, 226, False)])
+def test_attention(lib, dtype, B, H, N, causal):
+    _attention_case(lib, dtype, B, H, N, causal, 20)
+
+
+def test_attention_rescale_branch(lib):
+    _attention_case(lib, torch.bfloat16, 1, 2, 901, False, 30, spike=True)
+    _attention_case(lib, torch.float16, 1, 2, 77, True, 31, spike=True)
+
+
+def _pad_nhwc(x_nchw, dtype):
+    B, Cc, H, W = x_nchw.shape
+    p = torch.zeros((B, H + 2, W + 2, Cc), dtype=dtype, device=x_nchw.device)
+    p[:, 1:-1, 1:-1] = x_nchw.permute(0, 2, 3, 1).to(dtype)
+    return p.contiguous()
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,relu_in,relu_out,with_res",
+                         [(1, 15, 15, 64, 64, 1, 0, 0, False), (2, 30, 30, 128, 64, 1, 1, 1, False),
+                          (1, 30, 30, 64, 128, 2, 0, 0, False), (1, 24, 16, 256, 256, 1, 1, 0, True),
+                          (1, 120, 120, 256, 256, 1, 0, 0, True)])
+def test_conv3x3(lib, B, H, W, Cin, Cout, stride, relu_in, relu_out, with_res):
+    dt = torch.bfloat16
+    x = rnd((B, Cin, H, W), dt, 40)
+    w = rnd((Cout, Cin, 3, 3), dt, 41, 1 / math.sqrt(9 * Cin))
+    bias = rnd((Cout,), torch.float32, 42)
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = rnd((B, Cout, Ho, Wo), dt, 43) if with_res else None
+    xp = _pad_nhwc(x, dt)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()     # [Co, (ky,kx), Ci]
+    resp = _pad_nhwc(res, dt) if with_res else None
+    out = torch.zeros((B, Ho + 2, Wo + 2, Cout), dtype=dt).cuda()
+    _lib.check(lib.lseg_op_conv3x3(P(xp), P(wp), P(bias), P(resp), P(out), B, H, W, Cin, Cout, stride,
+                                   relu_in, relu_out, stream()))
+    torch.cuda.synchronize()
+    xin = F.relu(x.float()) if relu_in else x.float()
+    ref = F.conv2d(xin, w.float(), bias, stride=stride, padding=1)
+    if relu_out:
+        ref = F.relu(ref)
+    if with_res:
+        ref = ref + res.float()
+    got = out[:, 1:-1, 1:-1].permute(0, 3, 1, 2).float()
+    assert (got - ref).abs().max().item() < 2e-2 * max(1.0, ref.abs().max().item())
+    # the zero border must be untouched
+    assert out[:, 0].abs().max().item() == 0 and out[:, :, 0].abs().max().item() == 0
+    assert out[:, -1].abs().max().item() == 0 and out[:, :, -1].abs().max().item() == 0
+
+
+def test_upsample2x(lib):
+    dt = torch.bfloat16
+    x = rnd((2, 64, 15, 10), dt, 50)
+    out = torch.zeros((2, 30, 20, 64), dtype=dt).cuda()
+    _lib.check(lib.lseg_op_upsample2x_nhwc(P(_pad_nhwc(x, dt)), P(out), 2, 15, 10, 64, stream()))
+    ref = F.interpolate(x.float(), scale_factor=2, mode="bilinear", align_corners=True)
+    assert (out.permute(0, 3, 1, 2).float() - ref).abs().max().item() < 2e-2 * ref.abs().max().item()
+    pl = rnd((7, 24, 20), torch.float32, 51)
+    o2 = torch.zeros((7, 48, 40), dtype=torch.float32).cuda()
+    _lib.check(lib.lseg_op_upsample2x_planes(P(pl), P(o2), 7, 24, 20, stream()))
+    torch.cuda.synchronize()
+    ref2 = F.interpolate(pl[None], scale_factor=2, mode="bilinear", align_corners=True)[0]
+    assert (o2 - ref2).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("K", [150, 7, 2, 1000])
+def test_correlation_matches_oracle(lib, K):
+    """lseg_net.py:187-196 as restated in oracle.correlate: bit-exact except where the fp32
+    accumulation order changes an fp16 rounding (allow 1 fp16 ulp on <1% of logits)."""
+    from oracle.lseg_oracle import correlate, LOGIT_SCALE, r16
+    B, Pp, Cc = 2, 1000, 512
+    g = torch.Generator().manual_seed(60 + K)
+    feat = torch.randn((B * Pp, Cc), generator=g) * 3
+    text = torch.randn((K, Cc), generator=g).half()
+    ref = correlate(feat, text.float(), LOGIT_SCALE)                        # [M, K]
+    tn = r16(text.float() / r16(text.float().norm(dim=-1, keepdim=True))).half().cuda()
+    out = torch.zeros((B, K, Pp), dtype=torch.float32).cuda()
+    _lib.check(lib.lseg_op_correlation(P(feat.cuda()), P(tn), P(out), B, Pp, Cc, K, LOGIT_SCALE, stream()))
+    torch.cuda.synchronize()
+    got = out.permute(0, 2, 1).reshape(B * Pp, K).cpu()
+    assert torch.equal(got, r16(got))                                       # fp16-representable
+    diff = (got - ref).abs()
+    assert diff.max().item() <= 2 ** -6                                      # <= 1 ulp at |logit| < 16
+    assert (diff > 0).float().mean().item() < 0.02
+    assert (got.argmax(1) != ref.argmax(1)).float().mean().item() < 0.01
