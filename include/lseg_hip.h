@@ -73,11 +73,12 @@ typedef struct {
     /* CLIP text tower */
     int32_t text_vocab, text_ctx, text_width, text_heads, text_layers;
     /* execution plan */
-    int32_t img_h, img_w;     /* input size, multiples of 2*patch */
+    int32_t img_h, img_w;     /* input size, multiples of patch (and such that the reassemble pyramid is a x2 ladder) */
     int32_t max_batch;        /* workspace is sized for this many images per call */
     int32_t max_labels;       /* workspace is sized for this many labels (K) */
     int32_t image_dtype;      /* LSEG_BF16 (default) or LSEG_F16: MFMA operand type of the image tower */
-    int32_t flags;            /* reserved, 0 */
+    int32_t flags;            /* bit 0: run the text tower on all text_ctx positions (reference schedule)
+                               * instead of the exact causal truncation to max(EOT)+1 positions */
 } lseg_config;
 
 typedef struct lseg_engine* lseg_handle;

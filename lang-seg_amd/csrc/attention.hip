@@ -121,7 +121,11 @@ __global__ __launch_bounds__(256) void lseg_attention_kernel(const AttnArgs a) {
             }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        // exact "defer": when no row of this wave raised its running max the rescale factor is
+        // exactly 1 for every lane, so the exp and the 32 accumulator multiplies are skipped
+        const bool grew = !__all(m_new == m_run);
+        float alpha = 1.0f;
+        if (grew) alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
         float lsum = 0.f;
 #pragma unroll
@@ -133,10 +137,12 @@ __global__ __launch_bounds__(256) void lseg_attention_kernel(const AttnArgs a) {
                 lsum += p;
             }
         l_run = l_run * alpha + lsum;
+        if (grew) {
 #pragma unroll
-        for (int d = 0; d < 2; ++d)
+            for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        }
 
         // ---- P^T fragments (B operand), straight from the accumulator layout -----------------
         i32x4_t pf[2][2];
@@ -146,9 +152,7 @@ __global__ __launch_bounds__(256) void lseg_attention_kernel(const AttnArgs a) {
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int wd = 0; wd < 4; ++wd) {
-                    const uint32_t lo = from_f32<T>(s[sub][8 * s2 + 2 * wd]);
-                    const uint32_t hi16 = from_f32<T>(s[sub][8 * s2 + 2 * wd + 1]);
-                    pf[sub][s2][wd] = (int)(lo | (hi16 << 16));
+                    pf[sub][s2][wd] = (int)pack2<T>(s[sub][8 * s2 + 2 * wd], s[sub][8 * s2 + 2 * wd + 1]);
                 }
         // ---- O^T[d][q] += V^T[d][keys] P^T[keys][q] -----------------------------------------------
 #pragma unroll
@@ -178,12 +182,9 @@ __global__ __launch_bounds__(256) void lseg_attention_kernel(const AttnArgs a) {
         for (int d = 0; d < 2; ++d)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                uint16_t hv[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) hv[e] = from_f32<T>(o[d][g * 4 + e] * inv);
                 uint2 pk;
-                pk.x = (uint32_t)hv[0] | ((uint32_t)hv[1] << 16);
-                pk.y = (uint32_t)hv[2] | ((uint32_t)hv[3] << 16);
+                pk.x = pack2<T>(o[d][g * 4 + 0] * inv, o[d][g * 4 + 1] * inv);
+                pk.y = pack2<T>(o[d][g * 4 + 2] * inv, o[d][g * 4 + 3] * inv);
                 *reinterpret_cast<uint2*>(orow + d * 32 + g * 8 + hi * 4) = pk;
             }
     }

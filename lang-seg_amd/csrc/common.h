@@ -43,6 +43,24 @@ template <typename T> __device__ __forceinline__ uint16_t from_f32(float f);
 template <> __device__ __forceinline__ uint16_t from_f32<BF16>(float f) { return f32_to_bf16(f); }
 template <> __device__ __forceinline__ uint16_t from_f32<F16>(float f) { return f32_to_f16(f); }
 
+// Two fp32 -> one 32-bit word of two 16-bit floats (lo in bits 0..15), round-to-nearest-even.
+// bf16: gfx950's v_cvt_pk_bf16_f32 (no builtin; cdna_hip_programming.md T12), 1 instruction
+// instead of the ~10 of the bit-twiddling form.
+template <typename T> __device__ __forceinline__ uint32_t pack2(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t pack2<BF16>(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+template <> __device__ __forceinline__ uint32_t pack2<F16>(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    h2 v; v[0] = (_Float16)lo; v[1] = (_Float16)hi;
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ uint32_t pack2_dt(float lo, float hi, int dtype) {
+    return dtype == DT_F16 ? pack2<F16>(lo, hi) : pack2<BF16>(lo, hi);
+}
+
 __device__ __forceinline__ float load_as_f32(const void* p, size_t i, int dtype) {
     if (dtype == DT_F32) return ((const float*)p)[i];
     if (dtype == DT_F16) return f16_to_f32(((const uint16_t*)p)[i]);

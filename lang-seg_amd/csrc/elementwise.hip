@@ -64,12 +64,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* in, int in_d
             if (out_dtype == DT_F32) {
                 reinterpret_cast<float4*>((float*)out + (size_t)row * D)[g] = make_float4(y[0], y[1], y[2], y[3]);
             } else {
-                uint16_t h[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = out_dtype == DT_F16 ? f32_to_f16(y[e]) : f32_to_bf16(y[e]);
                 uint2 pk;
-                pk.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
-                pk.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+                pk.x = pack2_dt(y[0], y[1], out_dtype);
+                pk.y = pack2_dt(y[2], y[3], out_dtype);
                 reinterpret_cast<uint2*>((uint16_t*)out + (size_t)row * D)[g] = pk;
             }
         }
@@ -79,13 +76,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* in, int in_d
 // ---- patch im2col: x fp32 NCHW -> A [B*gh*gw, 3*P*P] (k = c*P*P + i*P + j), lseg_vit.py:179 ------
 __global__ void im2col_patch_kernel(const float* x, uint16_t* A, int B, int H, int W, int P, int dtype) {
     const int gh = H / P, gw = W / P, Kd = 3 * P * P;
-    const size_t total = (size_t)B * gh * gw * (Kd / 8);
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int k8 = (int)(idx % (Kd / 8));
-        const size_t m = idx / (Kd / 8);
+    const unsigned total = (unsigned)B * gh * gw * (Kd / 8);
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int k8 = (int)(idx % (unsigned)(Kd / 8));
+        const unsigned m = idx / (unsigned)(Kd / 8);
         const int k = k8 * 8;
         const int c = k / (P * P), rem = k - c * P * P, i = rem / P, j = rem - i * P;
-        const int b = (int)(m / (gh * gw)), p = (int)(m - (size_t)b * gh * gw), py = p / gw, px = p - py * gw;
+        const int b = (int)(m / (unsigned)(gh * gw)), p = (int)(m - (unsigned)b * gh * gw), py = p / gw, px = p - py * gw;
         const float* src = x + (((size_t)b * 3 + c) * H + py * P + i) * W + px * P + j;
         const float4 f0 = reinterpret_cast<const float4*>(src)[0];
         const float4 f1 = reinterpret_cast<const float4*>(src)[1];
@@ -93,11 +90,9 @@ __global__ void im2col_patch_kernel(const float* x, uint16_t* A, int B, int H, i
         uint32_t o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const uint32_t lo = dtype == DT_F16 ? f32_to_f16(f[2 * e]) : f32_to_bf16(f[2 * e]);
-            const uint32_t hi = dtype == DT_F16 ? f32_to_f16(f[2 * e + 1]) : f32_to_bf16(f[2 * e + 1]);
-            o[e] = lo | (hi << 16);
+            o[e] = pack2_dt(f[2 * e], f[2 * e + 1], dtype);
         }
-        reinterpret_cast<uint4*>(A + m * Kd + k)[0] = make_uint4(o[0], o[1], o[2], o[3]);
+        reinterpret_cast<uint4*>(A + (size_t)m * Kd + k)[0] = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -134,11 +129,11 @@ __global__ void cls_rows_kernel(const float* cls, const float* pos, float* x, in
 // ---- ProjectReadout concat (lseg_vit.py:87-88): x fp32 [B,N,D] -> A [B*(N-1), 2D] -----------------------
 __global__ void readout_cat_kernel(const float* x, uint16_t* A, int B, int ntok, int D, int dtype) {
     const int g8 = 2 * D / 8;
-    const size_t total = (size_t)B * (ntok - 1) * g8;
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int c8 = (int)(idx % g8);
-        const size_t m = idx / g8;
-        const int b = (int)(m / (ntok - 1)), t = (int)(m - (size_t)b * (ntok - 1));
+    const unsigned total = (unsigned)B * (ntok - 1) * g8;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int c8 = (int)(idx % (unsigned)g8);
+        const unsigned m = idx / (unsigned)g8;
+        const int b = (int)(m / (unsigned)(ntok - 1)), t = (int)(m - (unsigned)b * (ntok - 1));
         const int c = c8 * 8;
         const float* src = c < D ? x + ((size_t)b * ntok + t + 1) * D + c : x + (size_t)b * ntok * D + (c - D);
         const float4 f0 = reinterpret_cast<const float4*>(src)[0];
@@ -147,11 +142,9 @@ __global__ void readout_cat_kernel(const float* x, uint16_t* A, int B, int ntok,
         uint32_t o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const uint32_t lo = dtype == DT_F16 ? f32_to_f16(f[2 * e]) : f32_to_bf16(f[2 * e]);
-            const uint32_t hi = dtype == DT_F16 ? f32_to_f16(f[2 * e + 1]) : f32_to_bf16(f[2 * e + 1]);
-            o[e] = lo | (hi << 16);
+            o[e] = pack2_dt(f[2 * e], f[2 * e + 1], dtype);
         }
-        reinterpret_cast<uint4*>(A + m * (size_t)(2 * D) + c)[0] = make_uint4(o[0], o[1], o[2], o[3]);
+        reinterpret_cast<uint4*>(A + (size_t)m * (2 * D) + c)[0] = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -159,14 +152,14 @@ __global__ void readout_cat_kernel(const float* x, uint16_t* A, int B, int ntok,
 // (FeatureFusionBlock_custom.forward, lseg_blocks.py:352-354)
 __global__ void upsample2x_nhwc_kernel(const uint16_t* in, uint16_t* out, int B, int H, int W, int C, int dtype) {
     const int c8n = C / 8, Ho = 2 * H, Wo = 2 * W;
-    const size_t total = (size_t)B * Ho * Wo * c8n;
+    const unsigned total = (unsigned)B * Ho * Wo * c8n;
     const float ry = (float)(H - 1) / (float)(Ho - 1), rx = (float)(W - 1) / (float)(Wo - 1);
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int c8 = (int)(idx % c8n);
-        size_t p = idx / c8n;
-        const int xo = (int)(p % Wo); p /= Wo;
-        const int yo = (int)(p % Ho);
-        const int b = (int)(p / Ho);
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int c8 = (int)(idx % (unsigned)c8n);
+        unsigned p = idx / (unsigned)c8n;
+        const int xo = (int)(p % (unsigned)Wo); p /= (unsigned)Wo;
+        const int yo = (int)(p % (unsigned)Ho);
+        const int b = (int)(p / (unsigned)Ho);
         const float sy = ry * (float)yo, sx = rx * (float)xo;
         const int y0 = (int)sy, x0 = (int)sx;
         const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
@@ -194,9 +187,7 @@ __global__ void upsample2x_nhwc_kernel(const uint16_t* in, uint16_t* out, int B,
                 const float v10 = load_as_f32(&u10, 0, dtype), v11 = load_as_f32(&u11, 0, dtype);
                 r[hlf] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
             }
-            const uint32_t lo = dtype == DT_F16 ? f32_to_f16(r[0]) : f32_to_bf16(r[0]);
-            const uint32_t hi = dtype == DT_F16 ? f32_to_f16(r[1]) : f32_to_bf16(r[1]);
-            o[e] = lo | (hi << 16);
+            o[e] = pack2_dt(r[0], r[1], dtype);
         }
         *reinterpret_cast<uint4*>(out + (((size_t)b * Ho + yo) * Wo + xo) * C + (size_t)c8 * 8) = make_uint4(o[0], o[1], o[2], o[3]);
     }
@@ -204,20 +195,21 @@ __global__ void upsample2x_nhwc_kernel(const uint16_t* in, uint16_t* out, int B,
 
 // ---- bilinear x2, align_corners=True, fp32 planes [P,H,W] -> [P,2H,2W] (lseg_net.py:203) -----------
 // optional per-plane post-op none.  Each thread writes 4 consecutive outputs (16 B).
-__global__ void upsample2x_planes_kernel(const float* in, float* out, int P, int H, int W) {
+__global__ __launch_bounds__(256) void upsample2x_planes_kernel(const float* in, float* out, int P, int H, int W) {
+    // block = 2 output rows x 128 lanes; lane x4 writes outputs 4*x4 .. 4*x4+3 of its row
     const int Ho = 2 * H, Wo = 2 * W, w4 = Wo / 4;
-    const size_t total = (size_t)P * Ho * w4;
+    const unsigned rowid = blockIdx.x * 2 + (threadIdx.x >> 7);
+    if (rowid >= (unsigned)P * Ho) return;
+    const unsigned pl = rowid / (unsigned)Ho;
+    const int yo = (int)(rowid - pl * Ho);
     const float ry = (float)(H - 1) / (float)(Ho - 1), rx = (float)(W - 1) / (float)(Wo - 1);
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int x4 = (int)(idx % w4);
-        size_t p = idx / w4;
-        const int yo = (int)(p % Ho);
-        const size_t pl = p / Ho;
-        const float sy = ry * (float)yo;
-        const int y0 = (int)sy, y1 = y0 + (y0 < H - 1);
-        const float ly = sy - (float)y0;
-        const float* r0 = in + (pl * H + y0) * W;
-        const float* r1 = in + (pl * H + y1) * W;
+    const float sy = ry * (float)yo;
+    const int y0 = (int)sy, y1 = y0 + (y0 < H - 1);
+    const float ly = sy - (float)y0;
+    const float* r0 = in + ((size_t)pl * H + y0) * W;
+    const float* r1 = in + ((size_t)pl * H + y1) * W;
+    float* orow = out + (size_t)rowid * Wo;
+    for (int x4 = threadIdx.x & 127; x4 < w4; x4 += 128) {
         float o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -227,7 +219,8 @@ __global__ void upsample2x_planes_kernel(const float* in, float* out, int P, int
             const float lx = sx - (float)x0;
             o[e] = (1.f - ly) * ((1.f - lx) * r0[x0] + lx * r0[x1]) + ly * ((1.f - lx) * r1[x0] + lx * r1[x1]);
         }
-        reinterpret_cast<float4*>(out + (pl * Ho + yo) * Wo)[x4] = make_float4(o[0], o[1], o[2], o[3]);
+        const f32x4_t ov = {o[0], o[1], o[2], o[3]};     // written once, never re-read by the engine
+        __builtin_nontemporal_store(ov, reinterpret_cast<f32x4_t*>(orow) + x4);
     }
 }
 
@@ -268,13 +261,14 @@ __global__ __launch_bounds__(256) void l2norm_scale_f16_kernel(const float* f, u
 
 // ---- text: token+positional embedding in fp16 steps ([3P] clip/model.py encode_text) ---------------
 __global__ void text_embed_kernel(const int64_t* tok, const float* emb, const float* pos, uint16_t* x,
-                                  int rows, int L, int W) {
-    const size_t total = (size_t)rows * W;
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int d = (int)(idx % W);
-        const int r = (int)(idx / W);
-        const int l = r % L;
-        const float e = round_f16(emb[(size_t)tok[r] * W + d]);
+                                  int rows, int L, int ctx, int W) {
+    // rows = K * L: only the first L <= ctx positions of every label are embedded (tokens are [K, ctx])
+    const unsigned total = (unsigned)rows * W;
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int d = (int)(idx % (unsigned)W);
+        const int r = (int)(idx / (unsigned)W);
+        const int k = r / L, l = r - k * L;
+        const float e = round_f16(emb[(size_t)tok[(size_t)k * ctx + l] * W + d]);
         const float p = round_f16(pos[(size_t)l * W + d]);
         x[idx] = f32_to_f16(e + p);
     }
@@ -470,8 +464,9 @@ int launch_upsample2x_nhwc(const void* in, void* out, int B, int H, int W, int C
 }
 int launch_upsample2x_planes(const float* in, float* out, int P, int H, int W, hipStream_t st) {
     if ((2 * W) % 4) return set_error(LSEG_ERR_UNSUPPORTED, "upsample2x_planes: W=%d", W);
-    const size_t total = (size_t)P * 2 * H * (2 * W / 4);
-    hipLaunchKernelGGL(upsample2x_planes_kernel, dim3(grid_for(total)), dim3(256), 0, st, in, out, P, H, W);
+    const size_t rows = (size_t)P * 2 * H;
+    if (rows > 0x7fffffffu) return set_error(LSEG_ERR_UNSUPPORTED, "upsample2x_planes: too many rows");
+    hipLaunchKernelGGL(upsample2x_planes_kernel, dim3((unsigned)((rows + 1) / 2)), dim3(256), 0, st, in, out, P, H, W);
     CHECK_LAUNCH();
     return 0;
 }
@@ -484,8 +479,8 @@ int launch_l2norm_scale_f16(const float* f, void* a, int M, int C, float scale, 
     CHECK_LAUNCH();
     return 0;
 }
-int launch_text_embed(const int64_t* tok, const float* emb, const float* pos, void* x, int rows, int L, int W, hipStream_t st) {
-    hipLaunchKernelGGL(text_embed_kernel, dim3(grid_for((size_t)rows * W)), dim3(256), 0, st, tok, emb, pos, (uint16_t*)x, rows, L, W);
+int launch_text_embed(const int64_t* tok, const float* emb, const float* pos, void* x, int rows, int L, int ctx, int W, hipStream_t st) {
+    hipLaunchKernelGGL(text_embed_kernel, dim3(grid_for((size_t)rows * W)), dim3(256), 0, st, tok, emb, pos, (uint16_t*)x, rows, L, ctx, W);
     CHECK_LAUNCH();
     return 0;
 }

@@ -93,6 +93,7 @@ private:
     float* acts_[4] = {};
     // text
     int K_ = 0;
+    int tl_ = 0;                  // text positions actually computed (<= text_ctx), see set_tokens
     int64_t* d_tok_ = nullptr;
     int* d_eot_ = nullptr;
     uint16_t *tx_ = nullptr, *tln_ = nullptr, *tq_ = nullptr, *tk_ = nullptr, *tvt_ = nullptr, *tatt_ = nullptr,

@@ -67,7 +67,7 @@ int Engine::init() {
     if (c.abi_version != LSEG_ABI_VERSION) return set_error(LSEG_ERR_INVALID, "config abi_version %d != %d", c.abi_version, LSEG_ABI_VERSION);
     if (c.dim % c.heads || c.dim / c.heads != 64) return set_error(LSEG_ERR_UNSUPPORTED, "image head_dim must be 64 (dim %d / heads %d)", c.dim, c.heads);
     if (c.text_width % c.text_heads || c.text_width / c.text_heads != 64) return set_error(LSEG_ERR_UNSUPPORTED, "text head_dim must be 64");
-    if (c.img_h % (2 * c.patch) || c.img_w % (2 * c.patch)) return set_error(LSEG_ERR_INVALID, "image size %dx%d must be a multiple of 2*patch", c.img_h, c.img_w);
+    if (c.img_h % c.patch || c.img_w % c.patch) return set_error(LSEG_ERR_INVALID, "image size %dx%d must be a multiple of the patch size %d", c.img_h, c.img_w, c.patch);
     if (c.dim % 64 || c.features % 64 || c.out_c % 64 || c.text_width % 64 || (3 * c.patch * c.patch) % 64)
         return set_error(LSEG_ERR_UNSUPPORTED, "dim/features/out_c/text_width must be multiples of 64");
     for (int l = 0; l < 4; ++l)
@@ -329,6 +329,13 @@ int Engine::set_tokens(const int64_t* tok, int K, int ctx) {
     LSEG_HIP_TRY(hipMemcpy(d_tok_, tok, (size_t)K * ctx * sizeof(int64_t), hipMemcpyHostToDevice));
     LSEG_HIP_TRY(hipMemcpy(d_eot_, eot.data(), (size_t)K * sizeof(int), hipMemcpyHostToDevice));
     K_ = K;
+    // Exact causal truncation: with the -inf upper-triangular mask no position after a label's EOT
+    // token can influence its EOT row, and every other op of the tower is row-wise, so only the
+    // first max(eot)+1 positions are computed (bit-identical pooled features; flags bit 0 = the
+    // reference's full 77-position schedule).
+    int lmax = 0;
+    for (int k = 0; k < K; ++k) lmax = std::max(lmax, eot[k] + 1);
+    tl_ = (cfg.flags & 1) ? ctx : lmax;
     text_valid = false;
     return 0;
 }
@@ -338,8 +345,8 @@ int Engine::encode_text(hipStream_t st) {
     if (!finalized_) return set_error(LSEG_ERR_STATE, "parameters not finalised");
     if (K_ < 1) return set_error(LSEG_ERR_STATE, "no text tokens set");
     const lseg_config& c = cfg;
-    const int L = c.text_ctx, W = c.text_width, H = c.text_heads, M = K_ * L;
-    TRY(launch_text_embed(d_tok_, tok_emb_, tpos_, tx_, M, L, W, st));
+    const int L = tl_, W = c.text_width, H = c.text_heads, M = K_ * L;
+    TRY(launch_text_embed(d_tok_, tok_emb_, tpos_, tx_, M, L, c.text_ctx, W, st));
     GemmArgs g;
     for (int i = 0; i < c.text_layers; ++i) {
         TextBlock& b = tblocks_[i];

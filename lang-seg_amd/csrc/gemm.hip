@@ -15,6 +15,8 @@
 // XCD-aware tile rasterisation.  The MFMA is issued "swapped" (weights as the row
 // operand) so each lane ends up with 4 consecutive output channels of one row ->
 // 8/16-byte epilogue stores and float4 bias/residual loads.
+#include <type_traits>
+
 #include "gemm.h"
 #include "../../include/lseg_hip.h"
 
@@ -27,7 +29,25 @@ void gemm_args_init(GemmArgs& g) {
 
 namespace {
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// compile-time loop: keeps accumulator indices static (runtime-indexed register arrays go to scratch)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// erf via Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32-roundoff class) -- ~12 VALU
+// instead of the ~30 of ocml erff; GELU(erf) as in timm's nn.GELU.
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = 1.0f - poly * __expf(-ax * ax);
+    return x < 0.f ? -e : e;
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
 
 // ReLU on 8 packed 16-bit floats (bf16 or fp16): negative <=> sign bit <=> negative int16.
 __device__ __forceinline__ i32x4_t relu_frag(i32x4_t v) {
@@ -42,18 +62,80 @@ __device__ __forceinline__ i32x4_t relu_frag(i32x4_t v) {
     return r;
 }
 
-template <typename T>
-__device__ __attribute__((noinline)) void epilogue4(const GemmArgs& g, int m, int n, f32x4_t acc) {
-    // 4 consecutive output columns n..n+3 of row m.
-    float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-    const int nvalid = (g.N - n) < 4 ? (g.N - n) : 4;
-    if (nvalid <= 0) return;
-    if (g.bias) {
-        const int bn = g.bias_mod ? (n % g.bias_mod) : n;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (r < nvalid) v[r] += g.bias[bn + r];
+// ---- epilogue addressing: every output map is separable, off(m, n) = rowpart(m) + colpart(n) --------
+struct ColPart { size_t off; int which; };   // which: 0 -> C, 1 -> Ck, 2 -> Cv (MAP_QKV only)
+
+__device__ __forceinline__ ColPart col_part(const GemmArgs& g, int n) {
+    ColPart c{(size_t)n, 0};
+    switch (g.map_mode) {
+        case MAP_PIXSHUF: {
+            const int ij = n / g.ps_C, co = n - ij * g.ps_C;
+            const int i = ij / g.ps_s, j = ij - i * g.ps_s;
+            const int Wd = g.wo * g.ps_s + 2;
+            c.off = ((size_t)i * Wd + j) * g.ps_C + co;
+        } break;
+        case MAP_QKV: {
+            const int which = n / g.qkv_dim, rem = n - which * g.qkv_dim;
+            const int head = rem >> 6, d = rem & 63;
+            c.which = which;
+            c.off = which == 2 ? ((size_t)head * 64 + d) * g.qkv_npad : (size_t)head * g.qkv_npad * 64 + d;
+        } break;
+        case MAP_NCHW: c.off = (size_t)n * g.p_div; break;
+        default: break;
     }
+    return c;
+}
+// rowpart for the q/k (or only) layout in .x, for the transposed-v layout in .y (MAP_QKV)
+__device__ __forceinline__ void row_part(const GemmArgs& g, int m, size_t& r0, size_t& r1) {
+    r1 = 0;
+    switch (g.map_mode) {
+        case MAP_LINEAR: r0 = (size_t)m * g.ldc; break;
+        case MAP_PERIODIC: {
+            const int q = m / g.p_div, r = m - q * g.p_div;
+            r0 = (size_t)(q * g.p_mul + r + g.p_off) * g.ldc;
+        } break;
+        case MAP_PADDED: {
+            const int hw = g.ho * g.wo;
+            const int b = m / hw, p = m - b * hw;
+            const int y = p / g.wo, x = p - y * g.wo;
+            r0 = ((size_t)(b * (g.ho + 2) + y + 1) * (g.wo + 2) + x + 1) * g.ldc;
+        } break;
+        case MAP_PIXSHUF: {
+            const int hw = g.ho * g.wo;
+            const int b = m / hw, p = m - b * hw;
+            const int y = p / g.wo, x = p - y * g.wo;
+            const int Hd = g.ho * g.ps_s + 2, Wd = g.wo * g.ps_s + 2;
+            r0 = ((size_t)(b * Hd + y * g.ps_s + 1) * Wd + x * g.ps_s + 1) * g.ps_C;
+        } break;
+        case MAP_QKV: {
+            const int b = m / g.qkv_ntok, t = m - b * g.qkv_ntok;
+            r0 = ((size_t)b * g.qkv_heads * g.qkv_npad + t) * 64;
+            r1 = (size_t)b * g.qkv_heads * 64 * g.qkv_npad + t;
+        } break;
+        case MAP_NCHW: {
+            const int b = m / g.p_div, p = m - b * g.p_div;
+            r0 = (size_t)b * g.N * g.p_div + p;
+        } break;
+        default: r0 = 0; break;
+    }
+}
+
+__device__ __forceinline__ float4 load4_as_f32(const void* p, size_t off, int dtype) {
+    if (dtype == DT_F32) return *reinterpret_cast<const float4*>((const float*)p + off);
+    const uint2 u = *reinterpret_cast<const uint2*>((const uint16_t*)p + off);
+    float4 r;
+    if (dtype == DT_F16) {
+        r.x = f16_to_f32((uint16_t)u.x); r.y = f16_to_f32((uint16_t)(u.x >> 16));
+        r.z = f16_to_f32((uint16_t)u.y); r.w = f16_to_f32((uint16_t)(u.y >> 16));
+    } else {
+        r.x = bf16_to_f32((uint16_t)u.x); r.y = bf16_to_f32((uint16_t)(u.x >> 16));
+        r.z = bf16_to_f32((uint16_t)u.y); r.w = bf16_to_f32((uint16_t)(u.y >> 16));
+    }
+    return r;
+}
+
+template <typename T>
+__device__ __forceinline__ void apply_act(const GemmArgs& g, float (&v)[4]) {
     if (g.round_mid) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = to_f32<T>(from_f32<T>(v[r]));
@@ -76,86 +158,81 @@ __device__ __attribute__((noinline)) void epilogue4(const GemmArgs& g, int m, in
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
     }
+}
 
-    // ---- destination offset -------------------------------------------------------------
-    size_t off = 0;
-    size_t estride = 1;   // element stride between the 4 consecutive n
-    void* dst = g.C;
-    switch (g.map_mode) {
-        case MAP_LINEAR: off = (size_t)m * g.ldc + n; break;
-        case MAP_PERIODIC: {
-            const int q = m / g.p_div, r = m - q * g.p_div;
-            off = (size_t)(q * g.p_mul + r + g.p_off) * g.ldc + n;
-        } break;
-        case MAP_PADDED: {
-            const int hw = g.ho * g.wo;
-            const int b = m / hw, p = m - b * hw;
-            const int y = p / g.wo, x = p - y * g.wo;
-            off = ((size_t)(b * (g.ho + 2) + y + 1) * (g.wo + 2) + x + 1) * g.ldc + n;
-        } break;
-        case MAP_PIXSHUF: {
-            const int hw = g.ho * g.wo;
-            const int b = m / hw, p = m - b * hw;
-            const int y = p / g.wo, x = p - y * g.wo;
-            const int ij = n / g.ps_C, co = n - ij * g.ps_C;
-            const int i = ij / g.ps_s, j = ij - i * g.ps_s;
-            const int Hd = g.ho * g.ps_s + 2, Wd = g.wo * g.ps_s + 2;
-            off = ((size_t)(b * Hd + y * g.ps_s + i + 1) * Wd + x * g.ps_s + j + 1) * g.ps_C + co;
-        } break;
-        case MAP_QKV: {
-            const int which = n / g.qkv_dim, rem = n - which * g.qkv_dim;
-            const int head = rem >> 6, d = rem & 63;
-            const int b = m / g.qkv_ntok, t = m - b * g.qkv_ntok;
-            if (which == 2) {
-                dst = g.Cv;
-                off = ((size_t)(b * g.qkv_heads + head) * 64 + d) * g.qkv_npad + t;
-                estride = g.qkv_npad;
-            } else {
-                dst = which == 0 ? g.C : g.Ck;
-                off = ((size_t)(b * g.qkv_heads + head) * g.qkv_npad + t) * 64 + d;
-            }
-        } break;
-        case MAP_NCHW: {
-            const int b = m / g.p_div, p = m - b * g.p_div;
-            off = ((size_t)b * g.N + n) * g.p_div + p;
-            estride = g.p_div;
-        } break;
-    }
-
-    // ---- residual(s) ----------------------------------------------------------------------
-    if (g.res_mode != RES_NONE) {
-        size_t roff = off;
-        if (g.res_mode == RES_PERIODIC) roff = (size_t)((m % g.p_div) + g.p_off) * g.ldr + n;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (r < nvalid) {
-                v[r] += load_as_f32(g.res, roff + r * estride, g.res_dtype);
-                if (g.res2) v[r] += load_as_f32(g.res2, roff + r * estride, g.res_dtype);
-            }
-    }
-
-    // ---- store -------------------------------------------------------------------------------
-    if (estride == 1 && nvalid == 4) {
-        if (g.out_dtype == DT_F32) {
-            *reinterpret_cast<float4*>((float*)dst + off) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-            uint16_t h[4];
-            if (g.out_dtype == DT_F16) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) h[r] = f32_to_f16(v[r]);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) h[r] = f32_to_bf16(v[r]);
-            }
-            uint2 pk;
-            pk.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
-            pk.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
-            *reinterpret_cast<uint2*>((uint16_t*)dst + off) = pk;
-        }
+__device__ __forceinline__ void store4(void* dst, size_t off, int dtype, const float (&v)[4]) {
+    if (dtype == DT_F32) {
+        *reinterpret_cast<float4*>((float*)dst + off) = make_float4(v[0], v[1], v[2], v[3]);
     } else {
+        uint2 pk;
+        pk.x = pack2_dt(v[0], v[1], dtype);
+        pk.y = pack2_dt(v[2], v[3], dtype);
+        *reinterpret_cast<uint2*>((uint16_t*)dst + off) = pk;
+    }
+}
+
+// One output row m of this lane: NI groups of 4 consecutive columns.  All residual loads of the
+// row are issued before the first store (the residual may alias C: x += f(x) in place).
+template <typename T, int NI>
+__device__ __forceinline__ void epilogue_row(const GemmArgs& g, int m, const int (&ncol)[NI], const ColPart (&cp)[NI],
+                                             const float4 (&bias)[NI], f32x4_t (&acc)[NI]) {
+    size_t r0, r1;
+    row_part(g, m, r0, r1);
+    size_t rres = 0;
+    if (g.res_mode == RES_PERIODIC) rres = (size_t)((m % g.p_div) + g.p_off) * g.ldr;
+    const bool fast = (g.N % 4) == 0;          // every group of 4 columns is fully in range
+    float v[NI][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (r < nvalid) store_from_f32(dst, off + r * estride, g.out_dtype, v[r]);
+    for (int i = 0; i < NI; ++i) {
+        v[i][0] = acc[i][0] + bias[i].x; v[i][1] = acc[i][1] + bias[i].y;
+        v[i][2] = acc[i][2] + bias[i].z; v[i][3] = acc[i][3] + bias[i].w;
+    }
+    if (g.res_mode == RES_NONE) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) apply_act<T>(g, v[i]);
+    } else {
+        float4 rv[NI], rv2[NI];
+        const bool strided = g.map_mode == MAP_NCHW || g.map_mode == MAP_QKV;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            rv[i] = make_float4(0.f, 0.f, 0.f, 0.f); rv2[i] = rv[i];
+            if (ncol[i] >= g.N) continue;
+            const size_t roff = g.res_mode == RES_PERIODIC ? rres + ncol[i] : r0 + cp[i].off;
+            if (fast && !strided) {
+                rv[i] = load4_as_f32(g.res, roff, g.res_dtype);
+                if (g.res2) rv2[i] = load4_as_f32(g.res2, roff, g.res_dtype);
+            } else {
+                float t[4] = {0.f, 0.f, 0.f, 0.f};
+                for (int r = 0; r < 4; ++r)
+                    if (ncol[i] + r < g.N) t[r] = load_as_f32(g.res, roff + r, g.res_dtype) + (g.res2 ? load_as_f32(g.res2, roff + r, g.res_dtype) : 0.f);
+                rv[i] = make_float4(t[0], t[1], t[2], t[3]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            apply_act<T>(g, v[i]);
+            v[i][0] += rv[i].x + rv2[i].x; v[i][1] += rv[i].y + rv2[i].y;
+            v[i][2] += rv[i].z + rv2[i].z; v[i][3] += rv[i].w + rv2[i].w;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        if (ncol[i] >= g.N) continue;
+        void* dst = g.C;
+        size_t off = r0 + cp[i].off, estride = 1;
+        if (g.map_mode == MAP_QKV) {
+            if (cp[i].which == 2) { dst = g.Cv; off = r1 + cp[i].off; estride = g.qkv_npad; }
+            else if (cp[i].which == 1) dst = g.Ck;
+        } else if (g.map_mode == MAP_NCHW) {
+            estride = g.p_div;
+        }
+        if (estride == 1 && fast) {
+            store4(dst, off, g.out_dtype, v[i]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (ncol[i] + r < g.N) store_from_f32(dst, off + r * estride, g.out_dtype, v[i][r]);
+        }
     }
 }
 
@@ -268,19 +345,37 @@ __global__ __launch_bounds__(256) void lseg_gemm_kernel(const GemmArgs g) {
     }
 
     // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] ----------------
-    // The (out-of-line) epilogue reads its parameters straight from the kernarg segment, so
-    // the by-value GemmArgs is never copied to scratch.
-    const GemmArgs& gk = *reinterpret_cast<const GemmArgs*>((const void*)__builtin_amdgcn_kernarg_segment_ptr());
+    int ncol[NI];
+    ColPart cp[NI];
+    float4 bias[NI];
 #pragma unroll
-    for (int j = 0; j < MI; ++j) {
-        const int m = m0 + wm * WM + j * 16 + (lane & 15);
-        if (m >= g.M) continue;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int n = n0 + wn * WN + i * 16 + (lane >> 4) * 4;
-            epilogue4<T>(gk, m, n, acc[i][j]);
+    for (int i = 0; i < NI; ++i) {
+        const int n = n0 + wn * WN + i * 16 + (lane >> 4) * 4;
+        ncol[i] = n;
+        cp[i] = col_part(g, n < g.N ? n : 0);
+        bias[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.bias && n < g.N) {
+            const int bn = g.bias_mod ? (n % g.bias_mod) : n;
+            if ((g.N & 3) == 0) {
+                bias[i] = *reinterpret_cast<const float4*>(g.bias + bn);
+            } else {
+                bias[i].x = g.bias[bn];
+                if (n + 1 < g.N) bias[i].y = g.bias[bn + 1];
+                if (n + 2 < g.N) bias[i].z = g.bias[bn + 2];
+                if (n + 3 < g.N) bias[i].w = g.bias[bn + 3];
+            }
         }
     }
+    static_for<0, MI>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const int m = m0 + wm * WM + j * 16 + (lane & 15);
+        if (m < g.M) {
+            f32x4_t row[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) row[i] = acc[i][j];
+            epilogue_row<T, NI>(g, m, ncol, cp, bias, row);
+        }
+    });
 }
 
 template <typename T, int BM, int BN, bool CONV, bool RELU_IN, int TAG>

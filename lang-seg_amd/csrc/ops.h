@@ -17,7 +17,7 @@ int launch_readout_cat(const float* x, void* A, int B, int ntok, int D, int dtyp
 int launch_upsample2x_nhwc(const void* in, void* out, int B, int H, int W, int C, int dtype, hipStream_t st);
 int launch_upsample2x_planes(const float* in, float* out, int P, int H, int W, hipStream_t st);
 int launch_l2norm_scale_f16(const float* f, void* a, int M, int C, float scale, hipStream_t st);
-int launch_text_embed(const int64_t* tok, const float* emb, const float* pos, void* x, int rows, int L, int W, hipStream_t st);
+int launch_text_embed(const int64_t* tok, const float* emb, const float* pos, void* x, int rows, int L, int ctx, int W, hipStream_t st);
 int launch_text_pool(const void* x, const int* eot, void* pooled, int K, int L, int W, hipStream_t st);
 int launch_text_l2norm(const void* t, void* out, int K, int C, hipStream_t st);
 int launch_convert(const void* in, int in_dtype, void* out, int out_dtype, size_t n, hipStream_t st);

@@ -1,0 +1,122 @@
+"""LSegmentationModule -- mirror of the reference's modules/lsegmentation_module.py:26-304
+(Lightning base: forward / evaluate / evaluate_random, optimiser param groups + poly LR,
+criterion).  pytorch_lightning and PyTorch-Encoding are used when importable; when they are
+absent (this build environment) the class degrades to a plain nn.Module with the same
+attributes so the forward/evaluate surface (what test_lseg.py and the evaluators call) works.
+"""
+from argparse import ArgumentParser
+
+import torch
+import torch.nn as nn
+
+try:
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except ImportError:          # no Lightning: keep the nn.Module protocol the evaluators rely on
+    pl = None
+
+    class _Base(nn.Module):
+        def log(self, *a, **k):
+            pass
+
+try:
+    from encoding.nn import SegmentationLosses
+    from encoding.utils import batch_pix_accuracy, batch_intersection_union, SegmentationMetric
+except ImportError:
+    SegmentationLosses = SegmentationMetric = None
+
+    def batch_pix_accuracy(output, target):
+        """[3P] encoding/utils/metrics.py."""
+        predict = torch.argmax(output.long() if output.dtype == torch.bool else output, 1) + 1
+        target = target.long() + 1
+        pixel_labeled = (target > 0).sum()
+        pixel_correct = ((predict == target) & (target > 0)).sum()
+        return pixel_correct.item(), pixel_labeled.item()
+
+    def batch_intersection_union(output, target, nclass):
+        predict = torch.argmax(output, 1) + 1
+        target = target.long() + 1
+        predict = predict * (target > 0).long()
+        intersection = predict * (predict == target).long()
+        area_inter = torch.histc(intersection.float().cpu(), bins=nclass, min=1, max=nclass)
+        area_pred = torch.histc(predict.float().cpu(), bins=nclass, min=1, max=nclass)
+        area_lab = torch.histc(target.float().cpu(), bins=nclass, min=1, max=nclass)
+        return area_inter.numpy(), (area_pred + area_lab - area_inter).numpy()
+
+
+class LSegmentationModule(_Base):
+    def __init__(self, data_path, dataset, batch_size, base_lr, max_epochs, **kwargs):
+        super().__init__()
+        self.data_path = data_path
+        self.batch_size = batch_size
+        self.base_lr = base_lr / 16 * batch_size             # lsegmentation_module.py:32
+        self.lr = self.base_lr
+        self.epochs = max_epochs
+        self.other_kwargs = kwargs
+        self.enabled = False                                  # AMP explicitly off (:37)
+
+    def forward(self, x):
+        return self.net(x)
+
+    def evaluate(self, x, target=None):                       # :43-52
+        pred = self.net.forward(x)
+        if isinstance(pred, (tuple, list)):
+            pred = pred[0]
+        if target is None:
+            return pred
+        correct, labeled = batch_pix_accuracy(pred.data, target.data)
+        inter, union = batch_intersection_union(pred.data, target.data, self.nclass)
+        return correct, labeled, inter, union
+
+    def evaluate_random(self, x, labelset, target=None):      # :54-63
+        pred = self.net.forward(x, labelset)
+        if isinstance(pred, (tuple, list)):
+            pred = pred[0]
+        if target is None:
+            return pred
+        correct, labeled = batch_pix_accuracy(pred.data, target.data)
+        inter, union = batch_intersection_union(pred.data, target.data, self.nclass)
+        return correct, labeled, inter, union
+
+    def training_step(self, batch, batch_nb):                 # :66-81
+        raise NotImplementedError("training step (backward kernels + RCCL gradient all-reduce) is the next "
+                                  "row of the hot-path scope (SURVEY.md §8a17/§8e); this round ships inference")
+
+    def _filter_invalid(self, pred, target):                  # :114-117
+        valid = target != self.other_kwargs["ignore_index"]
+        _, mx = torch.max(pred, dim=1)
+        return mx[valid], target[valid]
+
+    def configure_optimizers(self):                           # :119-175 (same param groups / poly LR)
+        params_list = [{"params": self.net.pretrained.parameters(), "lr": self.base_lr}]
+        if hasattr(self.net, "scratch"):
+            params_list.append({"params": self.net.scratch.parameters(), "lr": self.base_lr * 10})
+        opt = torch.optim.SGD(params_list, lr=self.base_lr, momentum=0.9,
+                              weight_decay=self.other_kwargs.get("weight_decay", 1e-4))
+        sch = torch.optim.lr_scheduler.LambdaLR(opt, lambda x: pow(1.0 - x / self.epochs, 0.9))
+        return [opt], [sch]
+
+    def get_criterion(self, **kwargs):                        # :236-244
+        if SegmentationLosses is None:
+            return nn.CrossEntropyLoss(ignore_index=kwargs.get("ignore_index", -1))
+        return SegmentationLosses(se_loss=kwargs["se_loss"], aux=kwargs["aux"], nclass=self.num_classes,
+                                  se_weight=kwargs["se_weight"], aux_weight=kwargs["aux_weight"],
+                                  ignore_index=kwargs["ignore_index"])
+
+    @staticmethod
+    def add_model_specific_args(parent_parser):               # :246-304
+        parser = ArgumentParser(parents=[parent_parser], add_help=False)
+        parser.add_argument("--data_path", type=str, help="path where dataset is stored")
+        parser.add_argument("--dataset", default="ade20k", help="dataset to train on")
+        parser.add_argument("--batch_size", type=int, default=16, help="size of the batches")
+        parser.add_argument("--base_lr", type=float, default=0.004, help="learning rate")
+        parser.add_argument("--momentum", type=float, default=0.9, help="SGD momentum")
+        parser.add_argument("--weight_decay", type=float, default=1e-4, help="weight_decay")
+        parser.add_argument("--aux", action="store_true", default=False, help="Auxilary Loss")
+        parser.add_argument("--aux-weight", type=float, default=0.2, help="Auxilary loss weight (default: 0.2)")
+        parser.add_argument("--se-loss", action="store_true", default=False, help="Semantic Encoding Loss SE-loss")
+        parser.add_argument("--se-weight", type=float, default=0.2, help="SE-loss weight (default: 0.2)")
+        parser.add_argument("--midasproto", action="store_true", default=False, help="midasprotocol")
+        parser.add_argument("--ignore_index", type=int, default=-1, help="numeric value of ignore label in gt")
+        parser.add_argument("--augment", action="store_true", default=False, help="Use extended augmentations")
+        return parser

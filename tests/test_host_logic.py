@@ -1,0 +1,151 @@
+"""CPU-side checks: the drop-in boundary (module tree, state-dict keys, attributes, CLI flags),
+label parsing, tokenisation contract, and that liblseg_hip.so loads and exports every symbol
+declared in include/lseg_hip.h (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+import warnings
+
+import pytest
+import torch
+
+from lseg_hip.config import get_config
+from lseg_hip.synth import synthetic_state_dict, synthetic_tokens, read_labels, EOT_TOKEN, SOT_TOKEN
+
+
+def test_capi_library_loads_and_exports_every_declared_symbol(repo_root):
+    from lseg_hip import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(repo_root, "include", "lseg_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(lseg_[a-z0-9_]+)\s*\(", hdr, re.M))
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in lseg_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.lseg_abi_version() == _lib.ABI_VERSION
+    # struct layout agrees with the header (27 + 4*3 + ... int32 fields)
+    n_fields = len(re.findall(r"int32_t\s+[a-z_, \[\]0-9]+;", hdr.split("typedef struct {")[1].split("} lseg_config;")[0]))
+    assert ctypes.sizeof(_lib.LSegConfigC) % 4 == 0 and n_fields >= 20
+
+
+def test_no_device_fails_loudly():
+    from lseg_hip import _lib
+    lib = _lib.load()
+    if lib.lseg_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    rc = lib.lseg_op_gemm(None, None, None, None, None, 1, 1, 64, 2, 0, 0, None)
+    assert rc == -2 and b"no CPU fallback" in lib.lseg_last_error(None)
+    from lseg_hip.engine import HipEngine
+    with pytest.raises(_lib.LSegError):
+        HipEngine(get_config("tiny16"), 64, 64, 1, 2)
+
+
+def test_labels_parse_like_the_reference(repo_root):
+    labels = read_labels(os.path.join(repo_root, "lang-seg_amd", "label_files", "ade20k_objectInfo150.txt"))
+    assert len(labels) == 150 and labels[:5] == ["wall", "building", "sky", "floor", "tree"] and labels[-1] == "flag"
+    fss = read_labels(os.path.join(repo_root, "lang-seg_amd", "label_files", "fewshot_fss.txt"), skip_header=False)
+    assert len(fss) == 1000
+
+
+def test_synthetic_tokens_contract():
+    t = synthetic_tokens(["wall", "potted plant", ""], 49408, 77)
+    assert t.shape == (3, 77) and t.dtype == torch.int64
+    assert (t[:, 0] == SOT_TOKEN).all()
+    for row in t:
+        e = int(row.argmax())
+        assert row[e] == EOT_TOKEN and (row[e + 1:] == 0).all() and (row[1:e] < SOT_TOKEN).all()
+    assert t[1].argmax() == 3 and not torch.equal(t[0], t[1])
+
+
+def test_tokenize_falls_back_with_warning():
+    from lseg_hip import tokenizer
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        t = tokenizer.tokenize(["cat", "grass"])
+    assert t.shape == (2, 77)
+    try:
+        import clip  # noqa: F401
+    except ImportError:
+        if tokenizer._vocab_path() is None:
+            assert any("synthetic token ids" in str(x.message) for x in w)
+
+
+@pytest.mark.parametrize("backbone", ["clip_vitl16_384", "clip_vitb32_384", "tiny16"])
+def test_lsegnet_state_dict_layout_matches_reference_keys(backbone):
+    """the module tree must expose exactly the reference's keys/shapes/dtypes."""
+    warnings.simplefilter("ignore")
+    from modules.models.lseg_net import LSegNet
+    cfg = get_config(backbone)
+    with torch.device("meta") if backbone == "clip_vitl16_384" else torch.device("cpu"):
+        net = LSegNet(labels=["a", "b"], backbone=backbone, features=cfg.features, arch_option=0,
+                      block_depth=0, activation="lrelu")
+    have = {k: (tuple(v.shape), v.dtype) for k, v in net.state_dict().items()}
+    want = {k: (tuple(v.shape), v.dtype) for k, v in synthetic_state_dict(get_config(backbone) if backbone != "clip_vitl16_384" else cfg).items()} \
+        if backbone != "clip_vitl16_384" else None
+    if want is not None:
+        assert have == want
+    for k in ("pretrained.model.blocks.0.attn.qkv.weight", "pretrained.act_postprocess1.0.project.0.weight",
+              "pretrained.act_postprocess1.3.weight", "pretrained.act_postprocess1.4.weight",
+              "scratch.layer1_rn.weight", "scratch.refinenet1.resConfUnit1.bn1.running_var",
+              "scratch.refinenet4.out_conv.bias", "scratch.head1.weight",
+              "clip_pretrained.transformer.resblocks.0.attn.in_proj_weight", "clip_pretrained.text_projection",
+              "clip_pretrained.token_embedding.weight", "pretrained.model.norm.weight", "pretrained.model.head.bias"):
+        assert k in have, k
+    assert "logit_scale" not in have and not any(k.startswith("text") for k in have)   # lseg_net.py:141,158
+    assert have["clip_pretrained.transformer.resblocks.0.mlp.c_fc.weight"][1] == torch.float16
+    assert have["clip_pretrained.ln_final.weight"][1] == torch.float32
+    if backbone == "clip_vitl16_384":
+        assert have["pretrained.model.pos_embed"][0] == (1, 577, 1024)
+        assert have["pretrained.act_postprocess4.4.weight"][0] == (1024, 1024, 3, 3)
+        assert have["pretrained.act_postprocess1.4.weight"][0] == (256, 256, 4, 4)
+
+
+def test_lsegnet_surface_and_errors():
+    warnings.simplefilter("ignore")
+    from modules.models.lseg_net import LSegNet
+    net = LSegNet(labels=["wall", "sky", "tree"], backbone="tiny16", features=64, arch_option=0,
+                  block_depth=0, activation="lrelu")
+    assert net.text.shape == (3, 77) and net.out_c == 128 and net.crop_size == 480
+    assert abs(float(net.logit_scale) - 14.285714) < 1e-4 and not isinstance(net.logit_scale, torch.nn.Parameter)
+    assert hasattr(net, "clip_pretrained") and hasattr(net, "pretrained") and hasattr(net, "scratch")
+    net.pretrained.model.patch_embed.img_size = (480, 480)          # lseg_module.py:86-89
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        net.eval()(torch.zeros(1, 3, 64, 64))
+    # the visual tower of a real checkpoint round-trips through load/state_dict
+    sd = net.state_dict()
+    sd["clip_pretrained.visual.conv1.weight"] = torch.zeros(2, 2)
+    res = net.load_state_dict(sd, strict=True)
+    assert "clip_pretrained.visual.conv1.weight" in net.state_dict()
+    with pytest.raises(AssertionError):
+        LSegNet(labels=["a"], backbone="resnet101", features=64, arch_option=0, block_depth=0, activation="lrelu")
+
+
+def test_lsegmodule_surface(repo_root, monkeypatch):
+    warnings.simplefilter("ignore")
+    monkeypatch.chdir(os.path.join(repo_root, "lang-seg_amd"))
+    from modules.lseg_module import LSegModule
+    from argparse import ArgumentParser
+    parser = LSegModule.add_model_specific_args(ArgumentParser(add_help=False))
+    args = parser.parse_args(["--backbone", "tiny16", "--num_features", "64", "--data_path", "/nonexistent",
+                              "--batch_size", "2", "--base_lr", "0.004"])
+    assert args.arch_option == 0 and args.activation == "lrelu" and args.ignore_index == -1
+    m = LSegModule(max_epochs=1, **vars(args))
+    assert (m.base_size, m.crop_size) == (520, 480) and m.mean == [0.5] * 3 and m.std == [0.5] * 3
+    assert m._up_kwargs == {"mode": "bilinear", "align_corners": True}
+    assert m.num_classes == 150 and len(m.net.labels) == 150 and m.net.text.shape == (150, 77)
+    assert m.base_lr == 0.004 / 16 * 2
+    assert m.net.pretrained.model.patch_embed.img_size == (480, 480)
+    opt, sch = m.configure_optimizers()
+    assert len(opt[0].param_groups) == 2 and opt[0].param_groups[1]["lr"] == pytest.approx(10 * m.base_lr)
+    for attr in ("forward", "evaluate", "evaluate_random", "training_step", "cpu", "cuda", "eval", "state_dict"):
+        assert hasattr(m, attr)
+
+
+def test_shard_ranges_cover_everything():
+    from lseg_hip.dist import shard_range
+    for n in (0, 1, 7, 32, 33):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(e - s for s, e in spans) - min(e - s for s, e in spans) <= 1
