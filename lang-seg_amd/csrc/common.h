@@ -118,6 +118,14 @@ __device__ __forceinline__ void glds_slab_row(const uint16_t* src_row, int row_i
         (const __attribute__((address_space(1))) void*)(src_row + chunk * 8),
         (__attribute__((address_space(3))) void*)lds_slab, 16, 0, 0);
 }
+// Same, with a wave-uniform base pointer and a 32-bit per-lane byte offset (lets the compiler use
+// the SGPR-base + VGPR-offset addressing form: no 64-bit VALU adds in the K-loop).
+__device__ __forceinline__ void glds_slab_off(const char* base_uniform, uint32_t lane_byte_off,
+                                              char* lds_slab /* wave-uniform */) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(base_uniform + lane_byte_off),
+        (__attribute__((address_space(3))) void*)lds_slab, 16, 0, 0);
+}
 // Byte offset of logical 16-byte chunk `c` of row `r` inside a swizzled tile.
 __device__ __forceinline__ int tile_off(int r, int c) { return r * 128 + ((c ^ swz(r)) << 4); }
 

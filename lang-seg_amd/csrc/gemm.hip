@@ -237,54 +237,66 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& g, int m, const int
 }
 
 template <typename T, int BM, int BN, bool CONV, bool RELU_IN, int TAG>
-__global__ __launch_bounds__(256) void lseg_gemm_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(256, 2) void lseg_gemm_kernel(const GemmArgs g) {
     constexpr int WM = BM / 2, WN = BN / 2;     // per-wave sub-tile
     constexpr int MI = WM / 16, NI = WN / 16;   // 16x16 MFMA tiles per wave
     constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
     constexpr int A_SLABS = BM / 32, W_SLABS = BN / 32;   // 8-row slabs per wave per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform -> SALU addressing
     const int wm = w >> 1, wn = w & 1;
 
-    // ---- XCD-aware rasterisation: consecutive tile ids (same A row-block) share an XCD/L2 ----
+    // ---- persistent, XCD-aware tile schedule ------------------------------------------------------
+    // Workgroup b lands on XCD b%8 (observed dispatch, used for L2 affinity only).  XCD x owns the
+    // contiguous tile range [xs, xs+xc); its gridDim/8 workgroups walk it with stride gridDim/8, so
+    // at any time the XCD's workgroups sit on neighbouring tiles (same A row-block, adjacent W
+    // panels).  Tiles are n-fastest.
     const int tiles_n = (g.N + BN - 1) / BN;
-    const int nwg = gridDim.x;
-    int tile;
+    const int tiles_m = (g.M + BM - 1) / BM;
+    const int total = tiles_m * tiles_n;
+    const int wpx = gridDim.x >> 3;                       // gridDim.x is a multiple of 8
+    int tile, tile_end;
     {
-        const int bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int q = total >> 3, r = total & 7;
+        const int xs = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        tile = xs + idx;
+        tile_end = xs + q + (xcd < r ? 1 : 0);
     }
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    if (tile >= tile_end) return;
 
-    // ---- per-lane source rows for the direct-to-LDS loads -----------------------------------
-    const uint16_t* a_src[A_SLABS];
-    const uint16_t* w_src[W_SLABS];
-    int a_row[A_SLABS], w_row[W_SLABS];
+    // per-lane BYTE offsets (32-bit) of this lane's source rows, incl. the swizzled 16-byte chunk
+    uint32_t a_off[A_SLABS], w_off[W_SLABS];
+    const int lrow = lane >> 3;                           // row inside an 8-row slab
+    auto setup = [&](int t, int& m0, int& n0) {
+        m0 = (t / tiles_n) * BM;
+        n0 = (t - (t / tiles_n) * tiles_n) * BN;
 #pragma unroll
-    for (int s = 0; s < A_SLABS; ++s) {
-        const int r = (s * 4 + w) * 8 + (lane >> 3);
-        a_row[s] = r;
-        int m = m0 + r;
-        if (m > g.M - 1) m = g.M - 1;
-        if (CONV) {
-            const int hw = g.ho * g.wo;
-            const int b = m / hw, p = m - b * hw;
-            const int y = p / g.wo, x = p - y * g.wo;
-            a_src[s] = g.A + ((size_t)(b * g.hp + y * g.stride) * g.wp + x * g.stride) * g.cin;
-        } else {
-            a_src[s] = g.A + (size_t)m * g.lda;
+        for (int s = 0; s < A_SLABS; ++s) {
+            const int r = (s * 4 + w) * 8 + lrow;
+            int m = m0 + r;
+            if (m > g.M - 1) m = g.M - 1;
+            uint32_t e;
+            if (CONV) {
+                const int hw = g.ho * g.wo;
+                const int b = m / hw, p = m - b * hw;
+                const int y = p / g.wo, x = p - y * g.wo;
+                e = (uint32_t)(((b * g.hp + y * g.stride) * g.wp + x * g.stride) * g.cin);
+            } else {
+                e = (uint32_t)m * (uint32_t)g.lda;
+            }
+            a_off[s] = (e + (((lane & 7) ^ swz(r)) << 3)) * 2u;
         }
-    }
 #pragma unroll
-    for (int s = 0; s < W_SLABS; ++s) {
-        const int r = (s * 4 + w) * 8 + (lane >> 3);
-        w_row[s] = r;
-        int n = n0 + r;
-        if (n > g.N - 1) n = g.N - 1;
-        w_src[s] = g.W + (size_t)n * g.ldw;
-    }
+        for (int s = 0; s < W_SLABS; ++s) {
+            const int r = (s * 4 + w) * 8 + lrow;
+            int n = n0 + r;
+            if (n > g.N - 1) n = g.N - 1;
+            w_off[s] = ((uint32_t)n * (uint32_t)g.ldw + (((lane & 7) ^ swz(r)) << 3)) * 2u;
+        }
+    };
 
     const int nk = g.K >> 6;
     const int cpt = CONV ? (g.cin >> 6) : 1;    // 64-wide K chunks per conv tap
@@ -300,88 +312,135 @@ __global__ __launch_bounds__(256) void lseg_gemm_kernel(const GemmArgs g) {
         } else {
             koff_a = kt << 6;
         }
-        const int koff_w = kt << 6;
+        const char* abase = reinterpret_cast<const char*>(g.A + koff_a);       // wave-uniform
+        const char* wbase = reinterpret_cast<const char*>(g.W + (kt << 6));
 #pragma unroll
-        for (int s = 0; s < A_SLABS; ++s)
-            glds_slab_row(a_src[s] + koff_a, a_row[s], lane, sa + (s * 4 + w) * 1024);
+        for (int s = 0; s < A_SLABS; ++s) glds_slab_off(abase, a_off[s], sa + (s * 4 + w) * 1024);
 #pragma unroll
-        for (int s = 0; s < W_SLABS; ++s)
-            glds_slab_row(w_src[s] + koff_w, w_row[s], lane, sw + (s * 4 + w) * 1024);
+        for (int s = 0; s < W_SLABS; ++s) glds_slab_off(wbase, w_off[s], sw + (s * 4 + w) * 1024);
     };
 
     f32x4_t acc[NI][MI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < MI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // LDS fragment byte offsets of this lane (ks = 0 / 1); sub-tiles add i*2048 / j*2048
+    const int frow = lane & 15;
+    const int foff0 = tile_off(frow, lane >> 4), foff1 = tile_off(frow, 4 + (lane >> 4));
+    const int wbase_off = A_BYTES + wn * WN * 128, abase_off = wm * WM * 128;
 
+    auto compute = [&](int stage) {
+        const char* st = smem + stage * STAGE;
+        i32x4_t wf0[NI], af0[MI], wf1[NI], af1[MI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) wf0[i] = *reinterpret_cast<const i32x4_t*>(st + wbase_off + i * 2048 + foff0);
+#pragma unroll
+        for (int j = 0; j < MI; ++j) af0[j] = *reinterpret_cast<const i32x4_t*>(st + abase_off + j * 2048 + foff0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) wf1[i] = *reinterpret_cast<const i32x4_t*>(st + wbase_off + i * 2048 + foff1);
+#pragma unroll
+        for (int j = 0; j < MI; ++j) af1[j] = *reinterpret_cast<const i32x4_t*>(st + abase_off + j * 2048 + foff1);
+        if (RELU_IN) {
+#pragma unroll
+            for (int j = 0; j < MI; ++j) { af0[j] = relu_frag(af0[j]); af1[j] = relu_frag(af1[j]); }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < MI; ++j) acc[i][j] = mfma16<T>(wf0[i], af0[j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < MI; ++j) acc[i][j] = mfma16<T>(wf1[i], af1[j], acc[i][j]);
+        // schedule: the ks=0 fragments first, then the ks=1 fragment reads ride under the ks=0
+        // MFMAs (one exposed LDS latency per K-step instead of one per fragment)
+        __builtin_amdgcn_sched_group_barrier(0x100, NI + MI, 0);              // DS reads (ks=0)
+#pragma unroll
+        for (int q = 0; q < (NI + MI) / 2; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, (NI * MI) / ((NI + MI) / 2), 0);   // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                // DS reads (ks=1)
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NI * MI, 0);              // MFMA (ks=1)
+    };
+
+    int m0, n0;
+    setup(tile, m0, n0);
     issue(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        __builtin_amdgcn_s_waitcnt(0);   // own direct-to-LDS loads of tile kt have landed
-        __syncthreads();                 // everyone's have; everyone is done reading stage (kt+1)&1
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-        const char* sa = smem + (kt & 1) * STAGE;
-        const char* sw = sa + A_BYTES;
+    int stage = 0;
+    while (true) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int c = ks * 4 + (lane >> 4);
-            i32x4_t wf[NI], af[MI];
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int r = wn * WN + i * 16 + (lane & 15);
-                wf[i] = *reinterpret_cast<const i32x4_t*>(sw + tile_off(r, c));
-            }
-#pragma unroll
-            for (int j = 0; j < MI; ++j) {
-                const int r = wm * WM + j * 16 + (lane & 15);
-                af[j] = *reinterpret_cast<const i32x4_t*>(sa + tile_off(r, c));
-                if (RELU_IN) af[j] = relu_frag(af[j]);
-            }
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int j = 0; j < MI; ++j) acc[i][j] = mfma16<T>(wf[i], af[j], acc[i][j]);
+            for (int j = 0; j < MI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nk - 1; ++kt) {
+            __builtin_amdgcn_s_waitcnt(0);   // own direct-to-LDS loads of this K-block have landed
+            __syncthreads();                 // everyone's have; everyone is done reading the other stage
+            issue(kt + 1, stage ^ 1);
+            compute(stage);
+            stage ^= 1;
         }
-    }
+        // last K-block of the tile (peeled): cross-tile prefetch -- the next tile's first K-block
+        // flies during this tile's last MFMA block and its epilogue
+        const int next = tile + wpx;
+        const bool has_next = next < tile_end;
+        const int m0c = m0, n0c = n0;
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (has_next) {
+            setup(next, m0, n0);
+            issue(0, stage ^ 1);
+        }
+        compute(stage);
+        stage ^= 1;
 
-    // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] ----------------
-    int ncol[NI];
-    ColPart cp[NI];
-    float4 bias[NI];
+        // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] ------------
+        int ncol[NI];
+        ColPart cp[NI];
+        float4 bias[NI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int n = n0 + wn * WN + i * 16 + (lane >> 4) * 4;
-        ncol[i] = n;
-        cp[i] = col_part(g, n < g.N ? n : 0);
-        bias[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g.bias && n < g.N) {
-            const int bn = g.bias_mod ? (n % g.bias_mod) : n;
-            if ((g.N & 3) == 0) {
-                bias[i] = *reinterpret_cast<const float4*>(g.bias + bn);
-            } else {
-                bias[i].x = g.bias[bn];
-                if (n + 1 < g.N) bias[i].y = g.bias[bn + 1];
-                if (n + 2 < g.N) bias[i].z = g.bias[bn + 2];
-                if (n + 3 < g.N) bias[i].w = g.bias[bn + 3];
+        for (int i = 0; i < NI; ++i) {
+            const int n = n0c + wn * WN + i * 16 + (lane >> 4) * 4;
+            ncol[i] = n;
+            cp[i] = col_part(g, n < g.N ? n : 0);
+            bias[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g.bias && n < g.N) {
+                const int bn = g.bias_mod ? (n % g.bias_mod) : n;
+                if ((g.N & 3) == 0) {
+                    bias[i] = *reinterpret_cast<const float4*>(g.bias + bn);
+                } else {
+                    bias[i].x = g.bias[bn];
+                    if (n + 1 < g.N) bias[i].y = g.bias[bn + 1];
+                    if (n + 2 < g.N) bias[i].z = g.bias[bn + 2];
+                    if (n + 3 < g.N) bias[i].w = g.bias[bn + 3];
+                }
             }
         }
-    }
-    static_for<0, MI>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        const int m = m0 + wm * WM + j * 16 + (lane & 15);
-        if (m < g.M) {
+        // runtime loop over the MI output rows of this lane (one copy of the epilogue code); the
+        // accumulator row is selected with static indices so acc[][] stays in registers
+#pragma unroll 1
+        for (int j = 0; j < MI; ++j) {
             f32x4_t row[NI];
+            static_for<0, MI>([&](auto jc) {
+                constexpr int js = decltype(jc)::value;
+                if (j == js) {
 #pragma unroll
-            for (int i = 0; i < NI; ++i) row[i] = acc[i][j];
-            epilogue_row<T, NI>(g, m, ncol, cp, bias, row);
+                    for (int i = 0; i < NI; ++i) row[i] = acc[i][js];
+                }
+            });
+            const int m = m0c + wm * WM + j * 16 + (lane & 15);
+            if (m < g.M) epilogue_row<T, NI>(g, m, ncol, cp, bias, row);
         }
-    });
+        if (!has_next) break;
+        tile = next;
+    }
 }
 
 template <typename T, int BM, int BN, bool CONV, bool RELU_IN, int TAG>
 int launch_one(const GemmArgs& g, hipStream_t stream) {
     const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
     const size_t lds = 2 * (size_t)(BM + BN) * 128;
+    // persistent grid: a multiple of 8 (one slice per XCD), at most `slots` resident workgroups
+    constexpr int per_cu = (BM + BN) * 256 <= 32768 ? 4 : 2;      // LDS-limited workgroups per CU
+    const int slots = 256 * per_cu;
+    int grid = ((tiles + 7) / 8) * 8;
+    if (grid > slots) grid = slots;
     auto kern = lseg_gemm_kernel<T, BM, BN, CONV, RELU_IN, TAG>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -389,7 +448,7 @@ int launch_one(const GemmArgs& g, hipStream_t stream) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), lds, stream, g);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, g);
     LSEG_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -417,6 +476,12 @@ int launch_gemm(const GemmArgs& g, int ab_dtype, hipStream_t stream) {
     if (g.K % 64 != 0) return set_error(LSEG_ERR_UNSUPPORTED, "gemm: K=%d must be a multiple of 64", g.K);
     if (g.conv && (g.cin % 64 != 0)) return set_error(LSEG_ERR_UNSUPPORTED, "conv: Cin=%d must be a multiple of 64", g.cin);
     if ((g.lda % 8) || (g.ldw % 8)) return set_error(LSEG_ERR_UNSUPPORTED, "gemm: lda/ldw must be multiples of 8 elements");
+    {   // per-lane source offsets are 32-bit byte offsets
+        const double a_bytes = g.conv ? (double)g.M * g.stride * g.stride * 1.2 * g.cin * 2 + 4.0 * g.wp * g.cin * 2
+                                      : (double)g.M * g.lda * 2;
+        if (a_bytes >= 4.0e9 || (double)g.N * g.ldw * 2 >= 4.0e9)
+            return set_error(LSEG_ERR_UNSUPPORTED, "gemm: operand larger than 4 GB (32-bit lane offsets)");
+    }
     if (ab_dtype == DT_BF16) return dispatch<BF16>(g, stream);
     if (ab_dtype == DT_F16) return dispatch<F16>(g, stream);
     return set_error(LSEG_ERR_INVALID, "gemm: operand dtype %d", ab_dtype);
