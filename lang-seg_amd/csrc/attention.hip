@@ -35,10 +35,11 @@ struct AttnArgs {
 namespace {
 
 template <typename T>
-__global__ __launch_bounds__(256) void lseg_attention_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, 3) void lseg_attention_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (K 8 KB + Vt 8 KB)
     constexpr int TILE = 8192, STAGE = 2 * TILE;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform
     const int hi = lane >> 5, ql = lane & 31;
     const int bh = blockIdx.y;
     const int q0 = (blockIdx.x * 4 + w) * 32;
@@ -63,15 +64,24 @@ __global__ __launch_bounds__(256) void lseg_attention_kernel(const AttnArgs a) {
     }
     const int n_tiles = (kv_end + 63) >> 6;
 
+    // per-lane byte offsets of the two K rows / two V^T rows this lane streams per tile (swizzled chunk)
+    uint32_t k_off[2], v_off[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int r = (s * 4 + w) * 8 + (lane >> 3);
+        const int ch = ((lane & 7) ^ swz(r)) << 3;
+        k_off[s] = (uint32_t)(r * 64 + ch) * 2u;
+        v_off[s] = (uint32_t)(r * a.npad + ch) * 2u;
+    }
     auto issue = [&](int t, int stage) {
         char* sk = smem + stage * STAGE;
         char* sv = sk + TILE;
+        const char* kb = reinterpret_cast<const char*>(K + (size_t)t * 64 * 64);     // wave-uniform bases
+        const char* vb = reinterpret_cast<const char*>(Vt + (size_t)t * 64);
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const int slab = s * 4 + w;
-            const int r = slab * 8 + (lane >> 3);
-            glds_slab_row(K + (size_t)(t * 64 + r) * 64, r, lane, sk + slab * 1024);
-            glds_slab_row(Vt + (size_t)r * a.npad + t * 64, r, lane, sv + slab * 1024);
+            glds_slab_off(kb, k_off[s], sk + (s * 4 + w) * 1024);
+            glds_slab_off(vb, v_off[s], sv + (s * 4 + w) * 1024);
         }
     };
 
@@ -103,23 +113,24 @@ __global__ __launch_bounds__(256) void lseg_attention_kernel(const AttnArgs a) {
                 s[sub] = mfma32<T>(kf, qf[ks], s[sub]);
             }
         }
-        // ---- scale, mask, online softmax --------------------------------------------------------
-        const bool need_mask = a.causal || (t * 64 + 64 > a.ntok);
+        // ---- mask, online softmax (scale folded into the exp2 argument) -------------------------
+        const bool need_mask = a.causal || (t * 64 + 64 > a.ntok);        // wave-uniform
+        if (need_mask) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * 64 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const bool ok = key < a.ntok && (!a.causal || key <= qrow);
+                    s[sub][r] = ok ? s[sub][r] : -INFINITY;
+                }
+        }
         float mx = -INFINITY;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = s[sub][r] * a.scale_log2e;
-                if (need_mask) {
-                    const int key = t * 64 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const bool ok = key < a.ntok && (!a.causal || key <= qrow);
-                    v = ok ? v : -INFINITY;
-                }
-                s[sub][r] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[sub][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32)) * a.scale_log2e;               // scale > 0
         const float m_new = fmaxf(m_run, mx);
         // exact "defer": when no row of this wave raised its running max the rescale factor is
         // exactly 1 for every lane, so the exp and the 32 accumulator multiplies are skipped
@@ -132,7 +143,7 @@ __global__ __launch_bounds__(256) void lseg_attention_kernel(const AttnArgs a) {
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[sub][r] - m_new);
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[sub][r], a.scale_log2e, -m_new));
                 s[sub][r] = p;
                 lsum += p;
             }

@@ -15,6 +15,7 @@
 // XCD-aware tile rasterisation.  The MFMA is issued "swapped" (weights as the row
 // operand) so each lane ends up with 4 consecutive output channels of one row ->
 // 8/16-byte epilogue stores and float4 bias/residual loads.
+#include <cstdlib>
 #include <type_traits>
 
 #include "gemm.h"
@@ -171,6 +172,30 @@ __device__ __forceinline__ void store4(void* dst, size_t off, int dtype, const f
     }
 }
 
+// Per-tile column info of this lane: first column of each 4-wide group, its address part, its bias.
+template <int NI>
+__device__ __forceinline__ void epilogue_cols(const GemmArgs& g, int n_first, int (&ncol)[NI], ColPart (&cp)[NI],
+                                              float4 (&bias)[NI]) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int n = n_first + i * 16;
+        ncol[i] = n;
+        cp[i] = col_part(g, n < g.N ? n : 0);
+        bias[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g.bias && n < g.N) {
+            const int bn = g.bias_mod ? (n % g.bias_mod) : n;
+            if ((g.N & 3) == 0) {
+                bias[i] = *reinterpret_cast<const float4*>(g.bias + bn);
+            } else {
+                bias[i].x = g.bias[bn];
+                if (n + 1 < g.N) bias[i].y = g.bias[bn + 1];
+                if (n + 2 < g.N) bias[i].z = g.bias[bn + 2];
+                if (n + 3 < g.N) bias[i].w = g.bias[bn + 3];
+            }
+        }
+    }
+}
+
 // One output row m of this lane: NI groups of 4 consecutive columns.  All residual loads of the
 // row are issued before the first store (the residual may alias C: x += f(x) in place).
 template <typename T, int NI>
@@ -236,17 +261,49 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& g, int m, const int
     }
 }
 
-template <typename T, int BM, int BN, bool CONV, bool RELU_IN, int TAG>
-__global__ __launch_bounds__(256, 2) void lseg_gemm_kernel(const GemmArgs g) {
-    constexpr int WM = BM / 2, WN = BN / 2;     // per-wave sub-tile
-    constexpr int MI = WM / 16, NI = WN / 16;   // 16x16 MFMA tiles per wave
-    constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
-    constexpr int A_SLABS = BM / 32, W_SLABS = BN / 32;   // 8-row slabs per wave per stage
+// Tile configuration: BM x BN block tile, WGM x WGN waves (each wave owns a 64x64 sub-tile built
+// from 4x4 v_mfma_f32_16x16x32 tiles), NS LDS stages of BK = 64.
+//   Big   256x128, 4x2 waves, 3 stages (144 KB LDS, 1 workgroup/CU, loads fly two K-steps ahead)
+//   Mid   128x128, 2x2 waves, 2 stages ( 64 KB LDS, 2 workgroups/CU)
+//   Small  64x64,  2x2 waves (32x32 per wave), 2 stages: fills the chip when M*N is small
+template <int BM_, int BN_, int WGM_, int WGN_, int NS_>
+struct TileCfg {
+    static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, NS = NS_;
+    static constexpr int NW = WGM * WGN, THREADS = 64 * NW;
+    static constexpr int WM = BM / WGM, WN = BN / WGN;          // per-wave sub-tile
+    static constexpr int MI = WM / 16, NI = WN / 16;            // 16x16 MFMA tiles per wave
+    static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
+    static constexpr int A_SPW = BM / 8 / NW, W_SPW = BN / 8 / NW;   // 8-row slabs per wave per stage
+    static constexpr int SPW = A_SPW + W_SPW;
+    static constexpr int LDS = NS * STAGE;
+    static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "slabs must divide evenly over the waves");
+};
+using CfgBig = TileCfg<256, 128, 4, 2, 3>;
+using CfgMid = TileCfg<128, 128, 2, 2, 2>;
+using CfgSmall = TileCfg<64, 64, 2, 2, 2>;
+
+// Counted waits go through the BUILTIN, not inline asm: SIInsertWaitcnts understands a pre-existing
+// s_waitcnt and keeps its own scoreboard consistent.  An opaque asm wait left it believing that
+// epilogue loads were still pending across the persistent-loop back edge, and it planted a
+// vmcnt(0) in the middle of every K-step (draining the prefetch: -35% on K=1024 shapes).
+// gfx9 simm16: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] at [15:14]
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+}
+__device__ __forceinline__ void wait_lgkmcnt0() { __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14)); }
+
+template <typename T, typename CFG, bool CONV, bool RELU_IN, int TAG>
+__global__ __launch_bounds__(CFG::THREADS, 2) void lseg_gemm_kernel(const GemmArgs g) {
+    constexpr int BM = CFG::BM, BN = CFG::BN, NS = CFG::NS, NW = CFG::NW;
+    constexpr int WM = CFG::WM, WN = CFG::WN, MI = CFG::MI, NI = CFG::NI;
+    constexpr int A_BYTES = CFG::A_BYTES, STAGE = CFG::STAGE, A_SPW = CFG::A_SPW, W_SPW = CFG::W_SPW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // the out-of-line epilogue reads its parameters straight from the kernarg segment
+    const GemmArgs& gk = *reinterpret_cast<const GemmArgs*>((const void*)__builtin_amdgcn_kernarg_segment_ptr());
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform -> SALU addressing
-    const int wm = w >> 1, wn = w & 1;
+    const int wm = w / CFG::WGN, wn = w % CFG::WGN;
 
     // ---- persistent, XCD-aware tile schedule ------------------------------------------------------
     // Workgroup b lands on XCD b%8 (observed dispatch, used for L2 affinity only).  XCD x owns the
@@ -267,15 +324,16 @@ __global__ __launch_bounds__(256, 2) void lseg_gemm_kernel(const GemmArgs g) {
     }
     if (tile >= tile_end) return;
 
+    // ---- load side: runs NS-1 K-steps ahead of the MFMA side, across tile boundaries -------------
     // per-lane BYTE offsets (32-bit) of this lane's source rows, incl. the swizzled 16-byte chunk
-    uint32_t a_off[A_SLABS], w_off[W_SLABS];
+    uint32_t a_off[A_SPW], w_off[W_SPW];
     const int lrow = lane >> 3;                           // row inside an 8-row slab
-    auto setup = [&](int t, int& m0, int& n0) {
-        m0 = (t / tiles_n) * BM;
-        n0 = (t - (t / tiles_n) * tiles_n) * BN;
+    auto setup = [&](int t) {
+        const int m0 = (t / tiles_n) * BM;
+        const int n0 = (t - (t / tiles_n) * tiles_n) * BN;
 #pragma unroll
-        for (int s = 0; s < A_SLABS; ++s) {
-            const int r = (s * 4 + w) * 8 + lrow;
+        for (int s = 0; s < A_SPW; ++s) {
+            const int r = (s * NW + w) * 8 + lrow;
             int m = m0 + r;
             if (m > g.M - 1) m = g.M - 1;
             uint32_t e;
@@ -290,8 +348,8 @@ __global__ __launch_bounds__(256, 2) void lseg_gemm_kernel(const GemmArgs g) {
             a_off[s] = (e + (((lane & 7) ^ swz(r)) << 3)) * 2u;
         }
 #pragma unroll
-        for (int s = 0; s < W_SLABS; ++s) {
-            const int r = (s * 4 + w) * 8 + lrow;
+        for (int s = 0; s < W_SPW; ++s) {
+            const int r = (s * NW + w) * 8 + lrow;
             int n = n0 + r;
             if (n > g.N - 1) n = g.N - 1;
             w_off[s] = ((uint32_t)n * (uint32_t)g.ldw + (((lane & 7) ^ swz(r)) << 3)) * 2u;
@@ -300,26 +358,37 @@ __global__ __launch_bounds__(256, 2) void lseg_gemm_kernel(const GemmArgs g) {
 
     const int nk = g.K >> 6;
     const int cpt = CONV ? (g.cin >> 6) : 1;    // 64-wide K chunks per conv tap
-
-    auto issue = [&](int kt, int stage) {
-        char* sa = smem + stage * STAGE;
+    int itile = tile, ikt = 0, istage = 0;
+    setup(itile);
+    // issue the loads of K-step (itile, ikt) into LDS stage istage, then advance.  After the last
+    // tile the same tile is re-issued (never consumed): every K-step issues exactly SPW loads per
+    // wave, so the counted vmcnt below stays exact.
+    auto issue_next = [&]() {
+        char* sa = smem + istage * STAGE;
         char* sw = sa + A_BYTES;
         int koff_a;
         if (CONV) {
-            const int tap = kt / cpt, ci0 = (kt - tap * cpt) << 6;
+            const int tap = ikt / cpt, ci0 = (ikt - tap * cpt) << 6;
             const int ky = tap / 3, kx = tap - ky * 3;
             koff_a = (ky * g.wp + kx) * g.cin + ci0;
         } else {
-            koff_a = kt << 6;
+            koff_a = ikt << 6;
         }
         const char* abase = reinterpret_cast<const char*>(g.A + koff_a);       // wave-uniform
-        const char* wbase = reinterpret_cast<const char*>(g.W + (kt << 6));
+        const char* wbase = reinterpret_cast<const char*>(g.W + (ikt << 6));
 #pragma unroll
-        for (int s = 0; s < A_SLABS; ++s) glds_slab_off(abase, a_off[s], sa + (s * 4 + w) * 1024);
+        for (int s = 0; s < A_SPW; ++s) glds_slab_off(abase, a_off[s], sa + (s * NW + w) * 1024);
 #pragma unroll
-        for (int s = 0; s < W_SLABS; ++s) glds_slab_off(wbase, w_off[s], sw + (s * 4 + w) * 1024);
+        for (int s = 0; s < W_SPW; ++s) glds_slab_off(wbase, w_off[s], sw + (s * NW + w) * 1024);
+        istage = istage + 1 == NS ? 0 : istage + 1;
+        if (++ikt == nk) {
+            ikt = 0;
+            if (itile + wpx < tile_end) itile += wpx;
+            setup(itile);
+        }
     };
 
+    // ---- MFMA side ---------------------------------------------------------------------------------
     f32x4_t acc[NI][MI];
     // LDS fragment byte offsets of this lane (ks = 0 / 1); sub-tiles add i*2048 / j*2048
     const int frow = lane & 15;
@@ -360,60 +429,31 @@ __global__ __launch_bounds__(256, 2) void lseg_gemm_kernel(const GemmArgs g) {
         __builtin_amdgcn_sched_group_barrier(0x008, NI * MI, 0);              // MFMA (ks=1)
     };
 
-    int m0, n0;
-    setup(tile, m0, n0);
-    issue(0, 0);
-    int stage = 0;
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p) issue_next();          // prologue: NS-1 K-steps in flight
+    int cstage = 0;
     while (true) {
+        const int m0c = (tile / tiles_n) * BM, n0c = (tile - (tile / tiles_n) * tiles_n) * BN;
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < MI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < nk - 1; ++kt) {
-            __builtin_amdgcn_s_waitcnt(0);   // own direct-to-LDS loads of this K-block have landed
-            __syncthreads();                 // everyone's have; everyone is done reading the other stage
-            issue(kt + 1, stage ^ 1);
-            compute(stage);
-            stage ^= 1;
+        for (int kt = 0; kt < nk; ++kt) {
+            // (NS-1)*SPW loads are in flight; the oldest SPW (this K-step's stage) must have landed
+            wait_vmcnt<(NS - 2) * CFG::SPW>();
+            __builtin_amdgcn_s_barrier();        // everyone's have; everyone finished the stage refilled next
+            issue_next();
+            compute(cstage);
+            cstage = cstage + 1 == NS ? 0 : cstage + 1;
         }
-        // last K-block of the tile (peeled): cross-tile prefetch -- the next tile's first K-block
-        // flies during this tile's last MFMA block and its epilogue
-        const int next = tile + wpx;
-        const bool has_next = next < tile_end;
-        const int m0c = m0, n0c = n0;
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
-        if (has_next) {
-            setup(next, m0, n0);
-            issue(0, stage ^ 1);
-        }
-        compute(stage);
-        stage ^= 1;
 
         // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] ------------
+        // runtime loop over the MI output rows of this lane (one out-of-line copy of the epilogue
+        // code); the accumulator row is selected with static indices so acc[][] stays in registers
         int ncol[NI];
         ColPart cp[NI];
         float4 bias[NI];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int n = n0c + wn * WN + i * 16 + (lane >> 4) * 4;
-            ncol[i] = n;
-            cp[i] = col_part(g, n < g.N ? n : 0);
-            bias[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g.bias && n < g.N) {
-                const int bn = g.bias_mod ? (n % g.bias_mod) : n;
-                if ((g.N & 3) == 0) {
-                    bias[i] = *reinterpret_cast<const float4*>(g.bias + bn);
-                } else {
-                    bias[i].x = g.bias[bn];
-                    if (n + 1 < g.N) bias[i].y = g.bias[bn + 1];
-                    if (n + 2 < g.N) bias[i].z = g.bias[bn + 2];
-                    if (n + 3 < g.N) bias[i].w = g.bias[bn + 3];
-                }
-            }
-        }
-        // runtime loop over the MI output rows of this lane (one copy of the epilogue code); the
-        // accumulator row is selected with static indices so acc[][] stays in registers
+        epilogue_cols<NI>(g, n0c + wn * WN + (lane >> 4) * 4, ncol, cp, bias);
 #pragma unroll 1
         for (int j = 0; j < MI; ++j) {
             f32x4_t row[NI];
@@ -427,46 +467,291 @@ __global__ __launch_bounds__(256, 2) void lseg_gemm_kernel(const GemmArgs g) {
             const int m = m0c + wm * WM + j * 16 + (lane & 15);
             if (m < g.M) epilogue_row<T, NI>(g, m, ncol, cp, bias, row);
         }
-        if (!has_next) break;
-        tile = next;
+        if (NS > 2) wait_vmcnt<0>();     // see the ping-pong kernel: keeps stray vmcnt(0) out of the K-loop
+        if (tile + wpx >= tile_end) break;
+        tile += wpx;
     }
+    wait_vmcnt<0>();     // drain the never-consumed tail loads before the LDS is released
 }
 
-template <typename T, int BM, int BN, bool CONV, bool RELU_IN, int TAG>
-int launch_one(const GemmArgs& g, hipStream_t stream) {
-    const int tiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
-    const size_t lds = 2 * (size_t)(BM + BN) * 128;
-    // persistent grid: a multiple of 8 (one slice per XCD), at most `slots` resident workgroups
-    constexpr int per_cu = (BM + BN) * 256 <= 32768 ? 4 : 2;      // LDS-limited workgroups per CU
-    const int slots = 256 * per_cu;
+// ================================================================================================
+// "Ping-pong" kernel for large problems: 256x128 tile, 8 waves, 3-stage LDS ring (144 KB, one
+// workgroup per CU).  The workgroup is two 4-wave groups (G0 = waves 0-3 -> tile rows 0-127,
+// G1 = waves 4-7 -> rows 128-255; waves w and w+4 share a SIMD).  Time is cut into segments
+// separated by workgroup barriers; in every segment one group runs COMPUTE (32 MFMAs straight from
+// registers) while the other runs LOAD (its 6 direct-to-LDS loads of K-step L+2, then the 16
+// fragment reads of K-step L into registers).  The groups are one segment out of phase, so each
+// SIMD's matrix pipe always has exactly one wave feeding it while its partner does the memory work
+// -- the role split that the two-independent-workgroups kernel above only gets by accident.
+//
+//   segment 2T   : G0 COMPUTE(T)      | G1 LOAD(T)         -> every wave: vmcnt(6), barrier
+//   segment 2T+1 : G0 LOAD(T+1)       | G1 COMPUTE(T)      -> barrier
+//
+// Hazards (X = K-step, stage X%3):  RAW -- step X is issued in LOAD(X-2) segments (2X-5 by G0,
+// 2X-4 by G1) and first read in segment 2X-1; every wave waits vmcnt(6) (= all but its newest
+// share) before the barrier that closes segment 2X-2.  WAR -- stage X%3 is last read in segment 2X
+// (G1) and first refilled in segment 2X+1 (G0's LOAD(X+1) issues step X+3); the fragment reads are
+// drained (lgkmcnt(0)) before the closing barrier of their segment.
+// ================================================================================================
+template <typename T, bool CONV, bool RELU_IN, int TAG>
+__global__ __launch_bounds__(512, 2) void lseg_gemm_pp_kernel(const GemmArgs g) {
+    constexpr int BM = 256, BN = 128, NS = 3, NW = 8, WM = 64, WN = 64, MI = 4, NI = 4;
+    constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128, A_SPW = 4, W_SPW = 2, SPW = 6;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const GemmArgs& gk = *reinterpret_cast<const GemmArgs*>((const void*)__builtin_amdgcn_kernarg_segment_ptr());
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..7, wave-uniform
+    const int grp = w >> 2, wm2 = (w >> 1) & 1, wn = w & 1;
+
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int tiles_m = (g.M + BM - 1) / BM;
+    const int total = tiles_m * tiles_n;
+    const int wpx = gridDim.x >> 3;
+    int tile, tile_end;
+    {
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int q = total >> 3, r = total & 7;
+        const int xs = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        tile = xs + idx;
+        tile_end = xs + q + (xcd < r ? 1 : 0);
+    }
+    if (tile >= tile_end) return;
+
+    // ---- load side state: walks (tile, K-step) in order, two K-steps ahead of the fragment reads ----
+    uint32_t a_off[A_SPW], w_off[W_SPW];
+    const int lrow = lane >> 3;
+    auto setup = [&](int t) {
+        const int m0 = (t / tiles_n) * BM;
+        const int n0 = (t - (t / tiles_n) * tiles_n) * BN;
+#pragma unroll
+        for (int s = 0; s < A_SPW; ++s) {
+            const int r = (s * NW + w) * 8 + lrow;
+            int m = m0 + r;
+            if (m > g.M - 1) m = g.M - 1;
+            uint32_t e;
+            if (CONV) {
+                const int hw = g.ho * g.wo;
+                const int b = m / hw, p = m - b * hw;
+                const int y = p / g.wo, x = p - y * g.wo;
+                e = (uint32_t)(((b * g.hp + y * g.stride) * g.wp + x * g.stride) * g.cin);
+            } else {
+                e = (uint32_t)m * (uint32_t)g.lda;
+            }
+            a_off[s] = (e + (((lane & 7) ^ swz(r)) << 3)) * 2u;
+        }
+#pragma unroll
+        for (int s = 0; s < W_SPW; ++s) {
+            const int r = (s * NW + w) * 8 + lrow;
+            int n = n0 + r;
+            if (n > g.N - 1) n = g.N - 1;
+            w_off[s] = ((uint32_t)n * (uint32_t)g.ldw + (((lane & 7) ^ swz(r)) << 3)) * 2u;
+        }
+    };
+    const int nk = g.K >> 6;
+    const int cpt = CONV ? (g.cin >> 6) : 1;
+    int itile = tile, ikt = 0, istage = 0;
+    bool idone = false;                   // nothing left to issue (past the last tile of this workgroup)
+    setup(itile);
+    auto issue_next = [&]() {             // this wave's 6-load share of the next K-step in sequence
+        if (idone) return;
+        char* sa = smem + istage * STAGE;
+        char* sw = sa + A_BYTES;
+        int koff_a;
+        if (CONV) {
+            const int tap = ikt / cpt, ci0 = (ikt - tap * cpt) << 6;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            koff_a = (ky * g.wp + kx) * g.cin + ci0;
+        } else {
+            koff_a = ikt << 6;
+        }
+        const char* abase = reinterpret_cast<const char*>(g.A + koff_a);
+        const char* wbase = reinterpret_cast<const char*>(g.W + (ikt << 6));
+#pragma unroll
+        for (int s = 0; s < A_SPW; ++s) glds_slab_off(abase, a_off[s], sa + (s * NW + w) * 1024);
+#pragma unroll
+        for (int s = 0; s < W_SPW; ++s) glds_slab_off(wbase, w_off[s], sw + (s * NW + w) * 1024);
+        istage = istage == NS - 1 ? 0 : istage + 1;
+        if (++ikt == nk) {
+            ikt = 0;
+            if (itile + wpx < tile_end) { itile += wpx; setup(itile); }
+            else idone = true;
+        }
+    };
+
+    // ---- fragment registers + accumulators -----------------------------------------------------------
+    f32x4_t acc[NI][MI];
+    i32x4_t wf0[NI], af0[MI], wf1[NI], af1[MI];
+    const int frow = lane & 15;
+    const int foff0 = tile_off(frow, lane >> 4), foff1 = tile_off(frow, 4 + (lane >> 4));
+    const int wbase_off = A_BYTES + wn * WN * 128, abase_off = (grp * 128 + wm2 * WM) * 128;
+    int rstage = 0;                      // stage of the next K-step this wave reads fragments from
+
+    auto load_seg = [&]() {              // LOAD(L): issue step L+2, read the fragments of step L
+        issue_next();
+        const char* st = smem + rstage * STAGE;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) wf0[i] = *reinterpret_cast<const i32x4_t*>(st + wbase_off + i * 2048 + foff0);
+#pragma unroll
+        for (int j = 0; j < MI; ++j) af0[j] = *reinterpret_cast<const i32x4_t*>(st + abase_off + j * 2048 + foff0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) wf1[i] = *reinterpret_cast<const i32x4_t*>(st + wbase_off + i * 2048 + foff1);
+#pragma unroll
+        for (int j = 0; j < MI; ++j) af1[j] = *reinterpret_cast<const i32x4_t*>(st + abase_off + j * 2048 + foff1);
+        rstage = rstage == NS - 1 ? 0 : rstage + 1;
+        wait_lgkmcnt0();                 // reads drained before the stage can be refilled
+        if (RELU_IN) {
+#pragma unroll
+            for (int j = 0; j < MI; ++j) { af0[j] = relu_frag(af0[j]); af1[j] = relu_frag(af1[j]); }
+        }
+    };
+    auto compute_seg = [&]() {           // 32 MFMAs, registers only
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < MI; ++j) acc[i][j] = mfma16<T>(wf0[i], af0[j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < MI; ++j) acc[i][j] = mfma16<T>(wf1[i], af1[j], acc[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto seg_end = [&](bool vm_wait) {   // close a segment
+        __builtin_amdgcn_sched_barrier(0);
+        if (vm_wait) {
+            if (idone) wait_vmcnt<0>(); else wait_vmcnt<SPW>();
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto epilogue = [&](int t) {
+        const int m0c = (t / tiles_n) * BM, n0c = (t - (t / tiles_n) * tiles_n) * BN;
+        int ncol[NI];
+        ColPart cp[NI];
+        float4 bias[NI];
+        epilogue_cols<NI>(g, n0c + wn * WN + (lane >> 4) * 4, ncol, cp, bias);
+#pragma unroll 1
+        for (int j = 0; j < MI; ++j) {
+            f32x4_t row[NI];
+            static_for<0, MI>([&](auto jc) {
+                constexpr int js = decltype(jc)::value;
+                if (j == js) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) row[i] = acc[i][js];
+                }
+            });
+            const int m = m0c + grp * 128 + wm2 * WM + j * 16 + (lane & 15);
+            if (m < g.M) epilogue_row<T, NI>(g, m, ncol, cp, bias, row);
+        }
+    };
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < MI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    };
+
+    // ---- prologue: K-steps 0 and 1 in flight, step 0 landed ------------------------------------------
+    issue_next();
+    issue_next();
+    if (idone) wait_vmcnt<0>(); else wait_vmcnt<SPW>();
+    __builtin_amdgcn_s_barrier();
+    // Both groups run the SAME loop [LOAD ; barrier ; COMPUTE ; barrier]; G1 simply starts one
+    // barrier later (and G0 pays it back at the end), which puts the two groups one segment out of
+    // phase.  The vmcnt wait sits in front of the barrier that closes the EVEN segments: after
+    // COMPUTE for G0, after LOAD for G1.
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    int prev = -1;
+    while (true) {
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt == 0) {
+                if (prev >= 0) {
+                    epilogue(prev);                // overlaps the other group's COMPUTE segment
+                    // Explicit drain: bias/residual loads whose consumer was predicated off (tail
+                    // rows) would otherwise stay "pending" in the compiler's scoreboard, and it
+                    // protects their registers with a vmcnt(0) inside every K-step.
+                    wait_vmcnt<0>();
+                }
+                zero_acc();
+            }
+            load_seg();
+            if (grp == 1) seg_end(true); else seg_end(false);
+            compute_seg();
+            if (grp == 0) seg_end(true); else seg_end(false);
+        }
+        prev = tile;
+        if (tile + wpx >= tile_end) break;
+        tile += wpx;
+    }
+    epilogue(prev);
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    wait_vmcnt<0>();
+}
+
+template <typename T, bool CONV, bool RELU_IN, int TAG>
+int launch_pp(const GemmArgs& g, hipStream_t stream) {
+    const int tiles = ((g.M + 255) / 256) * ((g.N + 127) / 128);
+    const size_t lds = 3 * (256 + 128) * 128;
     int grid = ((tiles + 7) / 8) * 8;
-    if (grid > slots) grid = slots;
-    auto kern = lseg_gemm_kernel<T, BM, BN, CONV, RELU_IN, TAG>;
+    if (grid > 256) grid = 256;
+    auto kern = lseg_gemm_pp_kernel<T, CONV, RELU_IN, TAG>;
     static bool attr_done = false;
     if (!attr_done) {
         LSEG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, g);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, g);
     LSEG_HIP_TRY(hipGetLastError());
     return 0;
 }
 
+template <typename T, typename CFG, bool CONV, bool RELU_IN, int TAG>
+int launch_one(const GemmArgs& g, hipStream_t stream) {
+    const int tiles = ((g.M + CFG::BM - 1) / CFG::BM) * ((g.N + CFG::BN - 1) / CFG::BN);
+    const size_t lds = CFG::LDS;
+    // persistent grid: a multiple of 8 (one slice per XCD), at most `slots` resident workgroups
+    constexpr int by_lds = 163840 / CFG::LDS, by_waves = 8 / (CFG::NW / 4);
+    constexpr int per_cu = by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : by_waves;
+    const int slots = 256 * per_cu;
+    int grid = ((tiles + 7) / 8) * 8;
+    if (grid > slots) grid = slots;
+    auto kern = lseg_gemm_kernel<T, CFG, CONV, RELU_IN, TAG>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        LSEG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(CFG::THREADS), lds, stream, g);
+    LSEG_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <typename T, bool CONV, bool RELU_IN, int TAG>
+int pick_tile(const GemmArgs& g, hipStream_t stream) {
+    const long t_big = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
+    const long t_mid = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+    static const int force = getenv("LSEG_GEMM_TILE") ? atoi(getenv("LSEG_GEMM_TILE")) : 0;   // 1 small 2 mid 3 big
+    int pick = t_mid >= 192 ? 2 : 1;       // 3 = 256x128/8 waves/3 stages (lock-step), 4 = ping-pong
+    (void)t_big;
+    if (force) pick = force;
+    if (pick == 4) return launch_pp<T, CONV, RELU_IN, TAG>(g, stream);
+    if (pick == 3) return launch_one<T, CfgBig, CONV, RELU_IN, TAG>(g, stream);
+    if (pick == 2) return launch_one<T, CfgMid, CONV, RELU_IN, TAG>(g, stream);
+    return launch_one<T, CfgSmall, CONV, RELU_IN, TAG>(g, stream);
+}
+
 template <typename T>
 int dispatch(const GemmArgs& g, hipStream_t stream) {
-    const long tiles128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    const bool big = tiles128 >= 192;       // fills the 256 CUs reasonably with 128x128 tiles
     if (g.conv) {
-        if (g.relu_in)
-            return big ? launch_one<T, 128, 128, true, true, 0>(g, stream) : launch_one<T, 64, 64, true, true, 0>(g, stream);
-        return big ? launch_one<T, 128, 128, true, false, 0>(g, stream) : launch_one<T, 64, 64, true, false, 0>(g, stream);
+        if (g.relu_in) return pick_tile<T, true, true, 0>(g, stream);
+        return pick_tile<T, true, false, 0>(g, stream);
     }
     if (g.relu_in) return set_error(LSEG_ERR_UNSUPPORTED, "gemm: relu_in is only implemented for the conv path");
-    if (g.tag == 1) {
-        return big ? launch_one<T, 128, 128, false, false, 1>(g, stream) : launch_one<T, 64, 64, false, false, 1>(g, stream);
-    }
-    return big ? launch_one<T, 128, 128, false, false, 0>(g, stream) : launch_one<T, 64, 64, false, false, 0>(g, stream);
+    if (g.tag == 1) return pick_tile<T, false, false, 1>(g, stream);
+    return pick_tile<T, false, false, 0>(g, stream);
 }
 
 }  // namespace

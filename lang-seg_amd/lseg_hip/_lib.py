@@ -9,7 +9,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblseg_hip.so")
+LIB_PATH = os.environ.get("LSEG_HIP_LIB", os.path.join(_HERE, "liblseg_hip.so"))   # override: A/B-testing builds
 
 LSEG_F32, LSEG_F16, LSEG_BF16, LSEG_I64 = 0, 1, 2, 3
 RS_IDENTITY, RS_CONVT, RS_CONV_S2 = 0, 1, 2
