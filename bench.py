@@ -127,12 +127,20 @@ def main():
         fc1 = eng.profile("mlp_fc1")
         fwd = eng.profile("forward")
         roof = None
+        traffic = None      # HBM-side bytes per launch from the PMC passes (tools/collect_profiles.sh), if recorded
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):
+            t = json.load(open(tpath)).get("mlp_fc1_gemm", {})
+            if t.get("batch") == B and args.backbone == "clip_vitl16_384":
+                traffic = {"bytes_per_launch": round(t["traffic_bytes_per_launch"]), "algorithmic_bytes": t["algorithmic_bytes_per_launch"],
+                           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 gfx950 correction; "
+                                     "L2->fabric incl. Infinity-Cache hits"}
         if fc1["launches"]:
             avg_ms = fc1["total_ms"] / fc1["launches"]
             ach = fc1["flops_per_launch"] / (avg_ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": "lseg_gemm_kernel<bf16,128,128,tag=1> (ViT MLP fc1 + bias + GELU)",
                     "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "avg_launch_ms": round(avg_ms, 5), "launches": fc1["launches"],
                     "flops_per_launch": fc1["flops_per_launch"]}
         # whole-path figures (reference-algorithm FLOP convention)
