@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--labels", type=int, default=150)
     ap.add_argument("--backbone", default="clip_vitl16_384")
     ap.add_argument("--size", type=int, default=480)

@@ -196,31 +196,44 @@ __global__ void upsample2x_nhwc_kernel(const uint16_t* in, uint16_t* out, int B,
 // ---- bilinear x2, align_corners=True, fp32 planes [P,H,W] -> [P,2H,2W] (lseg_net.py:203) -----------
 // optional per-plane post-op none.  Each thread writes 4 consecutive outputs (16 B).
 __global__ __launch_bounds__(256) void upsample2x_planes_kernel(const float* in, float* out, int P, int H, int W) {
-    // block = 2 output rows x 128 lanes; lane x4 writes outputs 4*x4 .. 4*x4+3 of its row
+    // One block = one input-row pair -> the (up to 3) output rows whose source row y0 is this one.
+    // The two input rows are staged in LDS (coalesced float4 loads); every thread then produces 4
+    // consecutive outputs per output row from LDS and writes them with one 16-byte non-temporal
+    // store.  Output row yo belongs to the block with y0 = floor(yo*(H-1)/(2H-1)).
+    extern __shared__ float rows[];           // [2][W]
     const int Ho = 2 * H, Wo = 2 * W, w4 = Wo / 4;
-    const unsigned rowid = blockIdx.x * 2 + (threadIdx.x >> 7);
-    if (rowid >= (unsigned)P * Ho) return;
-    const unsigned pl = rowid / (unsigned)Ho;
-    const int yo = (int)(rowid - pl * Ho);
-    const float ry = (float)(H - 1) / (float)(Ho - 1), rx = (float)(W - 1) / (float)(Wo - 1);
-    const float sy = ry * (float)yo;
-    const int y0 = (int)sy, y1 = y0 + (y0 < H - 1);
-    const float ly = sy - (float)y0;
+    const unsigned pl = blockIdx.x / (unsigned)H;
+    const int y0 = (int)(blockIdx.x - pl * H);
+    const int y1 = y0 + (y0 < H - 1);
     const float* r0 = in + ((size_t)pl * H + y0) * W;
     const float* r1 = in + ((size_t)pl * H + y1) * W;
-    float* orow = out + (size_t)rowid * Wo;
-    for (int x4 = threadIdx.x & 127; x4 < w4; x4 += 128) {
-        float o[4];
+    for (int i = threadIdx.x; i < W / 4; i += 256) {
+        reinterpret_cast<float4*>(rows)[i] = reinterpret_cast<const float4*>(r0)[i];
+        reinterpret_cast<float4*>(rows + W)[i] = reinterpret_cast<const float4*>(r1)[i];
+    }
+    __syncthreads();
+    const float ry = (float)(H - 1) / (float)(Ho - 1), rx = (float)(W - 1) / (float)(Wo - 1);
+    // first output row mapped to y0: smallest yo with floor(ry*yo) == y0
+    int yo = (int)ceilf((float)y0 / ry);
+    while (yo > 0 && (int)(ry * (float)(yo - 1)) >= y0) --yo;
+    while ((int)(ry * (float)yo) < y0) ++yo;
+    for (; yo < Ho && (int)(ry * (float)yo) == y0; ++yo) {
+        const float sy = ry * (float)yo;
+        const float ly = sy - (float)y0;
+        float* orow = out + ((size_t)pl * Ho + yo) * Wo;
+        for (int x4 = threadIdx.x; x4 < w4; x4 += 256) {
+            float o[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int xo = x4 * 4 + e;
-            const float sx = rx * (float)xo;
-            const int x0 = (int)sx, x1 = x0 + (x0 < W - 1);
-            const float lx = sx - (float)x0;
-            o[e] = (1.f - ly) * ((1.f - lx) * r0[x0] + lx * r0[x1]) + ly * ((1.f - lx) * r1[x0] + lx * r1[x1]);
+            for (int e = 0; e < 4; ++e) {
+                const int xo = x4 * 4 + e;
+                const float sx = rx * (float)xo;
+                const int x0 = (int)sx, x1 = x0 + (x0 < W - 1);
+                const float lx = sx - (float)x0;
+                o[e] = (1.f - ly) * ((1.f - lx) * rows[x0] + lx * rows[x1]) + ly * ((1.f - lx) * rows[W + x0] + lx * rows[W + x1]);
+            }
+            const f32x4_t ov = {o[0], o[1], o[2], o[3]};     // written once, never re-read by the engine
+            __builtin_nontemporal_store(ov, reinterpret_cast<f32x4_t*>(orow) + x4);
         }
-        const f32x4_t ov = {o[0], o[1], o[2], o[3]};     // written once, never re-read by the engine
-        __builtin_nontemporal_store(ov, reinterpret_cast<f32x4_t*>(orow) + x4);
     }
 }
 
@@ -463,10 +476,10 @@ int launch_upsample2x_nhwc(const void* in, void* out, int B, int H, int W, int C
     return 0;
 }
 int launch_upsample2x_planes(const float* in, float* out, int P, int H, int W, hipStream_t st) {
-    if ((2 * W) % 4) return set_error(LSEG_ERR_UNSUPPORTED, "upsample2x_planes: W=%d", W);
-    const size_t rows = (size_t)P * 2 * H;
-    if (rows > 0x7fffffffu) return set_error(LSEG_ERR_UNSUPPORTED, "upsample2x_planes: too many rows");
-    hipLaunchKernelGGL(upsample2x_planes_kernel, dim3((unsigned)((rows + 1) / 2)), dim3(256), 0, st, in, out, P, H, W);
+    if (W % 4) return set_error(LSEG_ERR_UNSUPPORTED, "upsample2x_planes: W=%d must be a multiple of 4", W);
+    const size_t blocks = (size_t)P * H;
+    if (blocks > 0x7fffffffu) return set_error(LSEG_ERR_UNSUPPORTED, "upsample2x_planes: too many rows");
+    hipLaunchKernelGGL(upsample2x_planes_kernel, dim3((unsigned)blocks), dim3(256), 2 * W * sizeof(float), st, in, out, P, H, W);
     CHECK_LAUNCH();
     return 0;
 }

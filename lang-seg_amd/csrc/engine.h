@@ -99,6 +99,10 @@ private:
     uint16_t *tx_ = nullptr, *tln_ = nullptr, *tq_ = nullptr, *tk_ = nullptr, *tvt_ = nullptr, *tatt_ = nullptr,
              *tmlp_ = nullptr, *tpool_ = nullptr, *tfeat_ = nullptr, *tnorm_ = nullptr;
 
+    // ---- side stream: the (small, latency-bound) text tower overlaps the image tower ----------------
+    hipStream_t text_stream_ = nullptr;
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+
     // ---- profiling ---------------------------------------------------------------------------------
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_fc1_, ev_fwd_;
     std::vector<hipEvent_t> ev_pool_;

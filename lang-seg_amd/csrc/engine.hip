@@ -42,6 +42,9 @@ Engine::Engine(const lseg_config& c, int dev) : cfg(c), device(dev) {}
 
 Engine::~Engine() {
     (void)hipSetDevice(device);
+    if (text_stream_) (void)hipStreamDestroy(text_stream_);
+    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+    if (ev_join_) (void)hipEventDestroy(ev_join_);
     for (void* p : allocs_) (void)hipFree(p);
     for (auto e : ev_pool_) (void)hipEventDestroy(e);
 }
@@ -140,6 +143,9 @@ int Engine::init() {
     ALLOC(tpool_, uint16_t, Kl * W);
     ALLOC(tfeat_, uint16_t, Kl * c.out_c);
     ALLOC(tnorm_, uint16_t, Kl * c.out_c);
+    LSEG_HIP_TRY(hipStreamCreateWithFlags(&text_stream_, hipStreamNonBlocking));
+    LSEG_HIP_TRY(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+    LSEG_HIP_TRY(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
     LSEG_HIP_TRY(hipDeviceSynchronize());
     inited_ = true;
     return 0;
@@ -473,6 +479,17 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
     hipEvent_t fwd0 = nullptr, fwd1 = nullptr;
     if (profiling) { fwd0 = get_event(); fwd1 = get_event(); if (fwd0) (void)hipEventRecord(fwd0, st); }
 
+    // ---- text tower (lseg_net.py:181-183): re-run every call unless caching is on.  Its ~90 small
+    // kernels are latency-bound, so they run on a side stream next to the image tower; fork/join
+    // events keep everything ordered with respect to the caller's stream.
+    const bool run_text = !text_cache || !text_valid;
+    if (run_text) {
+        LSEG_HIP_TRY(hipEventRecord(ev_fork_, st));
+        LSEG_HIP_TRY(hipStreamWaitEvent(text_stream_, ev_fork_, 0));
+        TRY(encode_text(text_stream_));
+        LSEG_HIP_TRY(hipEventRecord(ev_join_, text_stream_));
+    }
+
     // ---- forward_flex (lseg_vit.py:166-201): patch embed + cls + pos -------------------------------------
     TRY(launch_im2col_patch(x_in, patchA_, B, c.img_h, c.img_w, c.patch, img_dt_, st));
     GemmArgs g;
@@ -553,8 +570,7 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
     // ---- refinenet4..1 (lseg_net.py:176-179) ---------------------------------------------------------------
     for (int r = 4; r >= 1; --r) TRY(refine(r, B, st));
 
-    // ---- text tower (lseg_net.py:181-183): re-run every call unless caching is on --------------------------
-    if (!text_cache || !text_valid) TRY(encode_text(st));
+    if (run_text) LSEG_HIP_TRY(hipStreamWaitEvent(st, ev_join_, 0));     // join before the correlation
 
     // ---- head1 + normalise + correlation (lseg_net.py:185-196) ------------------------------------------------
     const int h1 = 2 * lh_[0], w1 = 2 * lw_[0], hw1 = h1 * w1, Mp = B * hw1;

@@ -46,6 +46,7 @@ struct GemmArgs {
     // MAP_QKV
     void* Ck; void* Cv; int qkv_dim, qkv_ntok, qkv_npad, qkv_heads;
     int tag;                    // 0 generic, 1 = the profiled dominant instance (distinct symbol)
+    int dbg;                    // ablation knob (tools only): 1 = skip epilogue stores, 2 = skip the epilogue
 };
 
 void gemm_args_init(GemmArgs& g);

@@ -173,9 +173,22 @@ __device__ __forceinline__ void store4(void* dst, size_t off, int dtype, const f
 }
 
 // Per-tile column info of this lane: first column of each 4-wide group, its address part, its bias.
+// `wide` = the permlane-widened 16-byte store path applies to this launch (16-bit output, unit-stride
+// map, every 32-column pair fully in range); cpw[] = address part of the 8 columns a lane owns then.
 template <int NI>
-__device__ __forceinline__ void epilogue_cols(const GemmArgs& g, int n_first, int (&ncol)[NI], ColPart (&cp)[NI],
-                                              float4 (&bias)[NI]) {
+__device__ __forceinline__ bool epilogue_cols(const GemmArgs& g, int n_first, int lane, int (&ncol)[NI], ColPart (&cp)[NI],
+                                              ColPart (&cpw)[NI / 2], float4 (&bias)[NI]) {
+    const bool wide = g.out_dtype != DT_F32 && (g.N & 31) == 0 && g.map_mode != MAP_NCHW && g.dbg == 0 &&
+                      (g.map_mode != MAP_PIXSHUF || (g.ps_C & 31) == 0);
+    {
+        const int r16 = lane >> 4;
+        const int pair0 = n_first - r16 * 4;                  // first column of this lane's first sub-tile pair
+#pragma unroll
+        for (int p = 0; p < NI / 2; ++p) {
+            const int c = pair0 + p * 32 + (r16 & 1) * 16 + (r16 >> 1) * 8;
+            cpw[p] = col_part(g, c < g.N ? c : 0);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int n = n_first + i * 16;
@@ -194,13 +207,15 @@ __device__ __forceinline__ void epilogue_cols(const GemmArgs& g, int n_first, in
             }
         }
     }
+    return wide;
 }
 
 // One output row m of this lane: NI groups of 4 consecutive columns.  All residual loads of the
 // row are issued before the first store (the residual may alias C: x += f(x) in place).
 template <typename T, int NI>
 __device__ __forceinline__ void epilogue_row(const GemmArgs& g, int m, const int (&ncol)[NI], const ColPart (&cp)[NI],
-                                             const float4 (&bias)[NI], f32x4_t (&acc)[NI]) {
+                                             const ColPart (&cpw)[NI / 2], bool wide, const float4 (&bias)[NI],
+                                             f32x4_t (&acc)[NI]) {
     size_t r0, r1;
     row_part(g, m, r0, r1);
     size_t rres = 0;
@@ -239,6 +254,35 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& g, int m, const int
             v[i][0] += rv[i].x + rv2[i].x; v[i][1] += rv[i].y + rv2[i].y;
             v[i][2] += rv[i].z + rv2[i].z; v[i][3] += rv[i].w + rv2[i].w;
         }
+    }
+    if (g.dbg == 1) {   // ablation: keep the values live, skip the stores
+#pragma unroll
+        for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(v[i][0]), "v"(v[i][1]), "v"(v[i][2]), "v"(v[i][3]));
+        return;
+    }
+    // 16-bit outputs: a lane holds 8 bytes (4 columns) per 16-column sub-tile.  v_permlane16_swap on
+    // a pair of sub-tiles regroups them so every lane owns 16 contiguous bytes and one store
+    // instruction writes 16 rows x 64 contiguous bytes (half the store instructions; T21-style):
+    //   lane row r16 = lane>>4 ends up with columns  pair_base + (r16&1)*16 + (r16>>1)*8 .. +7
+    if (wide) {
+#pragma unroll
+        for (int i = 0; i < NI; i += 2) {
+            if (cpw[i / 2].which == 2) {       // V^T of MAP_QKV: strided, scalar stores
+#pragma unroll
+                for (int q = i; q < i + 2; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        store_from_f32(g.Cv, r1 + cp[q].off + (size_t)r * g.qkv_npad, g.out_dtype, v[q][r]);
+                continue;
+            }
+            const uint32_t a0 = pack2_dt(v[i][0], v[i][1], g.out_dtype), a1 = pack2_dt(v[i][2], v[i][3], g.out_dtype);
+            const uint32_t b0 = pack2_dt(v[i + 1][0], v[i + 1][1], g.out_dtype), b1 = pack2_dt(v[i + 1][2], v[i + 1][3], g.out_dtype);
+            const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+            void* dst = cpw[i / 2].which == 1 ? g.Ck : g.C;
+            *reinterpret_cast<uint4*>((uint16_t*)dst + r0 + cpw[i / 2].off) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        }
+        return;
     }
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -469,9 +513,9 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void lseg_gemm_kernel(const GemmAr
         // runtime loop over the MI output rows of this lane (one out-of-line copy of the epilogue
         // code); the accumulator row is selected with static indices so acc[][] stays in registers
         int ncol[NI];
-        ColPart cp[NI];
+        ColPart cp[NI], cpw[NI / 2];
         float4 bias[NI];
-        epilogue_cols<NI>(g, n0c + wn * WN + (lane >> 4) * 4, ncol, cp, bias);
+        const bool wide = epilogue_cols<NI>(g, n0c + wn * WN + (lane >> 4) * 4, lane, ncol, cp, cpw, bias);
 #pragma unroll 1
         for (int j = 0; j < MI; ++j) {
             f32x4_t row[NI];
@@ -483,7 +527,8 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void lseg_gemm_kernel(const GemmAr
                 }
             });
             const int m = m0c + wm * WM + j * 16 + (lane & 15);
-            if (m < g.M) epilogue_row<T, NI>(g, m, ncol, cp, bias, row);
+            if (g.dbg == 2) { asm volatile("" ::"v"(row[0][0]), "v"(row[NI - 1][3])); continue; }
+            if (m < g.M) epilogue_row<T, NI>(g, m, ncol, cp, cpw, wide, bias, row);
         }
         if (NS > 2) wait_vmcnt<0>();     // see the ping-pong kernel: keeps stray vmcnt(0) out of the K-loop
         if (tile + wpx >= tile_end) break;
@@ -649,9 +694,9 @@ __global__ __launch_bounds__(512, 2) void lseg_gemm_pp_kernel(const GemmArgs g) 
         tile_coords(t, tiles_m, tiles_n, mbc, nbc);
         const int m0c = mbc * BM, n0c = nbc * BN;
         int ncol[NI];
-        ColPart cp[NI];
+        ColPart cp[NI], cpw[NI / 2];
         float4 bias[NI];
-        epilogue_cols<NI>(g, n0c + wn * WN + (lane >> 4) * 4, ncol, cp, bias);
+        const bool wide = epilogue_cols<NI>(g, n0c + wn * WN + (lane >> 4) * 4, lane, ncol, cp, cpw, bias);
 #pragma unroll 1
         for (int j = 0; j < MI; ++j) {
             f32x4_t row[NI];
@@ -663,7 +708,7 @@ __global__ __launch_bounds__(512, 2) void lseg_gemm_pp_kernel(const GemmArgs g) 
                 }
             });
             const int m = m0c + grp * 128 + wm2 * WM + j * 16 + (lane & 15);
-            if (m < g.M) epilogue_row<T, NI>(g, m, ncol, cp, bias, row);
+            if (m < g.M) epilogue_row<T, NI>(g, m, ncol, cp, cpw, wide, bias, row);
         }
     };
     auto zero_acc = [&]() {
@@ -777,7 +822,10 @@ int dispatch(const GemmArgs& g, hipStream_t stream) {
 
 }  // namespace
 
-int launch_gemm(const GemmArgs& g, int ab_dtype, hipStream_t stream) {
+int launch_gemm(const GemmArgs& g_in, int ab_dtype, hipStream_t stream) {
+    GemmArgs g = g_in;
+    static const int dbg = getenv("LSEG_GEMM_DBG") ? atoi(getenv("LSEG_GEMM_DBG")) : 0;
+    g.dbg = dbg;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return set_error(LSEG_ERR_INVALID, "gemm: empty problem %dx%dx%d", g.M, g.N, g.K);
     if (g.K % 64 != 0) return set_error(LSEG_ERR_UNSUPPORTED, "gemm: K=%d must be a multiple of 64", g.K);
     if (g.conv && (g.cin % 64 != 0)) return set_error(LSEG_ERR_UNSUPPORTED, "conv: Cin=%d must be a multiple of 64", g.cin);
