@@ -49,6 +49,25 @@ __device__ __forceinline__ float erf_as(float x) {
     return x < 0.f ? -e : e;
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
+// The same GELU on two values at once: the polynomial runs on v_pk_fma_f32 / v_pk_mul_f32 (packed
+// fp32), only rcp and exp2 stay per-element: 21 VALU per pair instead of ~40.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
+    const f32x2_t z = x * 0.70710678118654752f;
+    f32x2_t az; az[0] = fabsf(z[0]); az[1] = fabsf(z[1]);
+    const f32x2_t d = az * 0.3275911f + 1.0f;
+    f32x2_t t; t[0] = __builtin_amdgcn_rcpf(d[0]); t[1] = __builtin_amdgcn_rcpf(d[1]);
+    f32x2_t p = t * 1.061405429f + (-1.453152027f);
+    p = p * t + 1.421413741f;
+    p = p * t + (-0.284496736f);
+    p = p * t + 0.254829592f;
+    p = p * t;
+    const f32x2_t nz2 = -(az * az) * 1.4426950408889634f;
+    f32x2_t e; e[0] = __builtin_amdgcn_exp2f(nz2[0]); e[1] = __builtin_amdgcn_exp2f(nz2[1]);
+    const f32x2_t erfabs = 1.0f - p * e;                       // erf(|z|)
+    f32x2_t axh; axh[0] = 0.5f * fabsf(x[0]); axh[1] = 0.5f * fabsf(x[1]);
+    return x * 0.5f + axh * erfabs;                            // 0.5x(1+erf z), erf odd
+}
 
 // ReLU on 8 packed 16-bit floats (bf16 or fp16): negative <=> sign bit <=> negative int16.
 __device__ __forceinline__ i32x4_t relu_frag(i32x4_t v) {
@@ -142,8 +161,8 @@ __device__ __forceinline__ void apply_act(const GemmArgs& g, float (&v)[4]) {
         for (int r = 0; r < 4; ++r) v[r] = to_f32<T>(from_f32<T>(v[r]));
     }
     if (g.act == ACT_GELU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        const f32x2_t lo = gelu_erf2(f32x2_t{v[0], v[1]}), hi = gelu_erf2(f32x2_t{v[2], v[3]});
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
     } else if (g.act == ACT_QUICKGELU) {
         // x * sigmoid(1.702 x); with round_mid every step is rounded like the fp16 eager ops
 #pragma unroll
@@ -492,46 +511,58 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void lseg_gemm_kernel(const GemmAr
 #pragma unroll
     for (int p = 0; p < NS - 1; ++p) issue_next();          // prologue: NS-1 K-steps in flight
     int cstage = 0;
+    int prev = -1;                                           // tile whose results still sit in acc[][]
+    auto k_step = [&]() {
+        // (NS-1)*SPW loads are in flight; the oldest SPW (this K-step's stage) must have landed
+        wait_vmcnt<(NS - 2) * CFG::SPW>();
+        __builtin_amdgcn_s_barrier();        // everyone's have; everyone finished the stage refilled next
+        issue_next();
+    };
     while (true) {
-        int mbc, nbc;
-        tile_coords(tile, tiles_m, tiles_n, mbc, nbc);
-        const int m0c = mbc * BM, n0c = nbc * BN;
+        // The epilogue of tile t runs INSIDE tile t+1's first K-step, after that step's wait/barrier
+        // and after the following K-step's loads have been issued: its stores are then acknowledged
+        // under the first MFMA block instead of being waited for (vmcnt counts stores) before it.
+        const bool have = tile < tile_end;
+        if (have) k_step();
+        if (prev >= 0) {
+            int mbc, nbc;
+            tile_coords(prev, tiles_m, tiles_n, mbc, nbc);
+            const int m0c = mbc * BM, n0c = nbc * BN;
+            int ncol[NI];
+            ColPart cp[NI], cpw[NI / 2];
+            float4 bias[NI];
+            const bool wide = epilogue_cols<NI>(g, n0c + wn * WN + (lane >> 4) * 4, lane, ncol, cp, cpw, bias);
+            // runtime loop over the MI output rows of this lane (one copy of the epilogue code); the
+            // accumulator row is selected with static indices so acc[][] stays in registers
+#pragma unroll 1
+            for (int j = 0; j < MI; ++j) {
+                f32x4_t row[NI];
+                static_for<0, MI>([&](auto jc) {
+                    constexpr int js = decltype(jc)::value;
+                    if (j == js) {
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) row[i] = acc[i][js];
+                    }
+                });
+                const int m = m0c + wm * WM + j * 16 + (lane & 15);
+                if (g.dbg == 2) { asm volatile("" ::"v"(row[0][0]), "v"(row[NI - 1][3])); continue; }
+                if (m < g.M) epilogue_row<T, NI>(g, m, ncol, cp, cpw, wide, bias, row);
+            }
+            if (NS > 2) wait_vmcnt<0>();     // see the ping-pong kernel: keeps stray vmcnt(0) out of the K-loop
+        }
+        if (!have) break;
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < MI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < nk; ++kt) {
-            // (NS-1)*SPW loads are in flight; the oldest SPW (this K-step's stage) must have landed
-            wait_vmcnt<(NS - 2) * CFG::SPW>();
-            __builtin_amdgcn_s_barrier();        // everyone's have; everyone finished the stage refilled next
-            issue_next();
+        compute(cstage);
+        cstage = cstage + 1 == NS ? 0 : cstage + 1;
+        for (int kt = 1; kt < nk; ++kt) {
+            k_step();
             compute(cstage);
             cstage = cstage + 1 == NS ? 0 : cstage + 1;
         }
-
-        // ---- epilogue: lane holds C[m = .. + (lane&15)][n = .. + (lane>>4)*4 + 0..3] ------------
-        // runtime loop over the MI output rows of this lane (one out-of-line copy of the epilogue
-        // code); the accumulator row is selected with static indices so acc[][] stays in registers
-        int ncol[NI];
-        ColPart cp[NI], cpw[NI / 2];
-        float4 bias[NI];
-        const bool wide = epilogue_cols<NI>(g, n0c + wn * WN + (lane >> 4) * 4, lane, ncol, cp, cpw, bias);
-#pragma unroll 1
-        for (int j = 0; j < MI; ++j) {
-            f32x4_t row[NI];
-            static_for<0, MI>([&](auto jc) {
-                constexpr int js = decltype(jc)::value;
-                if (j == js) {
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) row[i] = acc[i][js];
-                }
-            });
-            const int m = m0c + wm * WM + j * 16 + (lane & 15);
-            if (g.dbg == 2) { asm volatile("" ::"v"(row[0][0]), "v"(row[NI - 1][3])); continue; }
-            if (m < g.M) epilogue_row<T, NI>(g, m, ncol, cp, cpw, wide, bias, row);
-        }
-        if (NS > 2) wait_vmcnt<0>();     // see the ping-pong kernel: keeps stray vmcnt(0) out of the K-loop
-        if (tile + wpx >= tile_end) break;
+        prev = tile;
         tile += wpx;
     }
     wait_vmcnt<0>();     // drain the never-consumed tail loads before the LDS is released
