@@ -50,7 +50,7 @@ private:
     int pack_linear(const std::string& wkey, const std::string& bkey, int n, int k, int dt, Lin& out, hipStream_t st);
     int pack_f32(const std::string& key, size_t n, float*& out, hipStream_t st);
     int pack_conv3(const std::string& wkey, const std::string& bn_prefix, const std::string& bias_key, int co, int ci,
-                   Lin& out, hipStream_t st);
+                   int cop, int cip, Lin& out, hipStream_t st);
     int conv3x3(const void* in, const Lin& w, const void* res, const void* res2, void* out, int B, int H, int W,
                 int stride, int relu_in, int relu_out, hipStream_t st);
     int refine(int r, int B, hipStream_t st);
@@ -64,6 +64,7 @@ private:
     // derived geometry
     int gh_, gw_, np_, ntok_, npad_, img_dt_;
     int lh_[4], lw_[4];          // spatial size of reassembled level l (0..3)
+    int cp_[4];                  // reassemble channels rounded up to 64 (ViT-B/32: 96 -> 128), extra channels are 0
     int tnpad_;
 
     // ---- packed parameters -------------------------------------------------------------------

@@ -73,8 +73,10 @@ int Engine::init() {
     if (c.img_h % c.patch || c.img_w % c.patch) return set_error(LSEG_ERR_INVALID, "image size %dx%d must be a multiple of the patch size %d", c.img_h, c.img_w, c.patch);
     if (c.dim % 64 || c.features % 64 || c.out_c % 64 || c.text_width % 64 || (3 * c.patch * c.patch) % 64)
         return set_error(LSEG_ERR_UNSUPPORTED, "dim/features/out_c/text_width must be multiples of 64");
-    for (int l = 0; l < 4; ++l)
-        if (c.reassemble_ch[l] % 64) return set_error(LSEG_ERR_UNSUPPORTED, "reassemble channels %d (level %d) must be a multiple of 64 in this build", c.reassemble_ch[l], l + 1);
+    for (int l = 0; l < 4; ++l) {
+        if (c.reassemble_ch[l] % 8) return set_error(LSEG_ERR_UNSUPPORTED, "reassemble channels %d (level %d) must be a multiple of 8", c.reassemble_ch[l], l + 1);
+        cp_[l] = ((c.reassemble_ch[l] + 63) / 64) * 64;      // K of the MFMA GEMMs must be a multiple of 64
+    }
     if (c.max_batch < 1 || c.max_labels < 1) return set_error(LSEG_ERR_INVALID, "max_batch/max_labels");
     LSEG_HIP_TRY(hipSetDevice(device));
 
@@ -107,12 +109,12 @@ int Engine::init() {
     ALLOC(catA_, uint16_t, B * np_ * 2 * D);
     ALLOC(ro_, uint16_t, B * np_ * D);
     size_t r1max = 0;
-    for (int l = 0; l < 4; ++l) r1max = std::max(r1max, (size_t)c.reassemble_ch[l]);
+    for (int l = 0; l < 4; ++l) r1max = std::max(r1max, (size_t)cp_[l]);
     ALLOC(r1_, uint16_t, B * np_ * r1max);
     ALLOC(tmp_pad_, uint16_t, B * (gh_ + 2) * (gw_ + 2) * r1max);
     for (int l = 0; l < 4; ++l) {
         const size_t pp = B * (lh_[l] + 2) * (lw_[l] + 2);
-        ALLOC(L_[l], uint16_t, pp * c.reassemble_ch[l]);
+        ALLOC(L_[l], uint16_t, pp * cp_[l]);
         ALLOC(rn_[l], uint16_t, pp * F);
         ALLOC(t1_[l], uint16_t, pp * F);
         ALLOC(sum_[l], uint16_t, pp * F);
@@ -191,7 +193,7 @@ int Engine::pack_linear(const std::string& wkey, const std::string& bkey, int n,
 }
 
 int Engine::pack_conv3(const std::string& wkey, const std::string& bnp, const std::string& bias_key, int co, int ci,
-                       Lin& out, hipStream_t st) {
+                       int cop, int cip, Lin& out, hipStream_t st) {
     BoundParam w;
     TRY(need(wkey, w, {co, ci, 3, 3}));
     if (w.dtype != LSEG_F32) return set_error(LSEG_ERR_UNSUPPORTED, "'%s' must be fp32", wkey.c_str());
@@ -210,11 +212,11 @@ int Engine::pack_conv3(const std::string& wkey, const std::string& bnp, const st
         if (b.dtype != LSEG_F32) return set_error(LSEG_ERR_UNSUPPORTED, "'%s' must be fp32", bias_key.c_str());
         cb = (const float*)b.ptr;
     }
-    if (!out.w) ALLOC(out.w, uint16_t, (size_t)co * 9 * ci);
+    if (!out.w) ALLOC(out.w, uint16_t, (size_t)cop * 9 * cip);          // zero-initialised: padding stays 0
     const bool has_bias = bw || cb;
-    if (has_bias && !out.b) ALLOC(out.b, float, co);
-    out.n = co; out.k = 9 * ci;
-    return launch_pack_conv3x3((const float*)w.ptr, bw, bb, bm, bv, 1e-5f, cb, out.w, has_bias ? out.b : nullptr, co, ci, img_dt_, st);
+    if (has_bias && !out.b) ALLOC(out.b, float, cop);
+    out.n = cop; out.k = 9 * cip;
+    return launch_pack_conv3x3((const float*)w.ptr, bw, bb, bm, bv, 1e-5f, cb, out.w, has_bias ? out.b : nullptr, co, ci, cip, img_dt_, st);
 }
 
 int Engine::finalize(hipStream_t st) {
@@ -246,23 +248,34 @@ int Engine::finalize(hipStream_t st) {
     for (int l = 0; l < 4; ++l) {
         snprintf(buf, sizeof(buf), "pretrained.act_postprocess%d.", l + 1);
         const std::string a = buf;
-        const int C = c.reassemble_ch[l];
+        const int C = c.reassemble_ch[l], Cp = cp_[l];
         TRY(pack_linear(a + "0.project.0.weight", a + "0.project.0.bias", D, 2 * D, img_dt_, readout_[l], st));
-        TRY(pack_linear(a + "3.weight", a + "3.bias", C, D, img_dt_, r1x1_[l], st));
+        {   // 1x1 conv [C, D] -> [Cp, D] (rows >= C are zero: the padded channels stay exactly 0)
+            BoundParam w, b;
+            TRY(need(a + "3.weight", w, {C, D}));
+            TRY(need(a + "3.bias", b, {C}));
+            if (!r1x1_[l].w) ALLOC(r1x1_[l].w, uint16_t, (size_t)Cp * D);
+            if (!r1x1_[l].b) ALLOC(r1x1_[l].b, float, Cp);
+            r1x1_[l].n = Cp; r1x1_[l].k = D;
+            TRY(launch_convert(w.ptr, w.dtype, r1x1_[l].w, img_dt_, (size_t)C * D, st));
+            TRY(launch_convert(b.ptr, b.dtype, r1x1_[l].b, DT_F32, C, st));
+        }
         if (c.resample_kind[l] == LSEG_RS_CONVT) {
             const int s = c.resample_k[l];
-            BoundParam w;
+            BoundParam w, b;
             TRY(need(a + "4.weight", w, {C, C, s, s}));
+            TRY(need(a + "4.bias", b, {C}));
             if (w.dtype != LSEG_F32) return set_error(LSEG_ERR_UNSUPPORTED, "'%s4.weight' must be fp32", a.c_str());
-            if (!rsmp_[l].w) ALLOC(rsmp_[l].w, uint16_t, (size_t)s * s * C * C);
-            rsmp_[l].n = s * s * C; rsmp_[l].k = C;
-            TRY(launch_pack_convT((const float*)w.ptr, rsmp_[l].w, C, C, s, img_dt_, st));
-            TRY(pack_f32(a + "4.bias", C, rsmp_[l].b, st));
+            if (!rsmp_[l].w) ALLOC(rsmp_[l].w, uint16_t, (size_t)s * s * Cp * Cp);
+            if (!rsmp_[l].b) ALLOC(rsmp_[l].b, float, Cp);
+            rsmp_[l].n = s * s * Cp; rsmp_[l].k = Cp;
+            TRY(launch_pack_convT((const float*)w.ptr, rsmp_[l].w, C, C, Cp, s, img_dt_, st));
+            TRY(launch_convert(b.ptr, b.dtype, rsmp_[l].b, DT_F32, C, st));
         } else if (c.resample_kind[l] == LSEG_RS_CONV_S2) {
-            TRY(pack_conv3(a + "4.weight", "", a + "4.bias", C, C, rsmp_[l], st));
+            TRY(pack_conv3(a + "4.weight", "", a + "4.bias", C, C, Cp, Cp, rsmp_[l], st));
         }
         snprintf(buf, sizeof(buf), "scratch.layer%d_rn.weight", l + 1);
-        TRY(pack_conv3(buf, "", "", F, C, layer_rn_[l], st));
+        TRY(pack_conv3(buf, "", "", F, C, F, Cp, layer_rn_[l], st));
     }
     // ---- refinenets + head ------------------------------------------------------------------------------
     for (int r = 1; r <= 4; ++r) {
@@ -274,8 +287,8 @@ int Engine::finalize(hipStream_t st) {
             if (u == 1 && r == 4) continue;      // refinenet4.resConfUnit1 never runs (lseg_net.py:176)
             const std::string q = p + "resConfUnit" + std::to_string(u) + ".";
             Rcu& U = u == 1 ? R.u1 : R.u2;
-            TRY(pack_conv3(q + "conv1.weight", q + "bn1", "", F, F, U.c1, st));
-            TRY(pack_conv3(q + "conv2.weight", q + "bn2", "", F, F, U.c2, st));
+            TRY(pack_conv3(q + "conv1.weight", q + "bn1", "", F, F, F, F, U.c1, st));
+            TRY(pack_conv3(q + "conv2.weight", q + "bn2", "", F, F, F, F, U.c2, st));
         }
         R.has_u1 = r != 4;
     }
@@ -536,7 +549,7 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
                 if (!acts_[l]) ALLOC(acts_[l], float, (size_t)c.max_batch * ntok_ * D);
                 LSEG_HIP_TRY(hipMemcpyAsync(acts_[l], x_, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, st));
             }
-            const int C = c.reassemble_ch[l];
+            const int C = cp_[l];                 // padded channel count (== reassemble_ch unless ViT-B/32 level 1)
             // ProjectReadout (lseg_vit.py:86-90)
             TRY(launch_readout_cat(x_, catA_, B, ntok_, D, img_dt_, st));
             gemm_args_init(g);
@@ -624,17 +637,17 @@ int Engine::get_intermediate(const char* name, float* out, size_t cap, size_t* n
         const int H = 2 * lh_[l], W = 2 * lw_[l];
         need_n = (size_t)B * F * H * W;
         if (cap < need_n) return set_error(LSEG_ERR_INVALID, "buffer too small: %zu < %zu", cap, need_n);
-        TRY(launch_nhwc_to_nchw_f32(path_[l], out, B, H, W, F, l > 0 ? 1 : 0, img_dt_, st));
+        TRY(launch_nhwc_to_nchw_f32(path_[l], out, B, H, W, F, F, l > 0 ? 1 : 0, img_dt_, st));
     } else if (!strncmp(name, "rn", 2) && name[2] >= '1' && name[2] <= '4' && !name[3]) {
         const int l = name[2] - '1';
         need_n = (size_t)B * F * lh_[l] * lw_[l];
         if (cap < need_n) return set_error(LSEG_ERR_INVALID, "buffer too small: %zu < %zu", cap, need_n);
-        TRY(launch_nhwc_to_nchw_f32(rn_[l], out, B, lh_[l], lw_[l], F, 1, img_dt_, st));
+        TRY(launch_nhwc_to_nchw_f32(rn_[l], out, B, lh_[l], lw_[l], F, F, 1, img_dt_, st));
     } else if (!strncmp(name, "layer", 5) && name[5] >= '1' && name[5] <= '4' && !name[6]) {
         const int l = name[5] - '1';
         need_n = (size_t)B * cfg.reassemble_ch[l] * lh_[l] * lw_[l];
         if (cap < need_n) return set_error(LSEG_ERR_INVALID, "buffer too small: %zu < %zu", cap, need_n);
-        TRY(launch_nhwc_to_nchw_f32(L_[l], out, B, lh_[l], lw_[l], cfg.reassemble_ch[l], 1, img_dt_, st));
+        TRY(launch_nhwc_to_nchw_f32(L_[l], out, B, lh_[l], lw_[l], cfg.reassemble_ch[l], cp_[l], 1, img_dt_, st));
     } else if (!strcmp(name, "image_features")) {
         const int hw1 = 4 * lh_[0] * lw_[0];
         need_n = (size_t)B * cfg.out_c * hw1;

@@ -21,12 +21,13 @@ int launch_text_embed(const int64_t* tok, const float* emb, const float* pos, vo
 int launch_text_pool(const void* x, const int* eot, void* pooled, int K, int L, int W, hipStream_t st);
 int launch_text_l2norm(const void* t, void* out, int K, int C, hipStream_t st);
 int launch_convert(const void* in, int in_dtype, void* out, int out_dtype, size_t n, hipStream_t st);
+int launch_convert2d(const void* in, int in_dtype, void* out, int out_dtype, int R, int C, int ld, hipStream_t st);
 int launch_transpose_convert(const void* in, int in_dtype, void* out, int out_dtype, int R, int C, hipStream_t st);
 int launch_pack_conv3x3(const float* w, const float* bn_w, const float* bn_b, const float* bn_m, const float* bn_v,
-                        float bn_eps, const float* conv_bias, void* wp, float* bias_out, int Co, int Ci, int dtype,
+                        float bn_eps, const float* conv_bias, void* wp, float* bias_out, int Co, int Ci, int Cip, int dtype,
                         hipStream_t st);
-int launch_pack_convT(const float* w, void* wp, int Ci, int Co, int s, int dtype, hipStream_t st);
-int launch_nhwc_to_nchw_f32(const void* in, float* out, int B, int H, int W, int C, int pad, int dtype, hipStream_t st);
+int launch_pack_convT(const float* w, void* wp, int Ci, int Co, int Cp, int s, int dtype, hipStream_t st);
+int launch_nhwc_to_nchw_f32(const void* in, float* out, int B, int H, int W, int C, int Cs, int pad, int dtype, hipStream_t st);
 int launch_rows_to_nchw_f32(const float* in, float* out, int B, int HW, int C, hipStream_t st);
 int launch_head_block(const float* in, float* out, const float* w9, const float* bias, int B, int K, int H, int W,
                       int bottleneck, int act, int apply_act, hipStream_t st);

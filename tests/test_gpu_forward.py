@@ -135,6 +135,18 @@ def test_vitl16_480_k150_matches_oracle_and_golden(golden_dir):
     assert (tf - gt).abs().max().item() <= 4e-3
 
 
+def test_vitb32_480_k7_matches_oracle_and_golden(golden_dir):
+    """BASELINE.json configs[0] (the reference's CPU-runnable plumbing case): ViT-B/32, 480x480, K=7.
+    Level-1 reassemble has 96 channels: the engine pads it to 128 zero-weight channels."""
+    spec = MG.FULL["vitb32_480_k7"]
+    rep = check_case(spec, stage_tol=0.15)        # this random 12-layer net amplifies bf16 rounding to 2.6-12.7 %
+    rep16 = check_case(spec, image_dtype="fp16", stage_tol=0.03)
+    assert rep16["logits_maxabs"] <= 0.06
+    g = torch.load(os.path.join(golden_dir, "vitb32_480_k7.pt"))
+    cfg, sd, tok, x, eng, logits, amax = run_engine(spec, debug=False)
+    assert (logits.cpu()[:, :, ::16, ::16] - g["logits_sub16"]).abs().max().item() <= LOGIT_TOL
+
+
 def test_vitl16_fp16_operands_track_the_reference_8x_closer():
     rep = check_case(MG.FULL["vitl16_480_k150"], image_dtype="fp16", stage_tol=0.015)
     assert rep["logits_maxabs"] <= 0.06
