@@ -1,0 +1,112 @@
+"""Multi-scale + flip sliding-window evaluator -- the direct caller of the hot path
+(reference: additional_utils/encoding_models.py:54-139 `MultiEvalModule.forward` and
+additional_utils/models.py:55-140 `LSeg_MultiEvalModule.forward`).
+
+Same algorithm, same arithmetic order per pixel, but every crop of a scale and its mirrored twin
+go through the engine as ONE batch instead of 2 x n_crops separate B=1 forwards (a 4:3 ADE image
+costs the reference 36 B=1 forwards, each re-encoding the 150 labels; here 6 batched forwards).
+Images of a batch are independent in the engine, so the result is identical to the sequential
+schedule.  Only data movement (resize / pad / crop / flip / accumulate) happens here, in torch.
+"""
+import math
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+def _pad_image(img, mean, std, crop_size):          # encoding_models.py:144-155
+    b, c, h, w = img.shape
+    padh = crop_size - h if h < crop_size else 0
+    padw = crop_size - w if w < crop_size else 0
+    if padh == 0 and padw == 0:
+        return img
+    pad_values = -np.array(mean) / np.array(std)
+    out = img.new_empty((b, c, h + padh, w + padw))
+    for i in range(c):
+        out[:, i] = F.pad(img[:, i], (0, padw, 0, padh), value=float(pad_values[i]))
+    return out
+
+
+class BatchedMultiEval(torch.nn.Module):
+    """Drop-in for `MultiEvalModule(module, nclass, scales=..., flip=...)` on one GPU.
+
+    `module` needs .evaluate(x) / .evaluate_random(x, labels), .base_size, .crop_size, .mean, .std,
+    ._up_kwargs (the LSegModule surface, modules/lseg_module.py:29-93)."""
+
+    def __init__(self, module, nclass, flip=True, scales=(0.5, 0.75, 1.0, 1.25, 1.5, 1.75), max_batch=16):
+        super().__init__()
+        self.module = module
+        self.nclass = nclass
+        self.base_size = module.base_size
+        self.crop_size = module.crop_size
+        self.scales = list(scales)
+        self.flip = flip
+        self.max_batch = max_batch
+
+    def _infer(self, crops: torch.Tensor, label_set) -> torch.Tensor:
+        """module_inference (encoding_models.py:133-139) for a stack of crops: out = f(x) + flip(f(flip(x)))."""
+        xs = torch.cat([crops, torch.flip(crops, dims=[3])], dim=0) if self.flip else crops
+        outs = []
+        for i in range(0, xs.shape[0], self.max_batch):
+            chunk = xs[i:i + self.max_batch].contiguous()
+            outs.append(self.module.evaluate(chunk) if label_set is None
+                        else self.module.evaluate_random(chunk, label_set))
+        out = torch.cat(outs, dim=0)
+        if self.flip:
+            n = crops.shape[0]
+            out = out[:n] + torch.flip(out[n:], dims=[3])
+        return out
+
+    def parallel_forward(self, inputs: Sequence[torch.Tensor], label_set=None) -> List[torch.Tensor]:
+        """list of [3,h,w] images in, list of [1,nclass,h,w] score maps out (encoding_models.py:35-52)."""
+        return [self.forward(img.unsqueeze(0).cuda(), label_set) for img in inputs]
+
+    @torch.no_grad()
+    def forward(self, image: torch.Tensor, label_set=None) -> torch.Tensor:
+        batch, _, h, w = image.shape
+        assert batch == 1
+        nclass = self.nclass if label_set is None else len(label_set)
+        crop_size = self.crop_size
+        stride = int(crop_size * 2.0 / 3.0)
+        up = self.module._up_kwargs
+        scores = image.new_zeros((batch, nclass, h, w))
+        for scale in self.scales:
+            long_size = int(math.ceil(self.base_size * scale))
+            if h > w:
+                height = long_size
+                width = int(1.0 * w * long_size / h + 0.5)
+                short_size = width
+            else:
+                width = long_size
+                height = int(1.0 * h * long_size / w + 0.5)
+                short_size = height
+            cur_img = F.interpolate(image, (height, width), **up)
+            if long_size <= crop_size:
+                pad_img = _pad_image(cur_img, self.module.mean, self.module.std, crop_size)
+                outputs = self._infer(pad_img, label_set)[:, :, :height, :width]
+            else:
+                pad_img = _pad_image(cur_img, self.module.mean, self.module.std, crop_size) \
+                    if short_size < crop_size else cur_img
+                _, _, ph, pw = pad_img.shape
+                h_grids = int(math.ceil(1.0 * (ph - crop_size) / stride)) + 1
+                w_grids = int(math.ceil(1.0 * (pw - crop_size) / stride)) + 1
+                boxes, crops = [], []
+                for idh in range(h_grids):
+                    for idw in range(w_grids):
+                        h0, w0 = idh * stride, idw * stride
+                        h1, w1 = min(h0 + crop_size, ph), min(w0 + crop_size, pw)
+                        boxes.append((h0, h1, w0, w1))
+                        crops.append(_pad_image(pad_img[:, :, h0:h1, w0:w1], self.module.mean, self.module.std,
+                                                crop_size))
+                outs = self._infer(torch.cat(crops, dim=0), label_set)        # one batched pass per scale
+                outputs = image.new_zeros((batch, nclass, ph, pw))
+                count_norm = image.new_zeros((batch, 1, ph, pw))
+                for k, (h0, h1, w0, w1) in enumerate(boxes):                 # same accumulation order
+                    outputs[:, :, h0:h1, w0:w1] += outs[k:k + 1, :, :h1 - h0, :w1 - w0]
+                    count_norm[:, :, h0:h1, w0:w1] += 1
+                assert (count_norm == 0).sum() == 0
+                outputs = (outputs / count_norm)[:, :, :height, :width]
+            scores += F.interpolate(outputs, (h, w), **up)
+        return scores

@@ -1,0 +1,99 @@
+"""§8f rank 1: the batched multi-scale/flip evaluator must equal the reference's sequential schedule
+(additional_utils/encoding_models.py:54-139, restated literally below with B=1 calls)."""
+import math
+import warnings
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference_schedule(module, image, nclass, scales, flip):
+    """Literal restatement of MultiEvalModule.forward + module_inference: one B=1 call per crop/flip."""
+    def pad_image(img, mean, std, crop):
+        b, c, h, w = img.shape
+        padh, padw = max(crop - h, 0), max(crop - w, 0)
+        pv = -np.array(mean) / np.array(std)
+        out = img.new_empty((b, c, h + padh, w + padw))
+        for i in range(c):
+            out[:, i] = F.pad(img[:, i], (0, padw, 0, padh), value=float(pv[i]))
+        return out
+
+    def infer(x):
+        out = module.evaluate(x.contiguous())
+        if flip:
+            out = out + torch.flip(module.evaluate(torch.flip(x, dims=[3]).contiguous()), dims=[3])
+        return out
+
+    batch, _, h, w = image.shape
+    crop, base = module.crop_size, module.base_size
+    stride = int(crop * 2.0 / 3.0)
+    scores = image.new_zeros((batch, nclass, h, w))
+    for scale in scales:
+        long_size = int(math.ceil(base * scale))
+        if h > w:
+            height, width = long_size, int(1.0 * w * long_size / h + 0.5); short = width
+        else:
+            width, height = long_size, int(1.0 * h * long_size / w + 0.5); short = height
+        cur = F.interpolate(image, (height, width), **module._up_kwargs)
+        if long_size <= crop:
+            outputs = infer(pad_image(cur, module.mean, module.std, crop))[:, :, :height, :width]
+        else:
+            pad = pad_image(cur, module.mean, module.std, crop) if short < crop else cur
+            _, _, ph, pw = pad.shape
+            hg = int(math.ceil(1.0 * (ph - crop) / stride)) + 1
+            wg = int(math.ceil(1.0 * (pw - crop) / stride)) + 1
+            outputs = image.new_zeros((batch, nclass, ph, pw)); cnt = image.new_zeros((batch, 1, ph, pw))
+            for ih in range(hg):
+                for iw in range(wg):
+                    h0, w0 = ih * stride, iw * stride
+                    h1, w1 = min(h0 + crop, ph), min(w0 + crop, pw)
+                    o = infer(pad_image(pad[:, :, h0:h1, w0:w1], module.mean, module.std, crop))
+                    outputs[:, :, h0:h1, w0:w1] += o[:, :, :h1 - h0, :w1 - w0]
+                    cnt[:, :, h0:h1, w0:w1] += 1
+            outputs = (outputs / cnt)[:, :, :height, :width]
+        scores += F.interpolate(outputs, (h, w), **module._up_kwargs)
+    return scores
+
+
+class _Mod(torch.nn.Module):
+    """Minimal LSegModule surface around an LSegNet (the full LSegModule pins crop_size to 480)."""
+    def __init__(self, net, crop, base):
+        super().__init__()
+        self.net, self.crop_size, self.base_size = net, crop, base
+        self.mean, self.std = [0.5] * 3, [0.5] * 3
+        self._up_kwargs = {"mode": "bilinear", "align_corners": True}
+
+    def evaluate(self, x, target=None):
+        return self.net(x)
+
+    def evaluate_random(self, x, labelset, target=None):
+        return self.net(x, labelset)
+
+
+def test_batched_evaluator_equals_sequential_reference_schedule():
+    warnings.simplefilter("ignore")
+    from modules.models.lseg_net import LSegNet
+    from lseg_hip.config import get_config
+    from lseg_hip.evaluator import BatchedMultiEval
+    from lseg_hip.synth import synthetic_state_dict, synthetic_images
+    cfg = get_config("tiny16")
+    labels = ["wall", "sky", "tree", "floor", "other"]
+    net = LSegNet(labels=labels, backbone="tiny16", features=cfg.features, arch_option=0, block_depth=0,
+                  activation="lrelu")
+    net.load_state_dict(synthetic_state_dict(cfg, seed=2))
+    mod = _Mod(net.eval().cuda(), crop=64, base=72)
+    img = synthetic_images(1, 80, 104, seed=5).cuda()          # 4:3-ish, forces grids of crops at scale > 1
+    scales = [0.5, 0.75, 1.0, 1.25, 1.5, 1.75]
+    with torch.no_grad():
+        ref = _reference_schedule(mod, img, len(labels), scales, flip=True)
+        ev = BatchedMultiEval(mod, len(labels), flip=True, scales=scales, max_batch=8)
+        got = ev(img)
+        assert got.shape == ref.shape == (1, 5, 80, 104)
+        assert torch.allclose(got, ref, atol=1e-5, rtol=0), (got - ref).abs().max()
+        assert torch.equal(got.argmax(1), ref.argmax(1))
+        sub = ev.parallel_forward([img[0]], label_set=labels[:3])
+        assert sub[0].shape == (1, 3, 80, 104)
