@@ -175,6 +175,12 @@ int lseg_op_upsample2x_planes(const float* d_in, float* d_out, int P, int H, int
 int lseg_op_correlation(const float* d_feat, const void* d_text_f16, float* d_logits,
                         int B, int P, int C, int K, float logit_scale, void* stream);
 
+/* fused scratch.head1 + pixel normalisation (lseg_net.py:185-194, out_c = 512): x bf16 [M,F] pixels,
+ * w bf16 [512,F], bias fp32 [512]  ->  a fp16 [M,512] = fp16(scale * fp16(v/||v||_2)), v = x w^T + bias
+ * (the A operand of the correlation GEMM; the fp32 features are never materialised). */
+int lseg_op_head_features(const void* d_x_bf16, const void* d_w_bf16, const float* d_bias, void* d_a_f16,
+                          int M, int F, float logit_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -176,4 +176,14 @@ int lseg_op_correlation(const float* feat, const void* text_f16, float* logits, 
     return r;
 }
 
+int lseg_op_head_features(const void* x_bf16, const void* w_bf16, const float* bias, void* a_f16, int M, int F,
+                          float logit_scale, void* stream) {
+    int r = require_device(); if (r) return r;
+    GemmArgs g;
+    gemm_args_init(g);
+    g.A = (const uint16_t*)x_bf16; g.W = (const uint16_t*)w_bf16; g.M = M; g.N = 512; g.K = F; g.lda = F; g.ldw = F;
+    g.bias = bias; g.C = a_f16; g.out_dtype = DT_F16; g.ldc = 512; g.map_mode = MAP_ROWNORM; g.rn_scale = logit_scale;
+    return launch_gemm(g, DT_BF16, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -587,12 +587,20 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
 
     // ---- head1 + normalise + correlation (lseg_net.py:185-196) ------------------------------------------------
     const int h1 = 2 * lh_[0], w1 = 2 * lw_[0], hw1 = h1 * w1, Mp = B * hw1;
+    const float logit_scale = expf(logf(1.0f / 0.07f));                // lseg_net.py:141
     gemm_args_init(g);
     g.A = path_[0]; g.W = head1_.w; g.M = Mp; g.N = c.out_c; g.K = F; g.lda = F; g.ldw = F;
-    g.bias = head1_.b; g.C = feat_; g.out_dtype = DT_F32; g.ldc = c.out_c; g.map_mode = MAP_LINEAR;
-    TRY(launch_gemm(g, img_dt_, st));
-    const float logit_scale = expf(logf(1.0f / 0.07f));                // lseg_net.py:141
-    TRY(launch_l2norm_scale_f16(feat_, a16_, Mp, c.out_c, logit_scale, st));
+    g.bias = head1_.b;
+    if (c.out_c == 512 && !debug) {
+        // fused: head1 + fp32 L2-norm + the two fp16 roundings in one epilogue (rows are complete inside
+        // a workgroup); the 118 MB/image fp32 feature map is never written
+        g.C = a16_; g.out_dtype = DT_F16; g.ldc = c.out_c; g.map_mode = MAP_ROWNORM; g.rn_scale = logit_scale;
+        TRY(launch_gemm(g, img_dt_, st));
+    } else {
+        g.C = feat_; g.out_dtype = DT_F32; g.ldc = c.out_c; g.map_mode = MAP_LINEAR;
+        TRY(launch_gemm(g, img_dt_, st));
+        TRY(launch_l2norm_scale_f16(feat_, a16_, Mp, c.out_c, logit_scale, st));
+    }
     gemm_args_init(g);
     g.A = a16_; g.W = tnorm_; g.M = Mp; g.N = K_; g.K = c.out_c; g.lda = c.out_c; g.ldw = c.out_c;
     g.round_mid = 1; g.C = low_; g.out_dtype = DT_F32; g.map_mode = MAP_NCHW; g.p_div = hw1;

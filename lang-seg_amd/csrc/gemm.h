@@ -15,6 +15,7 @@ enum MapMode {
                       // [b, y*s+i+1, x*s+j+1, co] of a (Ho*s+2, Wo*s+2) map
     MAP_QKV = 4,      // n=(which, head, d), m=(b,t): q,k -> [b,head,t,d] ; v -> [b,head,d,t]
     MAP_NCHW = 5,     // m=(b,p), P=p_div pixels: C[(b*N + n)*P + p]  (label-major logits planes)
+    MAP_ROWNORM = 6,  // fused head (N == 512): C[m*ldc+n] = fp16(rn_scale * fp16(v / ||v_row||_2)), v = acc + bias
 };
 enum ResMode { RES_NONE = 0, RES_DEST = 1, RES_PERIODIC = 2 };
 
@@ -45,6 +46,7 @@ struct GemmArgs {
     int ps_s, ps_C;             // MAP_PIXSHUF
     // MAP_QKV
     void* Ck; void* Cv; int qkv_dim, qkv_ntok, qkv_npad, qkv_heads;
+    float rn_scale;             // MAP_ROWNORM: logit scale
     int tag;                    // 0 generic, 1 = the profiled dominant instance (distinct symbol)
     int dbg;                    // ablation knob (tools only): 1 = skip epilogue stores, 2 = skip the epilogue
 };

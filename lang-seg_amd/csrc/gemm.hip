@@ -329,9 +329,9 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& g, int m, const int
 //   Big   256x128, 4x2 waves, 3 stages (144 KB LDS, 1 workgroup/CU, loads fly two K-steps ahead)
 //   Mid   128x128, 2x2 waves, 2 stages ( 64 KB LDS, 2 workgroups/CU)
 //   Small  64x64,  2x2 waves (32x32 per wave), 2 stages: fills the chip when M*N is small
-template <int BM_, int BN_, int WGM_, int WGN_, int NS_>
+template <int BM_, int BN_, int WGM_, int WGN_, int NS_, int MINW_ = 2>
 struct TileCfg {
-    static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, NS = NS_;
+    static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, NS = NS_, MINW = MINW_;
     static constexpr int NW = WGM * WGN, THREADS = 64 * NW;
     static constexpr int WM = BM / WGM, WN = BN / WGN;          // per-wave sub-tile
     static constexpr int MI = WM / 16, NI = WN / 16;            // 16x16 MFMA tiles per wave
@@ -344,6 +344,9 @@ struct TileCfg {
 using CfgBig = TileCfg<256, 128, 4, 2, 3>;
 using CfgMid = TileCfg<128, 128, 2, 2, 2>;
 using CfgSmall = TileCfg<64, 64, 2, 2, 2>;
+// Row config: one workgroup owns complete 512-wide output rows (fused head1 + L2-norm + fp16 casts);
+// 128 accumulator registers per lane -> one wave per SIMD, 144 KB LDS + 1 KB reduction scratch
+using CfgRow = TileCfg<64, 512, 1, 4, 2, 1>;
 
 // Counted waits go through the BUILTIN, not inline asm: SIInsertWaitcnts understands a pre-existing
 // s_waitcnt and keeps its own scoreboard consistent.  An opaque asm wait left it believing that
@@ -371,7 +374,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 __device__ __forceinline__ void wait_lgkmcnt0() { __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14)); }
 
 template <typename T, typename CFG, bool CONV, bool RELU_IN, int TAG>
-__global__ __launch_bounds__(CFG::THREADS, 2) void lseg_gemm_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(const GemmArgs g) {
     constexpr int BM = CFG::BM, BN = CFG::BN, NS = CFG::NS, NW = CFG::NW;
     constexpr int WM = CFG::WM, WN = CFG::WN, MI = CFG::MI, NI = CFG::NI;
     constexpr int A_BYTES = CFG::A_BYTES, STAGE = CFG::STAGE, A_SPW = CFG::A_SPW, W_SPW = CFG::W_SPW;
@@ -528,6 +531,57 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void lseg_gemm_kernel(const GemmAr
             int mbc, nbc;
             tile_coords(prev, tiles_m, tiles_n, mbc, nbc);
             const int m0c = mbc * BM, n0c = nbc * BN;
+            if constexpr (CFG::BN == 512) {
+                // ---- fused head (lseg_net.py:185-194): v = head1(x)+bias ; a = fp16(s * fp16(v/||v||)) ----
+                // lane owns, for each of its MI rows, NI groups of 4 columns inside this wave's 128
+                // columns; the row's sum of squares is reduced over the 4 lane groups (shuffles) and
+                // over the 4 waves (LDS scratch behind the stage ring), in a fixed order.
+                float* red = reinterpret_cast<float*>(smem + NS * STAGE);      // [4 waves][64 rows]
+                const int n_first = n0c + wn * WN + (lane >> 4) * 4;
+                float ssq[MI];
+                static_for<0, MI>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    float s_ = 0.f;
+                    static_for<0, NI>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        const float4 bv = *reinterpret_cast<const float4*>(g.bias + n_first + i * 16);
+                        acc[i][j][0] += bv.x; acc[i][j][1] += bv.y; acc[i][j][2] += bv.z; acc[i][j][3] += bv.w;
+                        s_ += acc[i][j][0] * acc[i][j][0] + acc[i][j][1] * acc[i][j][1] +
+                              acc[i][j][2] * acc[i][j][2] + acc[i][j][3] * acc[i][j][3];
+                    });
+                    s_ += __shfl_xor(s_, 16);
+                    s_ += __shfl_xor(s_, 32);
+                    ssq[j] = s_;
+                });
+                if (lane < 16) {
+#pragma unroll
+                    for (int j = 0; j < MI; ++j) red[wn * 64 + j * 16 + lane] = ssq[j];
+                }
+                __syncthreads();
+                static_for<0, MI>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    const int rl = j * 16 + (lane & 15);
+                    const float nrm = sqrtf((red[rl] + red[64 + rl]) + (red[128 + rl] + red[192 + rl]));
+                    const int m = m0c + rl;
+                    const int r16 = lane >> 4;
+                    static_for<0, NI / 2>([&](auto pc) {
+                        constexpr int i = 2 * decltype(pc)::value;
+                        float y[2][4];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) y[q][r] = g.rn_scale * round_f16(acc[i + q][j][r] / nrm);
+                        const uint32_t a0 = pack2<F16>(y[0][0], y[0][1]), a1 = pack2<F16>(y[0][2], y[0][3]);
+                        const uint32_t b0 = pack2<F16>(y[1][0], y[1][1]), b1 = pack2<F16>(y[1][2], y[1][3]);
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                        const int col = n0c + wn * WN + i * 16 + (r16 & 1) * 16 + (r16 >> 1) * 8;
+                        if (m < g.M)
+                            *reinterpret_cast<uint4*>((uint16_t*)g.C + (size_t)m * g.ldc + col) =
+                                make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    });
+                });
+            } else {
             int ncol[NI];
             ColPart cp[NI], cpw[NI / 2];
             float4 bias[NI];
@@ -547,6 +601,7 @@ __global__ __launch_bounds__(CFG::THREADS, 2) void lseg_gemm_kernel(const GemmAr
                 const int m = m0c + wm * WM + j * 16 + (lane & 15);
                 if (g.dbg == 2) { asm volatile("" ::"v"(row[0][0]), "v"(row[NI - 1][3])); continue; }
                 if (m < g.M) epilogue_row<T, NI>(g, m, ncol, cp, cpw, wide, bias, row);
+            }
             }
             if (NS > 2) wait_vmcnt<0>();     // see the ping-pong kernel: keeps stray vmcnt(0) out of the K-loop
         }
@@ -807,7 +862,7 @@ int launch_pp(const GemmArgs& g, hipStream_t stream) {
 template <typename T, typename CFG, bool CONV, bool RELU_IN, int TAG>
 int launch_one(const GemmArgs& g, hipStream_t stream) {
     const int tiles = ((g.M + CFG::BM - 1) / CFG::BM) * ((g.N + CFG::BN - 1) / CFG::BN);
-    const size_t lds = CFG::LDS;
+    const size_t lds = CFG::LDS + (CFG::BN == 512 ? 1024 : 0);
     // persistent grid: a multiple of 8 (one slice per XCD), at most `slots` resident workgroups
     constexpr int by_lds = 163840 / CFG::LDS, by_waves = 8 / (CFG::NW / 4);
     constexpr int per_cu = by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : by_waves;
@@ -831,6 +886,11 @@ int pick_tile(const GemmArgs& g, hipStream_t stream) {
     const long t_big = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
     const long t_mid = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
     static const int force = getenv("LSEG_GEMM_TILE") ? atoi(getenv("LSEG_GEMM_TILE")) : 0;   // 1 small 2 mid 3 big
+    if (g.map_mode == MAP_ROWNORM) {
+        if (CONV || RELU_IN || g.N != 512 || !g.bias)
+            return set_error(LSEG_ERR_UNSUPPORTED, "fused head needs a plain GEMM with N == 512 and a bias");
+        return launch_one<T, CfgRow, false, false, 0>(g, stream);
+    }
     int pick = t_mid >= 192 ? 2 : 1;       // 3 = 256x128/8 waves/3 stages (lock-step), 4 = ping-pong
     (void)t_big;
     if (force) pick = force;

@@ -67,6 +67,7 @@ SIGNATURES = {
     "lseg_op_upsample2x_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "lseg_op_upsample2x_planes": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "lseg_op_correlation": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "lseg_op_head_features": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -207,3 +207,21 @@ def test_correlation_matches_oracle(lib, K):
     assert diff.max().item() <= 2 ** -6                                      # <= 1 ulp at |logit| < 16
     assert (diff > 0).float().mean().item() < 0.02
     assert (got.argmax(1) != ref.argmax(1)).float().mean().item() < 0.01
+
+
+@pytest.mark.parametrize("M,Fd", [(1000, 256), (57600, 256), (130, 64)])
+def test_fused_head_features(lib, M, Fd):
+    """head1 + L2 norm + fp16 casts in one GEMM epilogue == the unfused reference arithmetic."""
+    from oracle.lseg_oracle import LOGIT_SCALE, r16
+    dt = torch.bfloat16
+    x = rnd((M, Fd), dt, 70, 2.0)
+    w = rnd((512, Fd), dt, 71, 1 / math.sqrt(Fd))
+    b = rnd((512,), torch.float32, 72)
+    out = torch.zeros((M, 512), dtype=torch.float16).cuda()
+    _lib.check(lib.lseg_op_head_features(P(x), P(w), P(b), P(out), M, Fd, LOGIT_SCALE, stream()))
+    torch.cuda.synchronize()
+    v = x.float() @ w.float().t() + b
+    ref = r16(LOGIT_SCALE * r16(v / v.norm(dim=-1, keepdim=True)))
+    d = (out.float() - ref).abs()
+    assert d.max().item() <= 2 ** -7                      # 1 fp16 ulp at |a| < 8 (fp32 summation order)
+    assert (d > 0).float().mean().item() < 0.05
