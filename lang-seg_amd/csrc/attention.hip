@@ -16,10 +16,9 @@
 //   * row max / row sum are lane-local (plus one exchange with lane^32),
 //   * the online-softmax rescale of O is a per-lane scalar multiply,
 //   * the exponentiated scores feed the second MFMA straight from registers: the k-slot
-//     <-> key assignment of the second product is chosen to be exactly the accumulator
-//     layout of the first (key = 16*s + 4*(lane>>5) + (j&3) + 8*(j>>2)), and V^T is read
-//     from LDS with the same assignment (two 8-byte reads), so no cross-lane shuffle or
-//     LDS round trip of P is needed.
+//     accumulator layout of the first (key = 16*s + 4*(lane>>5) + (j&3) + 8*(j>>2)) is turned
+//     into the standard operand order (8 contiguous keys per lane) by one v_permlane32_swap per
+//     packed word -- no LDS round trip of P -- and V^T is read with conflict-free ds_read_b128.
 #include "common.h"
 #include "../../include/lseg_hip.h"
 
@@ -155,16 +154,26 @@ __global__ __launch_bounds__(256, 3) void lseg_attention_kernel(const AttnArgs a
                 for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
         }
 
-        // ---- P^T fragments (B operand), straight from the accumulator layout -----------------
+        // ---- P^T fragments (B operand) ----------------------------------------------------------
+        // The accumulator gives a lane keys {0-3, 8-11} (+4 for the upper half-wave) of each 16-key
+        // step.  One v_permlane32_swap per packed word trades the second quad of the lower half with
+        // the first quad of the upper half, so a lane ends up with 8 CONTIGUOUS keys (lower half
+        // 0-7, upper half 8-15): the standard operand order, and V^T is then read with one
+        // conflict-free ds_read_b128 per fragment instead of two 2-way-conflicting ds_read_b64.
         i32x4_t pf[2][2];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int wd = 0; wd < 4; ++wd) {
-                    pf[sub][s2][wd] = (int)pack2<T>(s[sub][8 * s2 + 2 * wd], s[sub][8 * s2 + 2 * wd + 1]);
-                }
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const uint32_t a0 = pack2<T>(s[sub][8 * s2 + 0], s[sub][8 * s2 + 1]);   // quad A, words 0/1
+                const uint32_t a1 = pack2<T>(s[sub][8 * s2 + 2], s[sub][8 * s2 + 3]);
+                const uint32_t b0 = pack2<T>(s[sub][8 * s2 + 4], s[sub][8 * s2 + 5]);   // quad B
+                const uint32_t b1 = pack2<T>(s[sub][8 * s2 + 6], s[sub][8 * s2 + 7]);
+                const auto w0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                const auto w1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                pf[sub][s2][0] = (int)w0[0]; pf[sub][s2][1] = (int)w1[0];
+                pf[sub][s2][2] = (int)w0[1]; pf[sub][s2][3] = (int)w1[1];
+            }
         // ---- O^T[d][q] += V^T[d][keys] P^T[keys][q] -----------------------------------------------
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
@@ -173,11 +182,7 @@ __global__ __launch_bounds__(256, 3) void lseg_attention_kernel(const AttnArgs a
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    const int c = sub * 4 + s2 * 2;
-                    const uint2 v0 = *reinterpret_cast<const uint2*>(sv + tile_off(row, c) + hi * 8);
-                    const uint2 v1 = *reinterpret_cast<const uint2*>(sv + tile_off(row, c + 1) + hi * 8);
-                    i32x4_t vf;
-                    vf[0] = (int)v0.x; vf[1] = (int)v0.y; vf[2] = (int)v1.x; vf[3] = (int)v1.y;
+                    const i32x4_t vf = *reinterpret_cast<const i32x4_t*>(sv + tile_off(row, sub * 4 + s2 * 2 + hi));
                     o[d] = mfma32<T>(vf, pf[sub][s2], o[d]);
                 }
         }

@@ -217,23 +217,25 @@ __global__ __launch_bounds__(256) void upsample2x_planes_kernel(const float* in,
     int yo = (int)ceilf((float)y0 / ry);
     while (yo > 0 && (int)(ry * (float)(yo - 1)) >= y0) --yo;
     while ((int)(ry * (float)yo) < y0) ++yo;
-    for (; yo < Ho && (int)(ry * (float)yo) == y0; ++yo) {
-        const float sy = ry * (float)yo;
+    int nrows = 0;
+    while (yo + nrows < Ho && (int)(ry * (float)(yo + nrows)) == y0) ++nrows;
+    // flatten (output row, 4-column group) over the whole block so no thread idles
+    for (int item = threadIdx.x; item < nrows * w4; item += 256) {
+        const int rr = item / w4, x4 = item - rr * w4;
+        const int yy = yo + rr;
+        const float sy = ry * (float)yy;
         const float ly = sy - (float)y0;
-        float* orow = out + ((size_t)pl * Ho + yo) * Wo;
-        for (int x4 = threadIdx.x; x4 < w4; x4 += 256) {
-            float o[4];
+        float o[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int xo = x4 * 4 + e;
-                const float sx = rx * (float)xo;
-                const int x0 = (int)sx, x1 = x0 + (x0 < W - 1);
-                const float lx = sx - (float)x0;
-                o[e] = (1.f - ly) * ((1.f - lx) * rows[x0] + lx * rows[x1]) + ly * ((1.f - lx) * rows[W + x0] + lx * rows[W + x1]);
-            }
-            const f32x4_t ov = {o[0], o[1], o[2], o[3]};     // written once, never re-read by the engine
-            __builtin_nontemporal_store(ov, reinterpret_cast<f32x4_t*>(orow) + x4);
+        for (int e = 0; e < 4; ++e) {
+            const int xo = x4 * 4 + e;
+            const float sx = rx * (float)xo;
+            const int x0 = (int)sx, x1 = x0 + (x0 < W - 1);
+            const float lx = sx - (float)x0;
+            o[e] = (1.f - ly) * ((1.f - lx) * rows[x0] + lx * rows[x1]) + ly * ((1.f - lx) * rows[W + x0] + lx * rows[W + x1]);
         }
+        const f32x4_t ov = {o[0], o[1], o[2], o[3]};     // written once, never re-read by the engine
+        __builtin_nontemporal_store(ov, reinterpret_cast<f32x4_t*>(out + ((size_t)pl * Ho + yy) * Wo) + x4);
     }
 }
 
