@@ -195,7 +195,7 @@ __global__ void upsample2x_nhwc_kernel(const uint16_t* in, uint16_t* out, int B,
 
 // ---- bilinear x2, align_corners=True, fp32 planes [P,H,W] -> [P,2H,2W] (lseg_net.py:203) -----------
 // optional per-plane post-op none.  Each thread writes 4 consecutive outputs (16 B).
-__global__ __launch_bounds__(256) void upsample2x_planes_kernel(const float* in, float* out, int P, int H, int W) {
+__global__ __launch_bounds__(128) void upsample2x_planes_kernel(const float* in, float* out, int P, int H, int W) {
     // One block = one input-row pair -> the (up to 3) output rows whose source row y0 is this one.
     // The two input rows are staged in LDS (coalesced float4 loads); every thread then produces 4
     // consecutive outputs per output row from LDS and writes them with one 16-byte non-temporal
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void upsample2x_planes_kernel(const float* in,
     const int y1 = y0 + (y0 < H - 1);
     const float* r0 = in + ((size_t)pl * H + y0) * W;
     const float* r1 = in + ((size_t)pl * H + y1) * W;
-    for (int i = threadIdx.x; i < W / 4; i += 256) {
+    for (int i = threadIdx.x; i < W / 4; i += 128) {
         reinterpret_cast<float4*>(rows)[i] = reinterpret_cast<const float4*>(r0)[i];
         reinterpret_cast<float4*>(rows + W)[i] = reinterpret_cast<const float4*>(r1)[i];
     }
@@ -217,25 +217,23 @@ __global__ __launch_bounds__(256) void upsample2x_planes_kernel(const float* in,
     int yo = (int)ceilf((float)y0 / ry);
     while (yo > 0 && (int)(ry * (float)(yo - 1)) >= y0) --yo;
     while ((int)(ry * (float)yo) < y0) ++yo;
-    int nrows = 0;
-    while (yo + nrows < Ho && (int)(ry * (float)(yo + nrows)) == y0) ++nrows;
-    // flatten (output row, 4-column group) over the whole block so no thread idles
-    for (int item = threadIdx.x; item < nrows * w4; item += 256) {
-        const int rr = item / w4, x4 = item - rr * w4;
-        const int yy = yo + rr;
-        const float sy = ry * (float)yy;
+    for (; yo < Ho && (int)(ry * (float)yo) == y0; ++yo) {
+        const float sy = ry * (float)yo;
         const float ly = sy - (float)y0;
-        float o[4];
+        float* orow = out + ((size_t)pl * Ho + yo) * Wo;
+        for (int x4 = threadIdx.x; x4 < w4; x4 += 128) {
+            float o[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int xo = x4 * 4 + e;
-            const float sx = rx * (float)xo;
-            const int x0 = (int)sx, x1 = x0 + (x0 < W - 1);
-            const float lx = sx - (float)x0;
-            o[e] = (1.f - ly) * ((1.f - lx) * rows[x0] + lx * rows[x1]) + ly * ((1.f - lx) * rows[W + x0] + lx * rows[W + x1]);
+            for (int e = 0; e < 4; ++e) {
+                const int xo = x4 * 4 + e;
+                const float sx = rx * (float)xo;
+                const int x0 = (int)sx, x1 = x0 + (x0 < W - 1);
+                const float lx = sx - (float)x0;
+                o[e] = (1.f - ly) * ((1.f - lx) * rows[x0] + lx * rows[x1]) + ly * ((1.f - lx) * rows[W + x0] + lx * rows[W + x1]);
+            }
+            const f32x4_t ov = {o[0], o[1], o[2], o[3]};     // written once, never re-read by the engine
+            __builtin_nontemporal_store(ov, reinterpret_cast<f32x4_t*>(orow) + x4);
         }
-        const f32x4_t ov = {o[0], o[1], o[2], o[3]};     // written once, never re-read by the engine
-        __builtin_nontemporal_store(ov, reinterpret_cast<f32x4_t*>(out + ((size_t)pl * Ho + yy) * Wo) + x4);
     }
 }
 
@@ -489,7 +487,7 @@ int launch_upsample2x_planes(const float* in, float* out, int P, int H, int W, h
     if (W % 4) return set_error(LSEG_ERR_UNSUPPORTED, "upsample2x_planes: W=%d must be a multiple of 4", W);
     const size_t blocks = (size_t)P * H;
     if (blocks > 0x7fffffffu) return set_error(LSEG_ERR_UNSUPPORTED, "upsample2x_planes: too many rows");
-    hipLaunchKernelGGL(upsample2x_planes_kernel, dim3((unsigned)blocks), dim3(256), 2 * W * sizeof(float), st, in, out, P, H, W);
+    hipLaunchKernelGGL(upsample2x_planes_kernel, dim3((unsigned)blocks), dim3(128), 2 * W * sizeof(float), st, in, out, P, H, W);
     CHECK_LAUNCH();
     return 0;
 }
