@@ -1,4 +1,5 @@
 // capi.hip -- extern "C" surface of liblseg_hip.so (declared in include/lseg_hip.h).
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -112,6 +113,9 @@ int lseg_op_gemm(const void* A, const void* W, const float* bias, const float* r
     g.A = (const uint16_t*)A; g.W = (const uint16_t*)W; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K;
     g.bias = bias; g.act = act;
     if (residual) { g.res_mode = RES_DEST; g.res = residual; g.res_dtype = DT_F32; }
+    if (getenv("LSEG_GEMM_DBG") && (atoi(getenv("LSEG_GEMM_DBG")) & 4)) {   // tools/gemm_phase_probe.py: timing dump
+        g.res_mode = RES_NONE; g.res2 = residual;
+    }
     g.C = C; g.out_dtype = od; g.ldc = N; g.map_mode = MAP_LINEAR;
     return launch_gemm(g, ab, (hipStream_t)stream);
 }

@@ -197,7 +197,7 @@ __device__ __forceinline__ void store4(void* dst, size_t off, int dtype, const f
 template <int NI>
 __device__ __forceinline__ bool epilogue_cols(const GemmArgs& g, int n_first, int lane, int (&ncol)[NI], ColPart (&cp)[NI],
                                               ColPart (&cpw)[NI / 2], float4 (&bias)[NI]) {
-    const bool wide = g.out_dtype != DT_F32 && (g.N & 31) == 0 && g.map_mode != MAP_NCHW && g.dbg == 0 &&
+    const bool wide = g.out_dtype != DT_F32 && (g.N & 31) == 0 && g.map_mode != MAP_NCHW && (g.dbg & 3) == 0 &&
                       (g.map_mode != MAP_PIXSHUF || (g.ps_C & 31) == 0);
     {
         const int r16 = lane >> 4;
@@ -274,7 +274,7 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& g, int m, const int
             v[i][2] += rv[i].z + rv2[i].z; v[i][3] += rv[i].w + rv2[i].w;
         }
     }
-    if (g.dbg == 1) {   // ablation: keep the values live, skip the stores
+    if ((g.dbg & 3) == 1) {   // ablation: keep the values live, skip the stores
 #pragma unroll
         for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(v[i][0]), "v"(v[i][1]), "v"(v[i][2]), "v"(v[i][3]));
         return;
@@ -321,6 +321,128 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& g, int m, const int
             for (int r = 0; r < 4; ++r)
                 if (ncol[i] + r < g.N) store_from_f32(dst, off + r * estride, g.out_dtype, v[i][r]);
         }
+    }
+}
+
+// ---- specialised epilogues of the ViT's four GEMMs ------------------------------------------------
+// The generic epilogue above decodes map/residual/dtype/activation at run time; measured with
+// tools/gemm_phase_probe.py it cost ~9,500 cycles per 128x128 tile (a quarter of a K=1024 tile: ~3,000
+// waiting for the bias loads, ~3,700 in run-time-dispatched conversion code, ~2,900 in stores).  The hot
+// shapes get compile-time variants: bias prefetched at the start of the tile, straight-line math,
+// permlane-widened 16-byte stores.  Requirements (checked by select_epi): N % 128 == 0, a bias,
+// no round_mid, 16-byte aligned rows.
+enum Epi {
+    EPI_GENERIC = 0,
+    EPI_LIN16 = 1,        // C[m*ldc+n] = T(acc + bias)                      (attention proj inputs, readout, ...)
+    EPI_LIN16_GELU = 2,   // C[m*ldc+n] = T(gelu(acc + bias))                (MLP fc1)
+    EPI_RES32 = 3,        // C[m*ldc+n] = res[m*ldc+n] + acc + bias, fp32    (attention proj / MLP fc2 on the residual stream)
+    EPI_QKV16 = 4,        // MAP_QKV, q,k -> [b,head,t,d], v -> [b,head,d,t]
+};
+
+// two adjacent 16-column sub-tiles (4 columns per lane each) -> 8 contiguous columns (16 bytes) per lane
+template <typename T>
+__device__ __forceinline__ uint4 widen16(const float (&x)[4], const float (&y)[4]) {
+    const uint32_t a0 = pack2<T>(x[0], x[1]), a1 = pack2<T>(x[2], x[3]);
+    const uint32_t b0 = pack2<T>(y[0], y[1]), b1 = pack2<T>(y[2], y[3]);
+    const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+    const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+    return make_uint4(s0[0], s1[0], s0[1], s1[1]);
+}
+
+// mrow0 / ncol0: first row / column of this WAVE's sub-tile (wave-uniform).  acc[i][j]: rows
+// mrow0 + j*16 + (lane&15), columns ncol0 + i*16 + (lane>>4)*4 .. +3.
+template <typename T, int EPI, int MI, int NI>
+__device__ __forceinline__ void fast_epilogue(const GemmArgs& g, f32x4_t (&acc)[NI][MI], int mrow0, int ncol0, int lane,
+                                              const float4 (&bias)[NI]) {
+    const int r16 = lane >> 4, ml = lane & 15;
+    const int cw = (r16 & 1) * 16 + (r16 >> 1) * 8;       // lane's 8 columns inside a 32-column pair after the swap
+    auto biased = [&](auto ic, auto jc, float (&v)[4]) {
+        constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
+        v[0] = acc[i][j][0] + bias[i].x; v[1] = acc[i][j][1] + bias[i].y;
+        v[2] = acc[i][j][2] + bias[i].z; v[3] = acc[i][j][3] + bias[i].w;
+    };
+    if constexpr (EPI == EPI_LIN16 || EPI == EPI_LIN16_GELU) {
+        uint16_t* cbase = (uint16_t*)g.C + ncol0 + cw;
+        static_for<0, MI>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int m = mrow0 + j * 16 + ml;
+            uint16_t* p = cbase + (size_t)m * g.ldc;
+            static_for<0, NI / 2>([&](auto pc) {
+                constexpr int i = 2 * decltype(pc)::value;
+                float x[4], y[4];
+                biased(std::integral_constant<int, i>{}, jc, x);
+                biased(std::integral_constant<int, i + 1>{}, jc, y);
+                if constexpr (EPI == EPI_LIN16_GELU) {
+                    const f32x2_t a = gelu_erf2(f32x2_t{x[0], x[1]}), b = gelu_erf2(f32x2_t{x[2], x[3]});
+                    const f32x2_t c = gelu_erf2(f32x2_t{y[0], y[1]}), d = gelu_erf2(f32x2_t{y[2], y[3]});
+                    x[0] = a[0]; x[1] = a[1]; x[2] = b[0]; x[3] = b[1];
+                    y[0] = c[0]; y[1] = c[1]; y[2] = d[0]; y[3] = d[1];
+                }
+                const uint4 o = widen16<T>(x, y);
+                if (m < g.M) *reinterpret_cast<uint4*>(p + i * 16) = o;
+            });
+        });
+    } else if constexpr (EPI == EPI_RES32) {
+        // every residual load of the sub-tile is in flight before the first store (in place: x += f(x))
+        float* cbase = (float*)g.C + ncol0 + r16 * 4;
+        const float* rbase = (const float*)g.res + ncol0 + r16 * 4;
+        float4 rv[MI][NI];
+        static_for<0, MI>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            int m = mrow0 + j * 16 + ml;
+            if (m > g.M - 1) m = g.M - 1;
+            const float* rp = rbase + (size_t)m * g.ldc;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) rv[j][i] = *reinterpret_cast<const float4*>(rp + i * 16);
+        });
+        static_for<0, MI>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int m = mrow0 + j * 16 + ml;
+            float* p = cbase + (size_t)m * g.ldc;
+            static_for<0, NI>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                float v[4];
+                biased(ic, jc, v);
+                if (m < g.M)
+                    *reinterpret_cast<float4*>(p + i * 16) =
+                        make_float4(v[0] + rv[j][i].x, v[1] + rv[j][i].y, v[2] + rv[j][i].z, v[3] + rv[j][i].w);
+            });
+        });
+    } else if constexpr (EPI == EPI_QKV16) {
+        // a wave's 64 columns are one head of one of q / k / v (wave-uniform)
+        const int which = ncol0 / g.qkv_dim;
+        const int head = (ncol0 - which * g.qkv_dim) >> 6;
+        const int d0 = (ncol0 - which * g.qkv_dim) & 63;      // 0 for 64-wide wave tiles, 0|32 for the 32-wide ones
+        static_for<0, MI>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int m = mrow0 + j * 16 + ml;
+            const int mm = m < g.M ? m : g.M - 1;
+            const int b = mm / g.qkv_ntok, t = mm - b * g.qkv_ntok;
+            const size_t bh = (size_t)b * g.qkv_heads + head;
+            if (which < 2) {
+                uint16_t* p = (uint16_t*)(which ? g.Ck : g.C) + (bh * g.qkv_npad + t) * 64 + d0 + cw;
+                static_for<0, NI / 2>([&](auto pc) {
+                    constexpr int i = 2 * decltype(pc)::value;
+                    float x[4], y[4];
+                    biased(std::integral_constant<int, i>{}, jc, x);
+                    biased(std::integral_constant<int, i + 1>{}, jc, y);
+                    const uint4 o = widen16<T>(x, y);
+                    if (m < g.M) *reinterpret_cast<uint4*>(p + i * 16) = o;
+                });
+            } else {
+                // V^T [b, head, d, t]: t is the contiguous axis; 16 lanes write 16 consecutive tokens
+                uint16_t* p = (uint16_t*)g.Cv + (bh * 64 + d0 + r16 * 4) * g.qkv_npad + t;
+                static_for<0, NI>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    float v[4];
+                    biased(ic, jc, v);
+                    if (m < g.M) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) p[(size_t)(i * 16 + r) * g.qkv_npad] = from_f32<T>(v[r]);
+                    }
+                });
+            }
+        });
     }
 }
 
@@ -373,7 +495,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 __device__ __forceinline__ void wait_lgkmcnt0() { __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14)); }
 
-template <typename T, typename CFG, bool CONV, bool RELU_IN, int TAG>
+template <typename T, typename CFG, bool CONV, bool RELU_IN, int EPI, int TAG>
 __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(const GemmArgs g) {
     constexpr int BM = CFG::BM, BN = CFG::BN, NS = CFG::NS, NW = CFG::NW;
     constexpr int WM = CFG::WM, WN = CFG::WN, MI = CFG::MI, NI = CFG::NI;
@@ -445,9 +567,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
     // issue the loads of K-step (itile, ikt) into LDS stage istage, then advance.  After the last
     // tile the same tile is re-issued (never consumed): every K-step issues exactly SPW loads per
     // wave, so the counted vmcnt below stays exact.
-    auto issue_next = [&]() {
-        char* sa = smem + istage * STAGE;
-        char* sw = sa + A_BYTES;
+    // source bases of the K-step the load cursor points at (wave-uniform)
+    auto load_bases = [&](const char*& abase, const char*& wbase) {
         int koff_a;
         if (CONV) {
             const int tap = ikt / cpt, ci0 = (ikt - tap * cpt) << 6;
@@ -456,12 +577,22 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
         } else {
             koff_a = ikt << 6;
         }
-        const char* abase = reinterpret_cast<const char*>(g.A + koff_a);       // wave-uniform
-        const char* wbase = reinterpret_cast<const char*>(g.W + (ikt << 6));
-#pragma unroll
-        for (int s = 0; s < A_SPW; ++s) glds_slab_off(abase, a_off[s], sa + (s * NW + w) * 1024);
-#pragma unroll
-        for (int s = 0; s < W_SPW; ++s) glds_slab_off(wbase, w_off[s], sw + (s * NW + w) * 1024);
+        abase = reinterpret_cast<const char*>(g.A + koff_a);
+        wbase = reinterpret_cast<const char*>(g.W + (ikt << 6));
+    };
+    // the q-th of this wave's SPW direct-to-LDS loads of that K-step (A slabs first, then W slabs)
+    auto issue_one = [&](auto qc, const char* abase, const char* wbase) {
+        constexpr int q = decltype(qc)::value;
+        char* sa = smem + istage * STAGE;
+        if constexpr (q < A_SPW) glds_slab_off(abase, a_off[q], sa + (q * NW + w) * 1024);
+        else glds_slab_off(wbase, w_off[q - A_SPW], sa + A_BYTES + ((q - A_SPW) * NW + w) * 1024);
+    };
+    auto issue_loads = [&]() {
+        const char *abase, *wbase;
+        load_bases(abase, wbase);
+        static_for<0, CFG::SPW>([&](auto qc) { issue_one(qc, abase, wbase); });
+    };
+    auto issue_advance = [&]() {           // move the load cursor to the next K-step (may cross a tile)
         istage = istage + 1 == NS ? 0 : istage + 1;
         if (++ikt == nk) {
             ikt = 0;
@@ -469,6 +600,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
             setup(itile);
         }
     };
+    auto issue_next = [&]() { issue_loads(); issue_advance(); };
 
     // ---- MFMA side ---------------------------------------------------------------------------------
     f32x4_t acc[NI][MI];
@@ -477,49 +609,75 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
     const int foff0 = tile_off(frow, lane >> 4), foff1 = tile_off(frow, 4 + (lane >> 4));
     const int wbase_off = A_BYTES + wn * WN * 128, abase_off = wm * WM * 128;
 
+    // One K-step: the DMA issues of the NEXT K-step ride between the MFMAs of this one.  Measured
+    // (tools/gemm_phase_probe.py) a wave spent ~500 cycles per K-step just issuing its 8
+    // global_load_lds (~60 cycles each) before its first MFMA; placed one per 4 MFMAs they issue in
+    // the matrix pipe's shadow.
     auto compute = [&](int stage) {
         const char* st = smem + stage * STAGE;
+        const char *abase, *wbase;
+        load_bases(abase, wbase);
         i32x4_t wf0[NI], af0[MI], wf1[NI], af1[MI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) wf0[i] = *reinterpret_cast<const i32x4_t*>(st + wbase_off + i * 2048 + foff0);
 #pragma unroll
-        for (int j = 0; j < MI; ++j) af0[j] = *reinterpret_cast<const i32x4_t*>(st + abase_off + j * 2048 + foff0);
-#pragma unroll
-        for (int i = 0; i < NI; ++i) wf1[i] = *reinterpret_cast<const i32x4_t*>(st + wbase_off + i * 2048 + foff1);
-#pragma unroll
-        for (int j = 0; j < MI; ++j) af1[j] = *reinterpret_cast<const i32x4_t*>(st + abase_off + j * 2048 + foff1);
-        if (RELU_IN) {
-#pragma unroll
-            for (int j = 0; j < MI; ++j) { af0[j] = relu_frag(af0[j]); af1[j] = relu_frag(af1[j]); }
+        for (int j = 0; j < MI; ++j) {
+            af0[j] = *reinterpret_cast<const i32x4_t*>(st + abase_off + j * 2048 + foff0);
+            if (RELU_IN) af0[j] = relu_frag(af0[j]);
         }
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
+        __builtin_amdgcn_sched_barrier(0);
+        // pinned order, one group per W fragment: {MI MFMAs ; the matching ks=1 fragment reads ; one or two
+        // DMA issues}.  The groups are fenced so the 8 loads are spread over the 32 MFMAs.
+        // all DMA issues go into the FIRST k-half (one per ~2 MFMAs) so they have the second half of the
+        // K-step plus the barrier to land (2-stage ring: they are waited for at the top of the next step)
+        constexpr int LPG = (CFG::SPW + NI - 1) / NI;                    // DMA issues per group
+        static_for<0, NI>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
 #pragma unroll
             for (int j = 0; j < MI; ++j) acc[i][j] = mfma16<T>(wf0[i], af0[j], acc[i][j]);
+            wf1[i] = *reinterpret_cast<const i32x4_t*>(st + wbase_off + i * 2048 + foff1);
+            if constexpr (i < MI) {
+                af1[i] = *reinterpret_cast<const i32x4_t*>(st + abase_off + i * 2048 + foff1);
+                if (RELU_IN) af1[i] = relu_frag(af1[i]);
+            }
+            static_for<0, LPG>([&](auto lc) {
+                constexpr int q = i * LPG + decltype(lc)::value;
+                if constexpr (q < CFG::SPW) issue_one(std::integral_constant<int, q>{}, abase, wbase);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if constexpr (MI > NI) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
+            for (int j = NI; j < MI; ++j) {
+                af1[j] = *reinterpret_cast<const i32x4_t*>(st + abase_off + j * 2048 + foff1);
+                if (RELU_IN) af1[j] = relu_frag(af1[j]);
+            }
+        }
+        static_for<0, NI>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
 #pragma unroll
             for (int j = 0; j < MI; ++j) acc[i][j] = mfma16<T>(wf1[i], af1[j], acc[i][j]);
-        // schedule: the ks=0 fragments first, then the ks=1 fragment reads ride under the ks=0
-        // MFMAs (one exposed LDS latency per K-step instead of one per fragment)
-        __builtin_amdgcn_sched_group_barrier(0x100, NI + MI, 0);              // DS reads (ks=0)
-#pragma unroll
-        for (int q = 0; q < (NI + MI) / 2; ++q) {
-            __builtin_amdgcn_sched_group_barrier(0x008, (NI * MI) / ((NI + MI) / 2), 0);   // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                // DS reads (ks=1)
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, NI * MI, 0);              // MFMA (ks=1)
+            __builtin_amdgcn_sched_barrier(0);
+        });
     };
 
 #pragma unroll
     for (int p = 0; p < NS - 1; ++p) issue_next();          // prologue: NS-1 K-steps in flight
     int cstage = 0;
     int prev = -1;                                           // tile whose results still sit in acc[][]
+    int pm0 = 0, pn0 = 0;                                    // ... and its origin
+    float4 biasv[EPI != EPI_GENERIC ? NI : 1];
+    unsigned long long tmark[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // dbg==3: cycles in {vm wait, barrier, epilogue, compute k>=1, t2 mark, first compute, vm wait kt==1}
+    unsigned long long kc0 = 0, kr0 = 0;             // dbg==3: whole-kernel s_memtime / s_memrealtime (100 MHz)
+    if ((g.dbg & 4)) { kc0 = __builtin_readcyclecounter(); kr0 = __builtin_amdgcn_s_memrealtime(); }
     auto k_step = [&]() {
         // (NS-1)*SPW loads are in flight; the oldest SPW (this K-step's stage) must have landed
+        unsigned long long t0 = 0, t1 = 0, t2 = 0;
+        if ((g.dbg & 4)) t0 = __builtin_readcyclecounter();
         wait_vmcnt<(NS - 2) * CFG::SPW>();
+        if ((g.dbg & 4)) t1 = __builtin_readcyclecounter();
         __builtin_amdgcn_s_barrier();        // everyone's have; everyone finished the stage refilled next
-        issue_next();
+        if ((g.dbg & 4)) { t2 = __builtin_readcyclecounter(); tmark[0] += t1 - t0; tmark[1] += t2 - t1; tmark[4] = t2; }
     };
     while (true) {
         // The epilogue of tile t runs INSIDE tile t+1's first K-step, after that step's wait/barrier
@@ -527,10 +685,10 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
         // under the first MFMA block instead of being waited for (vmcnt counts stores) before it.
         const bool have = tile < tile_end;
         if (have) k_step();
+        unsigned long long te0 = 0;
+        if ((g.dbg & 4)) te0 = __builtin_readcyclecounter();
         if (prev >= 0) {
-            int mbc, nbc;
-            tile_coords(prev, tiles_m, tiles_n, mbc, nbc);
-            const int m0c = mbc * BM, n0c = nbc * BN;
+            const int m0c = pm0, n0c = pn0;
             if constexpr (CFG::BN == 512) {
                 // ---- fused head (lseg_net.py:185-194): v = head1(x)+bias ; a = fp16(s * fp16(v/||v||)) ----
                 // lane owns, for each of its MI rows, NI groups of 4 columns inside this wave's 128
@@ -581,6 +739,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
                                 make_uint4(s0[0], s1[0], s0[1], s1[1]);
                     });
                 });
+            } else if constexpr (EPI != EPI_GENERIC) {
+                fast_epilogue<T, EPI, MI, NI>(g, acc, m0c + wm * WM, n0c + wn * WN, lane, biasv);
             } else {
             int ncol[NI];
             ColPart cp[NI], cpw[NI / 2];
@@ -599,30 +759,59 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
                     }
                 });
                 const int m = m0c + wm * WM + j * 16 + (lane & 15);
-                if (g.dbg == 2) { asm volatile("" ::"v"(row[0][0]), "v"(row[NI - 1][3])); continue; }
+                if ((g.dbg & 3) == 2) { asm volatile("" ::"v"(row[0][0]), "v"(row[NI - 1][3])); continue; }
                 if (m < g.M) epilogue_row<T, NI>(g, m, ncol, cp, cpw, wide, bias, row);
             }
             }
             if (NS > 2) wait_vmcnt<0>();     // see the ping-pong kernel: keeps stray vmcnt(0) out of the K-loop
         }
         if (!have) break;
+        {   // this tile's origin (its epilogue runs one iteration later) and, for the specialised
+            // epilogues, its bias: loaded now, consumed after the K-loop
+            int mbc, nbc;
+            tile_coords(tile, tiles_m, tiles_n, mbc, nbc);
+            pm0 = mbc * BM; pn0 = nbc * BN;
+            if constexpr (EPI != EPI_GENERIC) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    biasv[i] = *reinterpret_cast<const float4*>(g.bias + pn0 + wn * WN + i * 16 + (lane >> 4) * 4);
+            }
+        }
+        unsigned long long te1 = 0;
+        if ((g.dbg & 4)) { te1 = __builtin_readcyclecounter(); tmark[2] += te1 - te0; }
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < MI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         compute(cstage);
+        if ((g.dbg & 4)) tmark[5] += __builtin_readcyclecounter() - te1;
+        issue_advance();
         cstage = cstage + 1 == NS ? 0 : cstage + 1;
         for (int kt = 1; kt < nk; ++kt) {
+            if ((g.dbg & 4) && kt == 1) {
+                const unsigned long long v0 = tmark[0];
+                k_step();
+                tmark[6] += tmark[0] - v0;
+            } else
             k_step();
             compute(cstage);
+            if ((g.dbg & 4)) tmark[3] += __builtin_readcyclecounter() - tmark[4];
+            issue_advance();
             cstage = cstage + 1 == NS ? 0 : cstage + 1;
         }
         prev = tile;
         tile += wpx;
     }
+    if ((g.dbg & 4) && lane == 0 && g.res2) {
+        unsigned long long* o = (unsigned long long*)g.res2 + ((size_t)blockIdx.x * NW + w) * 8;
+        o[0] = tmark[0]; o[1] = tmark[1]; o[2] = tmark[2]; o[3] = tmark[3]; o[4] = tmark[5]; o[5] = tmark[6];
+        o[6] = __builtin_readcyclecounter() - kc0;              // whole kernel, shader cycles
+        o[7] = __builtin_amdgcn_s_memrealtime() - kr0;          // whole kernel, 100 MHz ticks
+    }
     wait_vmcnt<0>();     // drain the never-consumed tail loads before the LDS is released
 }
 
+#ifdef LSEG_GEMM_EXPERIMENTAL   // kept for reference: slower than CfgMid at every ViT shape
 // ================================================================================================
 // "Ping-pong" kernel for large problems: 256x128 tile, 8 waves, 3-stage LDS ring (144 KB, one
 // workgroup per CU).  The workgroup is two 4-wave groups (G0 = waves 0-3 -> tile rows 0-127,
@@ -859,7 +1048,9 @@ int launch_pp(const GemmArgs& g, hipStream_t stream) {
     return 0;
 }
 
-template <typename T, typename CFG, bool CONV, bool RELU_IN, int TAG>
+#endif  // LSEG_GEMM_EXPERIMENTAL
+
+template <typename T, typename CFG, bool CONV, bool RELU_IN, int EPI, int TAG>
 int launch_one(const GemmArgs& g, hipStream_t stream) {
     const int tiles = ((g.M + CFG::BM - 1) / CFG::BM) * ((g.N + CFG::BN - 1) / CFG::BN);
     const size_t lds = CFG::LDS + (CFG::BN == 512 ? 1024 : 0);
@@ -869,7 +1060,7 @@ int launch_one(const GemmArgs& g, hipStream_t stream) {
     const int slots = 256 * per_cu;
     int grid = ((tiles + 7) / 8) * 8;
     if (grid > slots) grid = slots;
-    auto kern = lseg_gemm_kernel<T, CFG, CONV, RELU_IN, TAG>;
+    auto kern = lseg_gemm_kernel<T, CFG, CONV, RELU_IN, EPI, TAG>;
     static bool attr_done = false;
     if (!attr_done) {
         LSEG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -881,34 +1072,63 @@ int launch_one(const GemmArgs& g, hipStream_t stream) {
     return 0;
 }
 
-template <typename T, bool CONV, bool RELU_IN, int TAG>
+template <typename T, bool CONV, bool RELU_IN, int EPI, int TAG>
 int pick_tile(const GemmArgs& g, hipStream_t stream) {
-    const long t_big = (long)((g.M + 255) / 256) * ((g.N + 127) / 128);
     const long t_mid = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    static const int force = getenv("LSEG_GEMM_TILE") ? atoi(getenv("LSEG_GEMM_TILE")) : 0;   // 1 small 2 mid 3 big
-    if (g.map_mode == MAP_ROWNORM) {
-        if (CONV || RELU_IN || g.N != 512 || !g.bias)
-            return set_error(LSEG_ERR_UNSUPPORTED, "fused head needs a plain GEMM with N == 512 and a bias");
-        return launch_one<T, CfgRow, false, false, 0>(g, stream);
-    }
-    int pick = t_mid >= 192 ? 2 : 1;       // 3 = 256x128/8 waves/3 stages (lock-step), 4 = ping-pong
-    (void)t_big;
+    static const int force = getenv("LSEG_GEMM_TILE") ? atoi(getenv("LSEG_GEMM_TILE")) : 0;   // 1 small 2 mid (3 big 4 ping-pong)
+    int pick = t_mid >= 192 ? 2 : 1;
     if (force) pick = force;
+#ifdef LSEG_GEMM_EXPERIMENTAL
     if (pick == 4) return launch_pp<T, CONV, RELU_IN, TAG>(g, stream);
-    if (pick == 3) return launch_one<T, CfgBig, CONV, RELU_IN, TAG>(g, stream);
-    if (pick == 2) return launch_one<T, CfgMid, CONV, RELU_IN, TAG>(g, stream);
-    return launch_one<T, CfgSmall, CONV, RELU_IN, TAG>(g, stream);
+    if (pick == 3) return launch_one<T, CfgBig, CONV, RELU_IN, EPI, TAG>(g, stream);
+#endif
+    if (pick == 2) return launch_one<T, CfgMid, CONV, RELU_IN, EPI, TAG>(g, stream);
+    return launch_one<T, CfgSmall, CONV, RELU_IN, EPI, TAG>(g, stream);
+}
+
+// Which specialised epilogue (if any) reproduces this launch exactly.
+template <typename T>
+int select_epi(const GemmArgs& g) {
+    constexpr int dt = std::is_same<T, BF16>::value ? DT_BF16 : DT_F16;
+    static const bool off = getenv("LSEG_GEMM_GENERIC_EPI") != nullptr;       // A/B switch (tools)
+    if (off || (g.dbg & 3) || !g.bias || g.bias_mod || g.round_mid || (g.res2 && !(g.dbg & 4)) || (g.N % 128) != 0) return EPI_GENERIC;
+    if ((reinterpret_cast<uintptr_t>(g.C) & 15) || (reinterpret_cast<uintptr_t>(g.bias) & 15)) return EPI_GENERIC;
+    if (g.map_mode == MAP_LINEAR && g.res_mode == RES_NONE && g.out_dtype == dt && (g.ldc % 8) == 0) {
+        if (g.act == ACT_NONE) return EPI_LIN16;
+        if (g.act == ACT_GELU) return EPI_LIN16_GELU;
+        return EPI_GENERIC;
+    }
+    if (g.map_mode == MAP_LINEAR && g.res_mode == RES_DEST && g.out_dtype == DT_F32 && g.res_dtype == DT_F32 &&
+        g.act == ACT_NONE && (g.ldc % 4) == 0 && !(reinterpret_cast<uintptr_t>(g.res) & 15))
+        return EPI_RES32;
+    if (g.map_mode == MAP_QKV && g.res_mode == RES_NONE && g.act == ACT_NONE && g.out_dtype == dt &&
+        (g.qkv_dim % 64) == 0 && g.qkv_dim == g.qkv_heads * 64 &&
+        !((reinterpret_cast<uintptr_t>(g.Ck) | reinterpret_cast<uintptr_t>(g.Cv)) & 15))
+        return EPI_QKV16;
+    return EPI_GENERIC;
 }
 
 template <typename T>
 int dispatch(const GemmArgs& g, hipStream_t stream) {
+    if (g.map_mode == MAP_ROWNORM) {
+        if (g.conv || g.relu_in || g.N != 512 || !g.bias)
+            return set_error(LSEG_ERR_UNSUPPORTED, "fused head needs a plain GEMM with N == 512 and a bias");
+        return launch_one<T, CfgRow, false, false, EPI_GENERIC, 0>(g, stream);
+    }
     if (g.conv) {
-        if (g.relu_in) return pick_tile<T, true, true, 0>(g, stream);
-        return pick_tile<T, true, false, 0>(g, stream);
+        if (g.relu_in) return pick_tile<T, true, true, EPI_GENERIC, 0>(g, stream);
+        return pick_tile<T, true, false, EPI_GENERIC, 0>(g, stream);
     }
     if (g.relu_in) return set_error(LSEG_ERR_UNSUPPORTED, "gemm: relu_in is only implemented for the conv path");
-    if (g.tag == 1) return pick_tile<T, false, false, 1>(g, stream);
-    return pick_tile<T, false, false, 0>(g, stream);
+    switch (select_epi<T>(g)) {
+        case EPI_LIN16: return pick_tile<T, false, false, EPI_LIN16, 0>(g, stream);
+        case EPI_LIN16_GELU:
+            if (g.tag == 1) return pick_tile<T, false, false, EPI_LIN16_GELU, 1>(g, stream);
+            return pick_tile<T, false, false, EPI_LIN16_GELU, 0>(g, stream);
+        case EPI_RES32: return pick_tile<T, false, false, EPI_RES32, 0>(g, stream);
+        case EPI_QKV16: return pick_tile<T, false, false, EPI_QKV16, 0>(g, stream);
+        default: return pick_tile<T, false, false, EPI_GENERIC, 0>(g, stream);
+    }
 }
 
 }  // namespace
