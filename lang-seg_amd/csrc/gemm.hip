@@ -386,26 +386,30 @@ __device__ __forceinline__ void fast_epilogue(const GemmArgs& g, f32x4_t (&acc)[
         // every residual load of the sub-tile is in flight before the first store (in place: x += f(x))
         float* cbase = (float*)g.C + ncol0 + r16 * 4;
         const float* rbase = (const float*)g.res + ncol0 + r16 * 4;
-        float4 rv[MI][NI];
-        static_for<0, MI>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            int m = mrow0 + j * 16 + ml;
-            if (m > g.M - 1) m = g.M - 1;
-            const float* rp = rbase + (size_t)m * g.ldc;
+        constexpr int JC = (16 / NI) < 1 ? 1 : ((16 / NI) > MI ? MI : (16 / NI));      // rows per chunk: <= 64 registers of prefetched residual
+        static_for<0, MI / JC>([&](auto cc) {
+            constexpr int jb = decltype(cc)::value * JC;
+            float4 rv[JC][NI];
+            static_for<0, JC>([&](auto jc) {
+                constexpr int j = jb + decltype(jc)::value;
+                int m = mrow0 + j * 16 + ml;
+                if (m > g.M - 1) m = g.M - 1;
+                const float* rp = rbase + (size_t)m * g.ldc;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) rv[j][i] = *reinterpret_cast<const float4*>(rp + i * 16);
-        });
-        static_for<0, MI>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            const int m = mrow0 + j * 16 + ml;
-            float* p = cbase + (size_t)m * g.ldc;
-            static_for<0, NI>([&](auto ic) {
-                constexpr int i = decltype(ic)::value;
-                float v[4];
-                biased(ic, jc, v);
-                if (m < g.M)
-                    *reinterpret_cast<float4*>(p + i * 16) =
-                        make_float4(v[0] + rv[j][i].x, v[1] + rv[j][i].y, v[2] + rv[j][i].z, v[3] + rv[j][i].w);
+                for (int i = 0; i < NI; ++i) rv[decltype(jc)::value][i] = *reinterpret_cast<const float4*>(rp + i * 16);
+            });
+            static_for<0, JC>([&](auto jc) {
+                constexpr int jl = decltype(jc)::value, j = jb + jl;
+                const int m = mrow0 + j * 16 + ml;
+                float* p = cbase + (size_t)m * g.ldc;
+                static_for<0, NI>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    float v[4];
+                    biased(ic, std::integral_constant<int, j>{}, v);
+                    if (m < g.M)
+                        *reinterpret_cast<float4*>(p + i * 16) =
+                            make_float4(v[0] + rv[jl][i].x, v[1] + rv[jl][i].y, v[2] + rv[jl][i].z, v[3] + rv[jl][i].w);
+                });
             });
         });
     } else if constexpr (EPI == EPI_QKV16) {
@@ -461,11 +465,17 @@ struct TileCfg {
     static constexpr int A_SPW = BM / 8 / NW, W_SPW = BN / 8 / NW;   // 8-row slabs per wave per stage
     static constexpr int SPW = A_SPW + W_SPW;
     static constexpr int LDS = NS * STAGE;
+    // DMA issues of one K-step: Q_B2 ride in the second half of the k-half-1 MFMA block of the previous
+    // step, Q_A in the k-half-0 block of the step before they are consumed.  128-accumulator tiles
+    // (a K-step is 2000+ cycles) issue everything early; the small-tile configs need the spread, their
+    // waves stall ~60 cycles per global_load_lds when two workgroups share the CU's address path.
+    static constexpr int Q_A = (BM * BN >= 65536) ? 0 : (SPW * NI) / (NI + (NI - NI / 2));
+    static constexpr int Q_B2 = SPW - Q_A;
     static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "slabs must divide evenly over the waves");
 };
-using CfgBig = TileCfg<256, 128, 4, 2, 3>;
 using CfgMid = TileCfg<128, 128, 2, 2, 2>;
 using CfgSmall = TileCfg<64, 64, 2, 2, 2>;
+using CfgHuge = TileCfg<256, 256, 4, 2, 2, 1>;     // 8 waves, 64x128 per wave, 128 KB LDS: half the L1/TA load per MFMA of Mid
 // Row config: one workgroup owns complete 512-wide output rows (fused head1 + L2-norm + fp16 casts);
 // 128 accumulator registers per lane -> one wave per SIMD, 144 KB LDS + 1 KB reduction scratch
 using CfgRow = TileCfg<64, 512, 1, 4, 2, 1>;
@@ -602,209 +612,241 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
     };
     auto issue_next = [&]() { issue_loads(); issue_advance(); };
 
-    // ---- MFMA side ---------------------------------------------------------------------------------
+    // ---- MFMA side: software-pipelined K-loop ---------------------------------------------------------
+    // One workgroup barrier per K-step, in the MIDDLE of the k-half-1 MFMA block:
+    //   block A   k-half-0 MFMAs of step k        | reads the k-half-1 fragments of stage k%2
+    //   block B1  first half of the k-half-1 MFMAs
+    //   vmcnt(0) ; s_barrier       -> every wave's DMA of step k+1 has landed, every wave is done reading stage k%2
+    //   block B2  rest of the k-half-1 MFMAs      | reads the k-half-0 fragments of step k+1 (other stage)
+    //                                             | issues the DMA of step k+2 into stage k%2
+    // so the wave always leaves the barrier with 8+ MFMAs of fragments in registers (no post-barrier
+    // LDS ramp: that ramp plus barrier skew idled the matrix pipe ~25% of every K-step in the
+    // barrier-at-the-top loop, tools/gemm_phase_probe.py), and a DMA has a full K-step to land.
+    static_assert(NS == 2, "the pipelined loop alternates two LDS stages");
     f32x4_t acc[NI][MI];
+    i32x4_t wf0[NI], af0[MI], wf1[NI], af1[MI];
     // LDS fragment byte offsets of this lane (ks = 0 / 1); sub-tiles add i*2048 / j*2048
     const int frow = lane & 15;
     const int foff0 = tile_off(frow, lane >> 4), foff1 = tile_off(frow, 4 + (lane >> 4));
     const int wbase_off = A_BYTES + wn * WN * 128, abase_off = wm * WM * 128;
+#ifdef GEMM_ABL_NOREAD      // ablation builds (tools/): K-loop without LDS fragment reads / DMA issues / MFMAs
+    auto ldfrag = [&](const char* p) { return i32x4_t{lane, lane, lane, lane}; };
+#else
+    auto ldfrag = [&](const char* p) { return *reinterpret_cast<const i32x4_t*>(p); };
+#endif
+#ifdef GEMM_ABL_NOMFMA
+    auto mm = [&](i32x4_t a, i32x4_t b, f32x4_t c) { asm volatile("" ::"v"(a), "v"(b)); return c; };
+#else
+    auto mm = [&](i32x4_t a, i32x4_t b, f32x4_t c) { return mfma16<T>(a, b, c); };
+#endif
+    auto lda = [&](const char* st, int j, int foff) {
+        i32x4_t v = ldfrag(st + abase_off + j * 2048 + foff);
+        if (RELU_IN) v = relu_frag(v);
+        return v;
+    };
 
-    // One K-step: the DMA issues of the NEXT K-step ride between the MFMAs of this one.  Measured
-    // (tools/gemm_phase_probe.py) a wave spent ~500 cycles per K-step just issuing its 8
-    // global_load_lds (~60 cycles each) before its first MFMA; placed one per 4 MFMAs they issue in
-    // the matrix pipe's shadow.
-    auto compute = [&](int stage) {
-        const char* st = smem + stage * STAGE;
+    unsigned long long tmark[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // dbg&4: cycles in {vm wait, barrier, epilogue, MFMA blocks}
+    unsigned long long kc0 = 0, kr0 = 0;                       // dbg&4: whole-kernel s_memtime / s_memrealtime (100 MHz)
+    if ((g.dbg & 4)) { kc0 = __builtin_readcyclecounter(); kr0 = __builtin_amdgcn_s_memrealtime(); }
+
+    int cstage = 0;
+    auto step = [&]() {
+        const char* st = smem + cstage * STAGE;
+        const char* nx = smem + (cstage ^ 1) * STAGE;
+        unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+        if ((g.dbg & 4)) t0 = __builtin_readcyclecounter();
         const char *abase, *wbase;
         load_bases(abase, wbase);
-        i32x4_t wf0[NI], af0[MI], wf1[NI], af1[MI];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) wf0[i] = *reinterpret_cast<const i32x4_t*>(st + wbase_off + i * 2048 + foff0);
-#pragma unroll
-        for (int j = 0; j < MI; ++j) {
-            af0[j] = *reinterpret_cast<const i32x4_t*>(st + abase_off + j * 2048 + foff0);
-            if (RELU_IN) af0[j] = relu_frag(af0[j]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // pinned order, one group per W fragment: {MI MFMAs ; the matching ks=1 fragment reads ; one or two
-        // DMA issues}.  The groups are fenced so the 8 loads are spread over the 32 MFMAs.
-        // all DMA issues go into the FIRST k-half (one per ~2 MFMAs) so they have the second half of the
-        // K-step plus the barrier to land (2-stage ring: they are waited for at the top of the next step)
-        constexpr int LPG = (CFG::SPW + NI - 1) / NI;                    // DMA issues per group
+        constexpr int LPA = (CFG::Q_A + NI - 1) / NI;                    // DMA issues per block-A group
+        // ---- block A
         static_for<0, NI>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
 #pragma unroll
-            for (int j = 0; j < MI; ++j) acc[i][j] = mfma16<T>(wf0[i], af0[j], acc[i][j]);
-            wf1[i] = *reinterpret_cast<const i32x4_t*>(st + wbase_off + i * 2048 + foff1);
-            if constexpr (i < MI) {
-                af1[i] = *reinterpret_cast<const i32x4_t*>(st + abase_off + i * 2048 + foff1);
-                if (RELU_IN) af1[i] = relu_frag(af1[i]);
-            }
-            static_for<0, LPG>([&](auto lc) {
-                constexpr int q = i * LPG + decltype(lc)::value;
+            for (int j = 0; j < MI; ++j) acc[i][j] = mm(wf0[i], af0[j], acc[i][j]);
+            wf1[i] = ldfrag(st + wbase_off + i * 2048 + foff1);
+            if constexpr (i < MI) af1[i] = lda(st, i, foff1);
+#ifndef GEMM_ABL_NODMA
+            static_for<0, LPA>([&](auto lc) {
+                constexpr int q = CFG::Q_B2 + i * LPA + decltype(lc)::value;
                 if constexpr (q < CFG::SPW) issue_one(std::integral_constant<int, q>{}, abase, wbase);
+            });
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        issue_advance();                 // the load cursor now points at step k+2
+        if constexpr (MI > NI) {
+#pragma unroll
+            for (int j = NI; j < MI; ++j) af1[j] = lda(st, j, foff1);
+        }
+        // ---- block B1
+        static_for<0, NI / 2>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+#pragma unroll
+            for (int j = 0; j < MI; ++j) acc[i][j] = mm(wf1[i], af1[j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if ((g.dbg & 4)) t1 = __builtin_readcyclecounter();
+        wait_lgkmcnt0();                 // this wave's reads of stage k%2 are complete ...
+        wait_vmcnt<0>();                 // ... and its share of step k+1 has landed (also: epilogue stores acknowledged)
+        if ((g.dbg & 4)) t2 = __builtin_readcyclecounter();
+        __builtin_amdgcn_s_barrier();
+        if ((g.dbg & 4)) t3 = __builtin_readcyclecounter();
+        // ---- block B2
+        load_bases(abase, wbase);
+        constexpr int G = NI - NI / 2;                                   // MFMA groups in this block
+        constexpr int RPG = (NI + MI + G - 1) / G;                       // next-step fragment reads per group
+        constexpr int LPG = (CFG::Q_B2 + G - 1) / G;                     // DMA issues per group
+        static_for<0, G>([&](auto gc) {
+            constexpr int gi = decltype(gc)::value, i = NI / 2 + gi;
+#pragma unroll
+            for (int j = 0; j < MI; ++j) acc[i][j] = mm(wf1[i], af1[j], acc[i][j]);
+            static_for<0, RPG>([&](auto rc) {
+                constexpr int r = gi * RPG + decltype(rc)::value;
+                if constexpr (r < NI) wf0[r] = ldfrag(nx + wbase_off + r * 2048 + foff0);
+                else if constexpr (r < NI + MI) af0[r - NI] = lda(nx, r - NI, foff0);
+            });
+            static_for<0, LPG>([&](auto lc) {
+                constexpr int q = gi * LPG + decltype(lc)::value;
+#ifndef GEMM_ABL_NODMA
+                if constexpr (q < CFG::Q_B2) issue_one(std::integral_constant<int, q>{}, abase, wbase);
+#endif
             });
             __builtin_amdgcn_sched_barrier(0);
         });
-        if constexpr (MI > NI) {
-#pragma unroll
-            for (int j = NI; j < MI; ++j) {
-                af1[j] = *reinterpret_cast<const i32x4_t*>(st + abase_off + j * 2048 + foff1);
-                if (RELU_IN) af1[j] = relu_frag(af1[j]);
-            }
+        cstage ^= 1;
+        if ((g.dbg & 4)) {
+            const unsigned long long t4 = __builtin_readcyclecounter();
+            tmark[0] += t2 - t1; tmark[1] += t3 - t2; tmark[3] += (t1 - t0) + (t4 - t3);
         }
-        static_for<0, NI>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-#pragma unroll
-            for (int j = 0; j < MI; ++j) acc[i][j] = mfma16<T>(wf1[i], af1[j], acc[i][j]);
-            __builtin_amdgcn_sched_barrier(0);
-        });
     };
 
+    // prologue: step 0 landed and its k-half-0 fragments in registers, step 1 in flight
+    issue_next();
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    {
+        const char* st = smem;
 #pragma unroll
-    for (int p = 0; p < NS - 1; ++p) issue_next();          // prologue: NS-1 K-steps in flight
-    int cstage = 0;
-    int prev = -1;                                           // tile whose results still sit in acc[][]
-    int pm0 = 0, pn0 = 0;                                    // ... and its origin
+        for (int i = 0; i < NI; ++i) wf0[i] = ldfrag(st + wbase_off + i * 2048 + foff0);
+#pragma unroll
+        for (int j = 0; j < MI; ++j) af0[j] = lda(st, j, foff0);
+    }
+    {   // the early part of step 1's loads; block A of step 0 issues the rest
+        const char *abase, *wbase;
+        load_bases(abase, wbase);
+        static_for<0, CFG::Q_B2>([&](auto qc) { issue_one(qc, abase, wbase); });
+    }
+
+    constexpr bool BIAS_PREFETCH = MI * NI <= 16;
     float4 biasv[EPI != EPI_GENERIC ? NI : 1];
-    unsigned long long tmark[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // dbg==3: cycles in {vm wait, barrier, epilogue, compute k>=1, t2 mark, first compute, vm wait kt==1}
-    unsigned long long kc0 = 0, kr0 = 0;             // dbg==3: whole-kernel s_memtime / s_memrealtime (100 MHz)
-    if ((g.dbg & 4)) { kc0 = __builtin_readcyclecounter(); kr0 = __builtin_amdgcn_s_memrealtime(); }
-    auto k_step = [&]() {
-        // (NS-1)*SPW loads are in flight; the oldest SPW (this K-step's stage) must have landed
-        unsigned long long t0 = 0, t1 = 0, t2 = 0;
-        if ((g.dbg & 4)) t0 = __builtin_readcyclecounter();
-        wait_vmcnt<(NS - 2) * CFG::SPW>();
-        if ((g.dbg & 4)) t1 = __builtin_readcyclecounter();
-        __builtin_amdgcn_s_barrier();        // everyone's have; everyone finished the stage refilled next
-        if ((g.dbg & 4)) { t2 = __builtin_readcyclecounter(); tmark[0] += t1 - t0; tmark[1] += t2 - t1; tmark[4] = t2; }
-    };
-    while (true) {
-        // The epilogue of tile t runs INSIDE tile t+1's first K-step, after that step's wait/barrier
-        // and after the following K-step's loads have been issued: its stores are then acknowledged
-        // under the first MFMA block instead of being waited for (vmcnt counts stores) before it.
-        const bool have = tile < tile_end;
-        if (have) k_step();
-        unsigned long long te0 = 0;
-        if ((g.dbg & 4)) te0 = __builtin_readcyclecounter();
-        if (prev >= 0) {
-            const int m0c = pm0, n0c = pn0;
-            if constexpr (CFG::BN == 512) {
-                // ---- fused head (lseg_net.py:185-194): v = head1(x)+bias ; a = fp16(s * fp16(v/||v||)) ----
-                // lane owns, for each of its MI rows, NI groups of 4 columns inside this wave's 128
-                // columns; the row's sum of squares is reduced over the 4 lane groups (shuffles) and
-                // over the 4 waves (LDS scratch behind the stage ring), in a fixed order.
-                float* red = reinterpret_cast<float*>(smem + NS * STAGE);      // [4 waves][64 rows]
-                const int n_first = n0c + wn * WN + (lane >> 4) * 4;
-                float ssq[MI];
-                static_for<0, MI>([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    float s_ = 0.f;
-                    static_for<0, NI>([&](auto ic) {
-                        constexpr int i = decltype(ic)::value;
-                        const float4 bv = *reinterpret_cast<const float4*>(g.bias + n_first + i * 16);
-                        acc[i][j][0] += bv.x; acc[i][j][1] += bv.y; acc[i][j][2] += bv.z; acc[i][j][3] += bv.w;
-                        s_ += acc[i][j][0] * acc[i][j][0] + acc[i][j][1] * acc[i][j][1] +
-                              acc[i][j][2] * acc[i][j][2] + acc[i][j][3] * acc[i][j][3];
-                    });
-                    s_ += __shfl_xor(s_, 16);
-                    s_ += __shfl_xor(s_, 32);
-                    ssq[j] = s_;
-                });
-                if (lane < 16) {
-#pragma unroll
-                    for (int j = 0; j < MI; ++j) red[wn * 64 + j * 16 + lane] = ssq[j];
-                }
-                __syncthreads();
-                static_for<0, MI>([&](auto jc) {
-                    constexpr int j = decltype(jc)::value;
-                    const int rl = j * 16 + (lane & 15);
-                    const float nrm = sqrtf((red[rl] + red[64 + rl]) + (red[128 + rl] + red[192 + rl]));
-                    const int m = m0c + rl;
-                    const int r16 = lane >> 4;
-                    static_for<0, NI / 2>([&](auto pc) {
-                        constexpr int i = 2 * decltype(pc)::value;
-                        float y[2][4];
-#pragma unroll
-                        for (int q = 0; q < 2; ++q)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) y[q][r] = g.rn_scale * round_f16(acc[i + q][j][r] / nrm);
-                        const uint32_t a0 = pack2<F16>(y[0][0], y[0][1]), a1 = pack2<F16>(y[0][2], y[0][3]);
-                        const uint32_t b0 = pack2<F16>(y[1][0], y[1][1]), b1 = pack2<F16>(y[1][2], y[1][3]);
-                        const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
-                        const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
-                        const int col = n0c + wn * WN + i * 16 + (r16 & 1) * 16 + (r16 >> 1) * 8;
-                        if (m < g.M)
-                            *reinterpret_cast<uint4*>((uint16_t*)g.C + (size_t)m * g.ldc + col) =
-                                make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                    });
-                });
-            } else if constexpr (EPI != EPI_GENERIC) {
-                fast_epilogue<T, EPI, MI, NI>(g, acc, m0c + wm * WM, n0c + wn * WN, lane, biasv);
-            } else {
-            int ncol[NI];
-            ColPart cp[NI], cpw[NI / 2];
-            float4 bias[NI];
-            const bool wide = epilogue_cols<NI>(g, n0c + wn * WN + (lane >> 4) * 4, lane, ncol, cp, cpw, bias);
-            // runtime loop over the MI output rows of this lane (one copy of the epilogue code); the
-            // accumulator row is selected with static indices so acc[][] stays in registers
-#pragma unroll 1
-            for (int j = 0; j < MI; ++j) {
-                f32x4_t row[NI];
-                static_for<0, MI>([&](auto jc) {
-                    constexpr int js = decltype(jc)::value;
-                    if (j == js) {
-#pragma unroll
-                        for (int i = 0; i < NI; ++i) row[i] = acc[i][js];
-                    }
-                });
-                const int m = m0c + wm * WM + j * 16 + (lane & 15);
-                if ((g.dbg & 3) == 2) { asm volatile("" ::"v"(row[0][0]), "v"(row[NI - 1][3])); continue; }
-                if (m < g.M) epilogue_row<T, NI>(g, m, ncol, cp, cpw, wide, bias, row);
-            }
-            }
-            if (NS > 2) wait_vmcnt<0>();     // see the ping-pong kernel: keeps stray vmcnt(0) out of the K-loop
-        }
-        if (!have) break;
-        {   // this tile's origin (its epilogue runs one iteration later) and, for the specialised
-            // epilogues, its bias: loaded now, consumed after the K-loop
+    for (; tile < tile_end; tile += wpx) {
+        int pm0, pn0;
+        {   // this tile's origin and, for the specialised epilogues, its bias (consumed after the K-loop)
             int mbc, nbc;
             tile_coords(tile, tiles_m, tiles_n, mbc, nbc);
             pm0 = mbc * BM; pn0 = nbc * BN;
-            if constexpr (EPI != EPI_GENERIC) {
+            if constexpr (EPI != EPI_GENERIC && BIAS_PREFETCH) {
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
                     biasv[i] = *reinterpret_cast<const float4*>(g.bias + pn0 + wn * WN + i * 16 + (lane >> 4) * 4);
             }
         }
-        unsigned long long te1 = 0;
-        if ((g.dbg & 4)) { te1 = __builtin_readcyclecounter(); tmark[2] += te1 - te0; }
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < MI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        compute(cstage);
-        if ((g.dbg & 4)) tmark[5] += __builtin_readcyclecounter() - te1;
-        issue_advance();
-        cstage = cstage + 1 == NS ? 0 : cstage + 1;
-        for (int kt = 1; kt < nk; ++kt) {
-            if ((g.dbg & 4) && kt == 1) {
-                const unsigned long long v0 = tmark[0];
-                k_step();
-                tmark[6] += tmark[0] - v0;
-            } else
-            k_step();
-            compute(cstage);
-            if ((g.dbg & 4)) tmark[3] += __builtin_readcyclecounter() - tmark[4];
-            issue_advance();
-            cstage = cstage + 1 == NS ? 0 : cstage + 1;
+        for (int kt = 0; kt < nk; ++kt) step();
+        // ---- epilogue: the next tile's first K-step is already in flight / in registers
+        unsigned long long te0 = 0;
+        if ((g.dbg & 4)) te0 = __builtin_readcyclecounter();
+        {
+            const int m0c = pm0, n0c = pn0;
+
+        if constexpr (CFG::BN == 512) {
+            // ---- fused head (lseg_net.py:185-194): v = head1(x)+bias ; a = fp16(s * fp16(v/||v||)) ----
+            // lane owns, for each of its MI rows, NI groups of 4 columns inside this wave's 128
+            // columns; the row's sum of squares is reduced over the 4 lane groups (shuffles) and
+            // over the 4 waves (LDS scratch behind the stage ring), in a fixed order.
+            float* red = reinterpret_cast<float*>(smem + NS * STAGE);      // [4 waves][64 rows]
+            const int n_first = n0c + wn * WN + (lane >> 4) * 4;
+            float ssq[MI];
+            static_for<0, MI>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                float s_ = 0.f;
+                static_for<0, NI>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
+                    const float4 bv = *reinterpret_cast<const float4*>(g.bias + n_first + i * 16);
+                    acc[i][j][0] += bv.x; acc[i][j][1] += bv.y; acc[i][j][2] += bv.z; acc[i][j][3] += bv.w;
+                    s_ += acc[i][j][0] * acc[i][j][0] + acc[i][j][1] * acc[i][j][1] +
+                          acc[i][j][2] * acc[i][j][2] + acc[i][j][3] * acc[i][j][3];
+                });
+                s_ += __shfl_xor(s_, 16);
+                s_ += __shfl_xor(s_, 32);
+                ssq[j] = s_;
+            });
+            if (lane < 16) {
+#pragma unroll
+                for (int j = 0; j < MI; ++j) red[wn * 64 + j * 16 + lane] = ssq[j];
+            }
+            __syncthreads();
+            static_for<0, MI>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const int rl = j * 16 + (lane & 15);
+                const float nrm = sqrtf((red[rl] + red[64 + rl]) + (red[128 + rl] + red[192 + rl]));
+                const int m = m0c + rl;
+                const int r16 = lane >> 4;
+                static_for<0, NI / 2>([&](auto pc) {
+                    constexpr int i = 2 * decltype(pc)::value;
+                    float y[2][4];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[q][r] = g.rn_scale * round_f16(acc[i + q][j][r] / nrm);
+                    const uint32_t a0 = pack2<F16>(y[0][0], y[0][1]), a1 = pack2<F16>(y[0][2], y[0][3]);
+                    const uint32_t b0 = pack2<F16>(y[1][0], y[1][1]), b1 = pack2<F16>(y[1][2], y[1][3]);
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                    const int col = n0c + wn * WN + i * 16 + (r16 & 1) * 16 + (r16 >> 1) * 8;
+                    if (m < g.M)
+                        *reinterpret_cast<uint4*>((uint16_t*)g.C + (size_t)m * g.ldc + col) =
+                            make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                });
+            });
+        } else if constexpr (EPI != EPI_GENERIC) {
+            if constexpr (!BIAS_PREFETCH) {       // 128-accumulator tiles have no registers to spare across the K-loop
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+                    biasv[i] = *reinterpret_cast<const float4*>(g.bias + n0c + wn * WN + i * 16 + (lane >> 4) * 4);
+            }
+            fast_epilogue<T, EPI, MI, NI>(g, acc, m0c + wm * WM, n0c + wn * WN, lane, biasv);
+        } else {
+        int ncol[NI];
+        ColPart cp[NI], cpw[NI / 2];
+        float4 bias[NI];
+        const bool wide = epilogue_cols<NI>(g, n0c + wn * WN + (lane >> 4) * 4, lane, ncol, cp, cpw, bias);
+        // runtime loop over the MI output rows of this lane (one copy of the epilogue code); the
+        // accumulator row is selected with static indices so acc[][] stays in registers
+#pragma unroll 1
+        for (int j = 0; j < MI; ++j) {
+            f32x4_t row[NI];
+            static_for<0, MI>([&](auto jc) {
+                constexpr int js = decltype(jc)::value;
+                if (j == js) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) row[i] = acc[i][js];
+                }
+            });
+            const int m = m0c + wm * WM + j * 16 + (lane & 15);
+            if ((g.dbg & 3) == 2) { asm volatile("" ::"v"(row[0][0]), "v"(row[NI - 1][3])); continue; }
+            if (m < g.M) epilogue_row<T, NI>(g, m, ncol, cp, cpw, wide, bias, row);
         }
-        prev = tile;
-        tile += wpx;
+        }
+        }
+        if ((g.dbg & 4)) tmark[2] += __builtin_readcyclecounter() - te0;
     }
     if ((g.dbg & 4) && lane == 0 && g.res2) {
         unsigned long long* o = (unsigned long long*)g.res2 + ((size_t)blockIdx.x * NW + w) * 8;
-        o[0] = tmark[0]; o[1] = tmark[1]; o[2] = tmark[2]; o[3] = tmark[3]; o[4] = tmark[5]; o[5] = tmark[6];
+        o[0] = tmark[0]; o[1] = tmark[1]; o[2] = tmark[2]; o[3] = tmark[3]; o[4] = 0; o[5] = 0;
         o[6] = __builtin_readcyclecounter() - kc0;              // whole kernel, shader cycles
         o[7] = __builtin_amdgcn_s_memrealtime() - kr0;          // whole kernel, 100 MHz ticks
     }
@@ -1077,10 +1119,22 @@ int pick_tile(const GemmArgs& g, hipStream_t stream) {
     const long t_mid = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
     static const int force = getenv("LSEG_GEMM_TILE") ? atoi(getenv("LSEG_GEMM_TILE")) : 0;   // 1 small 2 mid (3 big 4 ping-pong)
     int pick = t_mid >= 192 ? 2 : 1;
+    if (!CONV && EPI != EPI_GENERIC && pick == 2) {
+        // 256x256 tiles (one 8-wave workgroup per CU) move half the operand bytes per MFMA through the
+        // CU's L1/LDS-DMA path and run ~12% faster per flop than two 128x128 workgroups -- when the
+        // tile count quantises well over the 256 CUs.  Persistent schedules: ceil(tiles / slots) rounds.
+        const long t_huge = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
+        const double time_huge = (double)((t_huge + 255) / 256) * 4.0 / 1.12;
+        const double time_mid = (double)((t_mid + 511) / 512) * 2.0;
+        if (time_huge < time_mid) pick = 6;
+    }
     if (force) pick = force;
+    if constexpr (!CONV && EPI != EPI_GENERIC) {
+        if (pick == 6) return launch_one<T, CfgHuge, CONV, RELU_IN, EPI, TAG>(g, stream);
+    }
+    if (pick == 6) pick = 2;
 #ifdef LSEG_GEMM_EXPERIMENTAL
     if (pick == 4) return launch_pp<T, CONV, RELU_IN, TAG>(g, stream);
-    if (pick == 3) return launch_one<T, CfgBig, CONV, RELU_IN, EPI, TAG>(g, stream);
 #endif
     if (pick == 2) return launch_one<T, CfgMid, CONV, RELU_IN, EPI, TAG>(g, stream);
     return launch_one<T, CfgSmall, CONV, RELU_IN, EPI, TAG>(g, stream);

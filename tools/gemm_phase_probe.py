@@ -11,7 +11,9 @@ import torch
 from lseg_hip import _lib
 lib = _lib.load()
 P = lambda t: C.c_void_p(t.data_ptr())
-BM = BN = 128
+BM = int(os.environ.get("PROBE_BM", "128")); BN = int(os.environ.get("PROBE_BN", "128"))
+WAVES = (BM // 64) * (BN // 64) if BM * BN < 65536 else 8       # waves per workgroup
+MFMA_STEP = (BM * BN // WAVES // 256) * 2 * 16 * (WAVES // 4)   # MFMA-pipe cycles per K-step per SIMD
 shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or \
     [(28832, 4096, 1024), (28832, 1024, 4096), (7208, 1024, 4096), (8192, 8192, 8192)]
 for (M, N, K) in shapes:
@@ -25,14 +27,13 @@ for (M, N, K) in shapes:
         _lib.check(lib.lseg_op_gemm(P(A), P(W), P(bias), P(dump), P(out), M, N, K, 2, 2, 0, st))
     torch.cuda.synchronize()
     d = dump.view(-1, 8).cpu().double(); d = d[d[:, 6] > 0]
-    wgs = d.shape[0] / 4
+    wgs = d.shape[0] / WAVES
     tiles = math.ceil(M / BM) * math.ceil(N / BN) / wgs           # tiles per workgroup
     nk = K // 64
     m = d.mean(0)
     ghz = m[6] / (m[7] * 10.0)
     per_tile = m[6] / tiles
     print(f"{M}x{N}x{K}: {int(wgs)} workgroups, {tiles:.1f} tiles each, clock {ghz:.2f} GHz, kernel {m[7] * 0.01:.1f} us/wave, "
-          f"{per_tile:.0f} cycles/tile (MFMA-bound: {nk * 512 * 2})")
-    print(f"   per K-step (k>=1): vmcnt-wait {m[0] / (tiles * nk):.0f}  barrier {m[1] / (tiles * nk):.0f}  reads+MFMA {m[3] / (tiles * (nk - 1)):.0f}"
-          f"   | per tile: epilogue {m[2] / tiles:.0f}  first MFMA block {m[4] / tiles:.0f}  vmcnt-wait after epilogue {m[5] / tiles:.0f}"
-          f"  K-loop total {(m[0] + m[1] + m[3]) / tiles:.0f}")
+          f"{per_tile:.0f} cycles/tile (MFMA-bound: {nk * MFMA_STEP * (2 if WAVES == 4 else 1)})")
+    print(f"   per K-step: vmcnt-wait {m[0] / (tiles * nk):.0f}  barrier {m[1] / (tiles * nk):.0f}  MFMA blocks {m[3] / (tiles * nk):.0f}"
+          f"   | per tile: epilogue {m[2] / tiles:.0f}  K-loop total {(m[0] + m[1] + m[3]) / tiles:.0f}")

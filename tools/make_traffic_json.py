@@ -1,0 +1,22 @@
+#!/usr/bin/env python
+"""profiles/r01_traffic.json from the PMC summary of tools/collect_profiles.sh (gpurun_out/profiles/summary.json).
+HBM-side traffic of the profiled MLP fc1 GEMM (the TAG=1 kernel symbol), per launch:
+  FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled on gfx950 (MI355X_MICROARCH.md, HBM/rocprofv3 section)."""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "profiles", "summary.json")
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+pmc = json.load(open(src))["pmc"]
+name = [k for k in pmc if "lseg_gemm_kernel" in k and k.rstrip().endswith(", 1>(lseg::GemmArgs)")]
+assert len(name) == 1, name
+c = pmc[name[0]]
+M, N, K = batch * 901, 4096, 1024
+out = {"mlp_fc1_gemm": {
+    "kernel": name[0], "batch": batch,
+    "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c["WRITE_SIZE"],
+    "traffic_bytes_per_launch": (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024,
+    "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); FETCH counts L2->fabric requests incl. Infinity-Cache hits",
+    "algorithmic_bytes_per_launch": 2 * (M * K + N * K + M * N),
+    **{k: c[k] for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "TCC_HIT_sum", "TCC_MISS_sum", "SQ_LDS_BANK_CONFLICT") if k in c}}}
+json.dump(out, open(os.path.join(ROOT, "profiles", "r01_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
