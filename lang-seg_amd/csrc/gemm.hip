@@ -464,12 +464,17 @@ struct TileCfg {
     static constexpr int A_BYTES = BM * 128, W_BYTES = BN * 128, STAGE = A_BYTES + W_BYTES;
     static constexpr int A_SPW = BM / 8 / NW, W_SPW = BN / 8 / NW;   // 8-row slabs per wave per stage
     static constexpr int SPW = A_SPW + W_SPW;
-    static constexpr int LDS = NS * STAGE;
+    // LDS: separate rings for the two operands -- three K-steps of A, two of W.  The A panel of step k+2
+    // stays in flight ACROSS the barrier of step k (counted vmcnt, never 0 in the K-loop): the DMA queue
+    // never drains, and only the W half of a step's 2*SPW KB sits on the barrier's critical path.
+    static constexpr int A_RING = 3, W_RING = 2;
+    static constexpr int LDS = A_RING * A_BYTES + W_RING * W_BYTES;
     // DMA issues of one K-step: Q_B2 ride in the second half of the k-half-1 MFMA block of the previous
     // step, Q_A in the k-half-0 block of the step before they are consumed.  128-accumulator tiles
     // (a K-step is 2000+ cycles) issue everything early; the small-tile configs need the spread, their
     // waves stall ~60 cycles per global_load_lds when two workgroups share the CU's address path.
-    static constexpr int Q_A = (BM * BN >= 65536) ? 0 : (SPW * NI) / (NI + (NI - NI / 2));
+    static constexpr int Q_A0 = (BM * BN >= 65536) ? 0 : (SPW * NI) / (NI + (NI - NI / 2));
+    static constexpr int Q_A = Q_A0 > A_SPW ? A_SPW : Q_A0;      // the W panel (needed first) is always issued early
     static constexpr int Q_B2 = SPW - Q_A;
     static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "slabs must divide evenly over the waves");
 };
@@ -537,14 +542,14 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
     }
     if (tile >= tile_end) return;
 
-    // ---- load side: runs NS-1 K-steps ahead of the MFMA side, across tile boundaries -------------
+    // ---- load side: two cursors (A runs one K-step ahead of W), both walk (tile, K-step) in order -----
     // per-lane BYTE offsets (32-bit) of this lane's source rows, incl. the swizzled 16-byte chunk
     uint32_t a_off[A_SPW], w_off[W_SPW];
     const int lrow = lane >> 3;                           // row inside an 8-row slab
-    auto setup = [&](int t) {
+    auto setup_a = [&](int t) {
         int mb, nb;
         tile_coords(t, tiles_m, tiles_n, mb, nb);
-        const int m0 = mb * BM, n0 = nb * BN;
+        const int m0 = mb * BM;
 #pragma unroll
         for (int s = 0; s < A_SPW; ++s) {
             const int r = (s * NW + w) * 8 + lrow;
@@ -561,6 +566,11 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
             }
             a_off[s] = (e + (((lane & 7) ^ swz(r)) << 3)) * 2u;
         }
+    };
+    auto setup_w = [&](int t) {
+        int mb, nb;
+        tile_coords(t, tiles_m, tiles_n, mb, nb);
+        const int n0 = nb * BN;
 #pragma unroll
         for (int s = 0; s < W_SPW; ++s) {
             const int r = (s * NW + w) * 8 + lrow;
@@ -572,45 +582,57 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
 
     const int nk = g.K >> 6;
     const int cpt = CONV ? (g.cin >> 6) : 1;    // 64-wide K chunks per conv tap
-    int itile = tile, ikt = 0, istage = 0;
-    setup(itile);
-    // issue the loads of K-step (itile, ikt) into LDS stage istage, then advance.  After the last
-    // tile the same tile is re-issued (never consumed): every K-step issues exactly SPW loads per
-    // wave, so the counted vmcnt below stays exact.
-    // source bases of the K-step the load cursor points at (wave-uniform)
-    auto load_bases = [&](const char*& abase, const char*& wbase) {
+    constexpr int W_RING_OFF = CFG::A_RING * A_BYTES;
+    // After the last tile a cursor keeps re-issuing that tile (never consumed): every step issues exactly
+    // SPW loads per wave, so the counted vmcnt stays exact.
+    int atile = tile, akt = 0, aslot = 0;
+    int wtile = tile, wkt = 0, wslot = 0;
+    setup_a(atile);
+    setup_w(wtile);
+    const char *abase = nullptr, *wbase = nullptr;        // source bases of the K-steps the cursors point at
+    auto a_src = [&]() {
         int koff_a;
         if (CONV) {
-            const int tap = ikt / cpt, ci0 = (ikt - tap * cpt) << 6;
+            const int tap = akt / cpt, ci0 = (akt - tap * cpt) << 6;
             const int ky = tap / 3, kx = tap - ky * 3;
             koff_a = (ky * g.wp + kx) * g.cin + ci0;
         } else {
-            koff_a = ikt << 6;
+            koff_a = akt << 6;
         }
-        abase = reinterpret_cast<const char*>(g.A + koff_a);
-        wbase = reinterpret_cast<const char*>(g.W + (ikt << 6));
+        return reinterpret_cast<const char*>(g.A + koff_a);
     };
-    // the q-th of this wave's SPW direct-to-LDS loads of that K-step (A slabs first, then W slabs)
-    auto issue_one = [&](auto qc, const char* abase, const char* wbase) {
+    auto advance_a = [&]() {
+        aslot = aslot + 1 == CFG::A_RING ? 0 : aslot + 1;
+        if (++akt == nk) {
+            akt = 0;
+            if (atile + wpx < tile_end) atile += wpx;
+            setup_a(atile);
+        }
+    };
+    auto advance_w = [&]() {
+        wslot ^= 1;
+        if (++wkt == nk) {
+            wkt = 0;
+            if (wtile + wpx < tile_end) wtile += wpx;
+            setup_w(wtile);
+        }
+    };
+    // One issue GROUP = the W panel at the W cursor, then the A panel at the A cursor (one K-step further on);
+    // q indexes the group's SPW direct-to-LDS loads in that order.  A group may be split over two blocks of
+    // MFMAs: the bases are latched on the first load of each kind, the cursors advance on the last.
+    auto issue_q = [&](auto qc) {
         constexpr int q = decltype(qc)::value;
-        char* sa = smem + istage * STAGE;
-        if constexpr (q < A_SPW) glds_slab_off(abase, a_off[q], sa + (q * NW + w) * 1024);
-        else glds_slab_off(wbase, w_off[q - A_SPW], sa + A_BYTES + ((q - A_SPW) * NW + w) * 1024);
-    };
-    auto issue_loads = [&]() {
-        const char *abase, *wbase;
-        load_bases(abase, wbase);
-        static_for<0, CFG::SPW>([&](auto qc) { issue_one(qc, abase, wbase); });
-    };
-    auto issue_advance = [&]() {           // move the load cursor to the next K-step (may cross a tile)
-        istage = istage + 1 == NS ? 0 : istage + 1;
-        if (++ikt == nk) {
-            ikt = 0;
-            if (itile + wpx < tile_end) itile += wpx;
-            setup(itile);
+        if constexpr (q < W_SPW) {
+            if constexpr (q == 0) wbase = reinterpret_cast<const char*>(g.W + (wkt << 6));
+            glds_slab_off(wbase, w_off[q], smem + W_RING_OFF + wslot * CFG::W_BYTES + (q * NW + w) * 1024);
+            if constexpr (q == W_SPW - 1) advance_w();
+        } else {
+            constexpr int qa = q - W_SPW;
+            if constexpr (qa == 0) abase = a_src();
+            glds_slab_off(abase, a_off[qa], smem + aslot * A_BYTES + (qa * NW + w) * 1024);
+            if constexpr (qa == A_SPW - 1) advance_a();
         }
     };
-    auto issue_next = [&]() { issue_loads(); issue_advance(); };
 
     // ---- MFMA side: software-pipelined K-loop ---------------------------------------------------------
     // One workgroup barrier per K-step, in the MIDDLE of the k-half-1 MFMA block:
@@ -622,13 +644,12 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
     // so the wave always leaves the barrier with 8+ MFMAs of fragments in registers (no post-barrier
     // LDS ramp: that ramp plus barrier skew idled the matrix pipe ~25% of every K-step in the
     // barrier-at-the-top loop, tools/gemm_phase_probe.py), and a DMA has a full K-step to land.
-    static_assert(NS == 2, "the pipelined loop alternates two LDS stages");
     f32x4_t acc[NI][MI];
     i32x4_t wf0[NI], af0[MI], wf1[NI], af1[MI];
     // LDS fragment byte offsets of this lane (ks = 0 / 1); sub-tiles add i*2048 / j*2048
     const int frow = lane & 15;
     const int foff0 = tile_off(frow, lane >> 4), foff1 = tile_off(frow, 4 + (lane >> 4));
-    const int wbase_off = A_BYTES + wn * WN * 128, abase_off = wm * WM * 128;
+    const int wbase_off = wn * WN * 128, abase_off = wm * WM * 128;   // inside a W / A ring slot
 #ifdef GEMM_ABL_NOREAD      // ablation builds (tools/): K-loop without LDS fragment reads / DMA issues / MFMAs
     auto ldfrag = [&](const char* p) { return i32x4_t{lane, lane, lane, lane}; };
 #else
@@ -649,35 +670,50 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
     unsigned long long kc0 = 0, kr0 = 0;                       // dbg&4: whole-kernel s_memtime / s_memrealtime (100 MHz)
     if ((g.dbg & 4)) { kc0 = __builtin_readcyclecounter(); kr0 = __builtin_amdgcn_s_memrealtime(); }
 
-    int cstage = 0;
+    int ca = 0, cw = 0;                                  // ring slots of the K-step being computed
+    const bool early = NW == 8 && w >= 4 && !(g.dbg & 8);   // see sync() below (dbg bit 3: A/B switch, tools)
     auto step = [&]() {
-        const char* st = smem + cstage * STAGE;
-        const char* nx = smem + (cstage ^ 1) * STAGE;
+        const char* sa = smem + ca * A_BYTES;                                   // this step's panels
+        const char* sw = smem + W_RING_OFF + cw * CFG::W_BYTES;
+        const int na = ca + 1 == CFG::A_RING ? 0 : ca + 1;
+        const char* nxa = smem + na * A_BYTES;                                   // next step's
+        const char* nxw = smem + W_RING_OFF + (cw ^ 1) * CFG::W_BYTES;
         unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
         if ((g.dbg & 4)) t0 = __builtin_readcyclecounter();
-        const char *abase, *wbase;
-        load_bases(abase, wbase);
-        constexpr int LPA = (CFG::Q_A + NI - 1) / NI;                    // DMA issues per block-A group
-        // ---- block A
-        static_for<0, NI>([&](auto ic) {
-            constexpr int i = decltype(ic)::value;
-#pragma unroll
-            for (int j = 0; j < MI; ++j) acc[i][j] = mm(wf0[i], af0[j], acc[i][j]);
-            wf1[i] = ldfrag(st + wbase_off + i * 2048 + foff1);
-            if constexpr (i < MI) af1[i] = lda(st, i, foff1);
+        // Memory operations are interleaved ONE per MFMA (fenced): a wave that runs alone on its SIMD -- its
+        // partner waiting at the barrier -- then keeps the matrix pipe fed; in groups of 4 MFMAs followed by
+        // 3-5 loads the pipe drained after every group (a lone wave reached ~65% of the MFMA rate).
+        // ---- block A: NI*MI MFMAs; ops = k-half-1 fragment reads (A fragments first), then Q_A DMA issues
+        {
+            constexpr int NMF = NI * MI, OPS = NI + MI + CFG::Q_A;
+            static_for<0, NMF>([&](auto tc) {
+                constexpr int t = decltype(tc)::value, i = t / MI, j = t % MI;
+                acc[i][j] = mm(wf0[i], af0[j], acc[i][j]);
+                static_for<(t * OPS) / NMF, ((t + 1) * OPS) / NMF>([&](auto oc) {
+                    constexpr int o = decltype(oc)::value;
+                    if constexpr (o < MI) af1[o] = lda(sa, o, foff1);
+                    else if constexpr (o < MI + NI) wf1[o - MI] = ldfrag(sw + wbase_off + (o - MI) * 2048 + foff1);
 #ifndef GEMM_ABL_NODMA
-            static_for<0, LPA>([&](auto lc) {
-                constexpr int q = CFG::Q_B2 + i * LPA + decltype(lc)::value;
-                if constexpr (q < CFG::SPW) issue_one(std::integral_constant<int, q>{}, abase, wbase);
-            });
+                    else issue_q(std::integral_constant<int, CFG::Q_B2 + o - MI - NI>{});
 #endif
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        issue_advance();                 // the load cursor now points at step k+2
-        if constexpr (MI > NI) {
-#pragma unroll
-            for (int j = NI; j < MI; ++j) af1[j] = lda(st, j, foff1);
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
         }
+        // The step's barrier: every wave's reads of this step's ring slots are complete (all issued in block A)
+        // and its share of step k+1 has landed; only the A panel of step k+2 (the last A_SPW loads issued) stays
+        // in flight across it.  8-wave workgroups put two waves on every SIMD (w and w+4): the second group
+        // takes the barrier one block EARLIER in its instruction stream, which shifts it a quarter step in time --
+        // while one wave of a SIMD is in the load-heavy block B2 its partner is in the MFMA-only block B1.
+        auto sync = [&]() {
+            if ((g.dbg & 4)) t1 = __builtin_readcyclecounter();
+            wait_lgkmcnt0();
+            wait_vmcnt<A_SPW>();
+            if ((g.dbg & 4)) t2 = __builtin_readcyclecounter();
+            __builtin_amdgcn_s_barrier();
+            if ((g.dbg & 4)) t3 = __builtin_readcyclecounter();
+        };
+        if (NW == 8 && early) sync();
         // ---- block B1
         static_for<0, NI / 2>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
@@ -685,57 +721,43 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
             for (int j = 0; j < MI; ++j) acc[i][j] = mm(wf1[i], af1[j], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
         });
-        if ((g.dbg & 4)) t1 = __builtin_readcyclecounter();
-        wait_lgkmcnt0();                 // this wave's reads of stage k%2 are complete ...
-        wait_vmcnt<0>();                 // ... and its share of step k+1 has landed (also: epilogue stores acknowledged)
-        if ((g.dbg & 4)) t2 = __builtin_readcyclecounter();
-        __builtin_amdgcn_s_barrier();
-        if ((g.dbg & 4)) t3 = __builtin_readcyclecounter();
+        if (!(NW == 8 && early)) sync();
         // ---- block B2
-        load_bases(abase, wbase);
-        constexpr int G = NI - NI / 2;                                   // MFMA groups in this block
-        constexpr int RPG = (NI + MI + G - 1) / G;                       // next-step fragment reads per group
-        constexpr int LPG = (CFG::Q_B2 + G - 1) / G;                     // DMA issues per group
-        static_for<0, G>([&](auto gc) {
-            constexpr int gi = decltype(gc)::value, i = NI / 2 + gi;
-#pragma unroll
-            for (int j = 0; j < MI; ++j) acc[i][j] = mm(wf1[i], af1[j], acc[i][j]);
-            static_for<0, RPG>([&](auto rc) {
-                constexpr int r = gi * RPG + decltype(rc)::value;
-                if constexpr (r < NI) wf0[r] = ldfrag(nx + wbase_off + r * 2048 + foff0);
-                else if constexpr (r < NI + MI) af0[r - NI] = lda(nx, r - NI, foff0);
-            });
-            static_for<0, LPG>([&](auto lc) {
-                constexpr int q = gi * LPG + decltype(lc)::value;
+        {   // (NI - NI/2)*MI MFMAs; ops = next step's k-half-0 fragment reads (A first), then Q_B2 DMA issues
+            constexpr int I0 = NI / 2, NMF = (NI - I0) * MI, OPS = NI + MI + CFG::Q_B2;
+            static_for<0, NMF>([&](auto tc) {
+                constexpr int t = decltype(tc)::value, i = I0 + t / MI, j = t % MI;
+                acc[i][j] = mm(wf1[i], af1[j], acc[i][j]);
+                static_for<(t * OPS) / NMF, ((t + 1) * OPS) / NMF>([&](auto oc) {
+                    constexpr int o = decltype(oc)::value;
+                    if constexpr (o < MI) af0[o] = lda(nxa, o, foff0);
+                    else if constexpr (o < MI + NI) wf0[o - MI] = ldfrag(nxw + wbase_off + (o - MI) * 2048 + foff0);
 #ifndef GEMM_ABL_NODMA
-                if constexpr (q < CFG::Q_B2) issue_one(std::integral_constant<int, q>{}, abase, wbase);
+                    else issue_q(std::integral_constant<int, o - MI - NI>{});
 #endif
+                });
+                __builtin_amdgcn_sched_barrier(0);
             });
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        cstage ^= 1;
+        }
+        ca = na; cw ^= 1;
         if ((g.dbg & 4)) {
             const unsigned long long t4 = __builtin_readcyclecounter();
             tmark[0] += t2 - t1; tmark[1] += t3 - t2; tmark[3] += (t1 - t0) + (t4 - t3);
         }
     };
 
-    // prologue: step 0 landed and its k-half-0 fragments in registers, step 1 in flight
-    issue_next();
+    // prologue.  Steady state at the barrier of step k: landed W(k+1), A(k+1); in flight A(k+2); the group
+    // {W(k+2), A(k+3)} is issued behind the barrier.  So: W(0), A(0) | A(1) | {W(1), A(2)} (its tail in block A).
+    static_for<0, W_SPW>([&](auto qc) { issue_q(qc); });                                   // W(0)
+    static_for<0, A_SPW>([&](auto qc) { issue_q(std::integral_constant<int, W_SPW + decltype(qc)::value>{}); });   // A(0)
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
-    {
-        const char* st = smem;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) wf0[i] = ldfrag(st + wbase_off + i * 2048 + foff0);
+    for (int i = 0; i < NI; ++i) wf0[i] = ldfrag(smem + W_RING_OFF + wbase_off + i * 2048 + foff0);
 #pragma unroll
-        for (int j = 0; j < MI; ++j) af0[j] = lda(st, j, foff0);
-    }
-    {   // the early part of step 1's loads; block A of step 0 issues the rest
-        const char *abase, *wbase;
-        load_bases(abase, wbase);
-        static_for<0, CFG::Q_B2>([&](auto qc) { issue_one(qc, abase, wbase); });
-    }
+    for (int j = 0; j < MI; ++j) af0[j] = lda(smem, j, foff0);
+    static_for<0, A_SPW>([&](auto qc) { issue_q(std::integral_constant<int, W_SPW + decltype(qc)::value>{}); });   // A(1)
+    static_for<0, CFG::Q_B2>([&](auto qc) { issue_q(qc); });                               // head of {W(1), A(2)}
 
     constexpr bool BIAS_PREFETCH = MI * NI <= 16;
     float4 biasv[EPI != EPI_GENERIC ? NI : 1];
@@ -767,7 +789,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
             // lane owns, for each of its MI rows, NI groups of 4 columns inside this wave's 128
             // columns; the row's sum of squares is reduced over the 4 lane groups (shuffles) and
             // over the 4 waves (LDS scratch behind the stage ring), in a fixed order.
-            float* red = reinterpret_cast<float*>(smem + NS * STAGE);      // [4 waves][64 rows]
+            float* red = reinterpret_cast<float*>(smem + CFG::LDS);      // [4 waves][64 rows]
             const int n_first = n0c + wn * WN + (lane >> 4) * 4;
             float ssq[MI];
             static_for<0, MI>([&](auto jc) {
