@@ -114,6 +114,11 @@ int lseg_set_text_tokens(lseg_handle h, const int64_t* host_tokens, int K, int c
 int lseg_encode_text(lseg_handle h, void* stream);
 int lseg_set_text_cache(lseg_handle h, int enabled);   /* 0 (default) = re-encode per forward */
 int lseg_get_text_features(lseg_handle h, void* dev_out_f16 /* [K,out_c] fp16 */, void* stream);
+/* Zero-shot variant -- replaces: LSegNetZS.forward(x, class_info) (lseg_net_zs.py:177-214): every image brings
+ * its OWN label set.  labels_per_image = k > 0: the K = B*k token rows are grouped per image, image b is
+ * correlated with rows [b*k, (b+1)*k) only and lseg_forward writes [B,k,img_h,img_w]; 0 (default) = one
+ * label set shared by the batch.  Takes effect at the next lseg_forward (which must be called with B = K/k). */
+int lseg_set_text_grouping(lseg_handle h, int labels_per_image);
 
 /* ---- forward -----------------------------------------------------------------------
  * replaces: LSeg.forward(x, labelset) (lseg_net.py:160-205).
@@ -180,6 +185,17 @@ int lseg_op_correlation(const float* d_feat, const void* d_text_f16, float* d_lo
  * (the A operand of the correlation GEMM; the fp32 features are never materialised). */
 int lseg_op_head_features(const void* d_x_bf16, const void* d_w_bf16, const float* d_bias, void* d_a_f16,
                           int M, int F, float logit_scale, void* stream);
+
+/* Segmentation statistics of a score tensor against a target mask, on the device (one pass over the scores).
+ * replaces: the host-side metric / loss step after LSeg.forward --
+ *   batch_pix_accuracy + batch_intersection_union ([3P] encoding/utils/metrics.py; called at
+ *   lsegmentation_module.py:49-50,59-60 and through SegmentationMetric.update at test_lseg.py:385-388), and the
+ *   forward value of SegmentationLosses = nn.CrossEntropyLoss(ignore_index) ([3P] encoding/nn/loss.py; :72).
+ * d_scores fp32 [B,K,H,W]; d_target int64 [B,H,W] (values -1 = unlabeled / 0..K-1);
+ * d_counts int64 [2+3K] = {correct, labeled, area_inter[K], area_pred[K], area_lab[K]}  (union = pred + lab - inter);
+ * d_nll double [2] = {sum over valid pixels of -log_softmax(scores)[target], number of valid pixels}. */
+int lseg_op_seg_stats(const float* d_scores, const int64_t* d_target, int B, int K, int H, int W, int ignore_index,
+                      int64_t* d_counts, double* d_nll, void* stream);
 
 #ifdef __cplusplus
 }

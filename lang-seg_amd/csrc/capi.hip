@@ -70,6 +70,13 @@ int lseg_set_text_tokens(lseg_handle h, const int64_t* host_tokens, int K, int c
 }
 int lseg_encode_text(lseg_handle h, void* stream) { GUARD(h); return h->e->encode_text((hipStream_t)stream); }
 int lseg_set_text_cache(lseg_handle h, int enabled) { GUARD(h); h->e->text_cache = enabled != 0; return LSEG_OK; }
+int lseg_set_text_grouping(lseg_handle h, int labels_per_image) {
+    GUARD(h);
+    if (labels_per_image < 0 || labels_per_image > h->e->cfg.max_labels)
+        return set_error(LSEG_ERR_INVALID, "labels_per_image=%d outside [0, max_labels]", labels_per_image);
+    h->e->group_k = labels_per_image;
+    return LSEG_OK;
+}
 int lseg_get_text_features(lseg_handle h, void* dev_out, void* stream) {
     GUARD(h);
     if (!dev_out) return set_error(LSEG_ERR_INVALID, "out NULL");
@@ -188,6 +195,15 @@ int lseg_op_head_features(const void* x_bf16, const void* w_bf16, const float* b
     g.A = (const uint16_t*)x_bf16; g.W = (const uint16_t*)w_bf16; g.M = M; g.N = 512; g.K = F; g.lda = F; g.ldw = F;
     g.bias = bias; g.C = a_f16; g.out_dtype = DT_F16; g.ldc = 512; g.map_mode = MAP_ROWNORM; g.rn_scale = logit_scale;
     return launch_gemm(g, DT_BF16, (hipStream_t)stream);
+}
+
+int lseg_op_seg_stats(const float* d_scores, const int64_t* d_target, int B, int K, int H, int W, int ignore_index,
+                      int64_t* d_counts, double* d_nll, void* stream) {
+    int r = require_device(); if (r) return r;
+    if (!d_scores || !d_target || !d_counts || !d_nll) return set_error(LSEG_ERR_INVALID, "seg_stats: NULL pointer");
+    if (B < 1 || K < 1 || K > 4096 || H < 1 || W < 1) return set_error(LSEG_ERR_INVALID, "seg_stats: bad shape B=%d K=%d %dx%d", B, K, H, W);
+    return launch_seg_stats(d_scores, d_target, B, K, H * W, ignore_index, reinterpret_cast<unsigned long long*>(d_counts),
+                            d_nll, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -432,6 +432,77 @@ __global__ void argmax_planes_kernel(const float* in, uint8_t* out, int B, int K
     }
 }
 
+// ---- segmentation statistics on device -------------------------------------------------------------------------------
+// One pass over the [B,K,H,W] fp32 scores: per pixel the arg-max label, its log-sum-exp and the score at the target;
+// accumulates what the host-side metric code of the reference computes from the full logits tensor:
+//   pixAcc / IoU counts  -- [3P] encoding/utils/metrics.py batch_pix_accuracy / batch_intersection_union
+//                           (call sites lsegmentation_module.py:49-50,59-60; test_lseg.py:385-388)
+//   cross-entropy        -- [3P] encoding/nn/loss.py SegmentationLosses = nn.CrossEntropyLoss(ignore_index)
+//                           (call site lsegmentation_module.py:72): sum of -log_softmax(scores)[target] and the pixel count
+// counts: [0] correct, [1] labeled, [2..2+K) area_inter, [2+K..2+2K) area_pred, [2+2K..2+3K) area_lab ; nll: [0] sum, [1] count.
+// Integer counts are exact (atomics on integers); the NLL sum is a double atomic (order-dependent in the last bits).
+__global__ __launch_bounds__(256) void seg_stats_kernel(const float* __restrict__ scores, const long long* __restrict__ target,
+                                                        int K, int HW, size_t npix, int ignore_index,
+                                                        unsigned long long* __restrict__ counts, double* __restrict__ nll) {
+    extern __shared__ unsigned int hist[];                // [3K] per-block class histograms + [2] pixel counts
+    for (int i = threadIdx.x; i < 3 * K + 2; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    double loss = 0.0;
+    unsigned int nvalid = 0;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i % HW);
+        const size_t b = i / HW;
+        const float* col = scores + b * (size_t)K * HW + p;
+        const long long t = target[i];
+        float m = -INFINITY, ssum = 0.f, at_t = 0.f;
+        int arg = 0;
+        for (int k = 0; k < K; ++k) {
+            const float v = col[(size_t)k * HW];
+            if (v > m) {                                  // first maximum wins (torch.max / argmax tie rule)
+                ssum = ssum * __expf(m - v) + 1.f;        // online log-sum-exp (exp(-inf) = 0 on the first label)
+                m = v; arg = k;
+            } else {
+                ssum += __expf(v - m);
+            }
+            if (k == t) at_t = v;
+        }
+        const long long t1 = t + 1;                        // metrics.py: target + 1, predict + 1
+        const int pred1 = arg + 1;
+        if (t1 > 0) {
+            atomicAdd(&hist[3 * K + 1], 1u);               // labeled
+            atomicAdd(&hist[K + pred1 - 1], 1u);           // area_pred: predict * (target > 0)
+            if (t1 <= K) atomicAdd(&hist[2 * K + (int)t1 - 1], 1u);   // area_lab (np.histogram range (1, nclass))
+            if (pred1 == t1) {
+                atomicAdd(&hist[3 * K], 1u);               // correct
+                atomicAdd(&hist[pred1 - 1], 1u);           // area_inter
+            }
+        }
+        if (t != (long long)ignore_index && t >= 0 && t < K) {
+            loss += (double)(m + __logf(ssum) - at_t);
+            ++nvalid;
+        }
+    }
+    // block reduction of the loss, then one atomic per block / per non-empty histogram bin
+    __shared__ double lred[256];
+    __shared__ unsigned int nred[256];
+    lred[threadIdx.x] = loss; nred[threadIdx.x] = nvalid;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { lred[threadIdx.x] += lred[threadIdx.x + s]; nred[threadIdx.x] += nred[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && nred[0]) {
+        atomicAdd(&nll[0], lred[0]);
+        atomicAdd(&nll[1], (double)nred[0]);
+    }
+    for (int i = threadIdx.x; i < 3 * K + 2; i += blockDim.x) {
+        const unsigned int v = hist[i];
+        if (!v) continue;
+        const int dst = i < 3 * K ? 2 + i : i - 3 * K;    // [3K] -> correct, [3K+1] -> labeled
+        atomicAdd(&counts[dst], (unsigned long long)v);
+    }
+}
+
 inline int grid_for(size_t total, int block = 256) {
     size_t g = (total + block - 1) / block;
     if (g > 256 * 16) g = 256 * 16;      // cap + grid-stride (cdna guide G11)
@@ -561,6 +632,19 @@ int launch_head_block(const float* in, float* out, const float* w9, const float*
 }
 int launch_argmax_planes(const float* in, uint8_t* out, int B, int K, int HW, hipStream_t st) {
     hipLaunchKernelGGL(argmax_planes_kernel, dim3(grid_for((size_t)B * HW)), dim3(256), 0, st, in, out, B, K, HW);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_seg_stats(const float* scores, const int64_t* target, int B, int K, int HW, int ignore_index,
+                     unsigned long long* counts, double* nll, hipStream_t st) {
+    if (K < 1 || K > 4096) return -1;
+    LSEG_HIP_TRY(hipMemsetAsync(counts, 0, (size_t)(2 + 3 * K) * sizeof(unsigned long long), st));
+    LSEG_HIP_TRY(hipMemsetAsync(nll, 0, 2 * sizeof(double), st));
+    const size_t npix = (size_t)B * HW;
+    int grid = (int)std::min<size_t>((npix + 255) / 256, 2048);
+    hipLaunchKernelGGL(seg_stats_kernel, dim3(grid), dim3(256), (size_t)(3 * K + 2) * sizeof(unsigned int), st,
+                       scores, reinterpret_cast<const long long*>(target), K, HW, npix, ignore_index, counts, nll);
     CHECK_LAUNCH();
     return 0;
 }

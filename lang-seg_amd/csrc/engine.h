@@ -42,6 +42,7 @@ public:
     lseg_config cfg;
     int device;
     bool text_cache = false, text_valid = false, profiling = false, debug = false;
+    int group_k = 0;              // > 0: per-image label sets of this size (LSegNetZS), see lseg_set_text_grouping
     std::string err;
 
 private:

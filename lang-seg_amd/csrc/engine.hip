@@ -601,25 +601,40 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
         TRY(launch_gemm(g, img_dt_, st));
         TRY(launch_l2norm_scale_f16(feat_, a16_, Mp, c.out_c, logit_scale, st));
     }
+    const int Kout = group_k > 0 ? group_k : K_;            // label planes per image
+    if (group_k > 0) {
+        // lseg_net_zs.py:198-208: image b against its own k text rows -- B small GEMMs [hw1,out_c] x [out_c,k]
+        if (K_ != B * group_k)
+            return set_error(LSEG_ERR_INVALID, "grouped labels: %d token rows != B=%d x %d labels per image", K_, B, group_k);
+        if (c.arch_option != 0) return set_error(LSEG_ERR_UNSUPPORTED, "per-image label sets have no head blocks (lseg_net_zs.py:177-214)");
+        for (int b = 0; b < B; ++b) {
+            gemm_args_init(g);
+            g.A = a16_ + (size_t)b * hw1 * c.out_c; g.W = tnorm_ + (size_t)b * group_k * c.out_c;
+            g.M = hw1; g.N = group_k; g.K = c.out_c; g.lda = c.out_c; g.ldw = c.out_c;
+            g.round_mid = 1; g.C = low_ + (size_t)b * group_k * hw1; g.out_dtype = DT_F32; g.map_mode = MAP_NCHW; g.p_div = hw1;
+            TRY(launch_gemm(g, DT_F16, st));
+        }
+    } else {
     gemm_args_init(g);
     g.A = a16_; g.W = tnorm_; g.M = Mp; g.N = K_; g.K = c.out_c; g.lda = c.out_c; g.ldw = c.out_c;
     g.round_mid = 1; g.C = low_; g.out_dtype = DT_F32; g.map_mode = MAP_NCHW; g.p_div = hw1;
     TRY(launch_gemm(g, DT_F16, st));
+    }
     float* low = low_;
     if (c.arch_option == 1 || c.arch_option == 2) {                    // lseg_net.py:198-201
         const int bott = c.arch_option == 1;
         float* src = low_; float* dst = low2_;           // low_ stays intact (the "lowres" tap)
         for (int d = 0; d < c.block_depth - 1; ++d) {
-            TRY(launch_head_block(src, dst, hb_w_, hb_b_, B, K_, h1, w1, bott, c.activation, 1, st));
+            TRY(launch_head_block(src, dst, hb_w_, hb_b_, B, Kout, h1, w1, bott, c.activation, 1, st));
             src = dst; dst = (dst == low2_) ? low3_ : low2_;
         }
-        TRY(launch_head_block(src, dst, hb_w_, hb_b_, B, K_, h1, w1, bott, c.activation, 0, st));
+        TRY(launch_head_block(src, dst, hb_w_, hb_b_, B, Kout, h1, w1, bott, c.activation, 0, st));
         low = dst;
     }
-    if (argmax_out && K_ > 256) return set_error(LSEG_ERR_UNSUPPORTED, "uint8 argmax needs K <= 256 (K=%d)", K_);
-    if (argmax_out) TRY(launch_argmax_planes(low, argmax_out, B, K_, hw1, st));
+    if (argmax_out && Kout > 256) return set_error(LSEG_ERR_UNSUPPORTED, "uint8 argmax needs K <= 256 (K=%d)", Kout);
+    if (argmax_out) TRY(launch_argmax_planes(low, argmax_out, B, Kout, hw1, st));
     // ---- scratch.output_conv: bilinear x2, align_corners=True (lseg_net.py:203) ----------------------------------
-    if (logits) TRY(launch_upsample2x_planes(low, logits, B * K_, h1, w1, st));
+    if (logits) TRY(launch_upsample2x_planes(low, logits, B * Kout, h1, w1, st));
     if (profiling && fwd0 && fwd1) { (void)hipEventRecord(fwd1, st); ev_fwd_.push_back({fwd0, fwd1}); }
     return 0;
 }
@@ -663,7 +678,7 @@ int Engine::get_intermediate(const char* name, float* out, size_t cap, size_t* n
         TRY(launch_rows_to_nchw_f32(feat_, out, B, hw1, cfg.out_c, st));
     } else if (!strcmp(name, "lowres")) {
         const int hw1 = 4 * lh_[0] * lw_[0];
-        need_n = (size_t)B * K_ * hw1;
+        need_n = (size_t)B * (group_k > 0 ? group_k : K_) * hw1;
         if (cap < need_n) return set_error(LSEG_ERR_INVALID, "buffer too small: %zu < %zu", cap, need_n);
         LSEG_HIP_TRY(hipMemcpyAsync(out, low_, need_n * sizeof(float), hipMemcpyDeviceToDevice, st));
     } else {

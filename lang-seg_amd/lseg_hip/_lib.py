@@ -55,6 +55,7 @@ SIGNATURES = {
     "lseg_encode_text": (_i, [_vp, _vp]),
     "lseg_set_text_cache": (_i, [_vp, _i]),
     "lseg_get_text_features": (_i, [_vp, _vp, _vp]),
+    "lseg_set_text_grouping": (_i, [_vp, _i]),
     "lseg_forward": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "lseg_get_intermediate": (_i, [_vp, C.c_char_p, _vp, _sz, C.POINTER(_sz), _vp]),
     "lseg_set_debug": (_i, [_vp, _i]),
@@ -68,6 +69,7 @@ SIGNATURES = {
     "lseg_op_upsample2x_planes": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "lseg_op_correlation": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "lseg_op_head_features": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "lseg_op_seg_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -70,6 +70,7 @@ class HipEngine:
         _lib.check(self.lib.lseg_create(C.byref(self._c), self.device.index or 0, C.byref(h)))
         self._h = h
         self._K = 0
+        self._group = 0
         self._keep: List[torch.Tensor] = []
 
     def close(self):
@@ -106,12 +107,16 @@ class HipEngine:
         del keep      # finalize synchronises: the engine now owns packed copies
 
     # ---- text -------------------------------------------------------------------------------------------
-    def set_tokens(self, tokens: torch.Tensor):
+    def set_tokens(self, tokens: torch.Tensor, labels_per_image: int = 0):
+        """tokens int64 [K, ctx].  labels_per_image = k > 0 (LSegNetZS, lseg_net_zs.py:177-214): the K = B*k rows are
+        per-image label sets, image b is correlated with rows [b*k, (b+1)*k) and forward returns [B, k, H, W]."""
         tok = tokens.detach().to("cpu", torch.int64).contiguous()
         K, ctx = tok.shape
         arr = (C.c_int64 * (K * ctx)).from_buffer_copy(tok.numpy().tobytes())
         _lib.check(self.lib.lseg_set_text_tokens(self._h, arr, K, ctx))
+        _lib.check(self.lib.lseg_set_text_grouping(self._h, int(labels_per_image)))
         self._K = K
+        self._group = int(labels_per_image)
 
     def encode_text(self) -> torch.Tensor:
         _lib.check(self.lib.lseg_encode_text(self._h, C.c_void_p(_stream_ptr(self.device))))
@@ -131,7 +136,10 @@ class HipEngine:
         B, Cc, H, W = x.shape
         if (Cc, H, W) != (3, self.img_h, self.img_w):
             raise ValueError(f"engine was planned for 3x{self.img_h}x{self.img_w}, got {Cc}x{H}x{W}")
-        logits = torch.empty((B, self._K, H, W), dtype=torch.float32, device=self.device) if want_logits else None
+        Kout = self._group if self._group > 0 else self._K
+        if self._group > 0 and self._K != B * self._group:
+            raise ValueError(f"per-image label sets: {self._K} token rows != batch {B} x {self._group}")
+        logits = torch.empty((B, Kout, H, W), dtype=torch.float32, device=self.device) if want_logits else None
         amax = torch.empty((B, H // 2, W // 2), dtype=torch.uint8, device=self.device) if want_argmax else None
         _lib.check(self.lib.lseg_forward(
             self._h, C.c_void_p(x.data_ptr()), B,

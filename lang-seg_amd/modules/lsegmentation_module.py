@@ -21,27 +21,14 @@ except ImportError:          # no Lightning: keep the nn.Module protocol the eva
 
 try:
     from encoding.nn import SegmentationLosses
-    from encoding.utils import batch_pix_accuracy, batch_intersection_union, SegmentationMetric
+    from encoding.utils import SegmentationMetric
 except ImportError:
     SegmentationLosses = SegmentationMetric = None
 
-    def batch_pix_accuracy(output, target):
-        """[3P] encoding/utils/metrics.py."""
-        predict = torch.argmax(output.long() if output.dtype == torch.bool else output, 1) + 1
-        target = target.long() + 1
-        pixel_labeled = (target > 0).sum()
-        pixel_correct = ((predict == target) & (target > 0)).sum()
-        return pixel_correct.item(), pixel_labeled.item()
-
-    def batch_intersection_union(output, target, nclass):
-        predict = torch.argmax(output, 1) + 1
-        target = target.long() + 1
-        predict = predict * (target > 0).long()
-        intersection = predict * (predict == target).long()
-        area_inter = torch.histc(intersection.float().cpu(), bins=nclass, min=1, max=nclass)
-        area_pred = torch.histc(predict.float().cpu(), bins=nclass, min=1, max=nclass)
-        area_lab = torch.histc(target.float().cpu(), bins=nclass, min=1, max=nclass)
-        return area_inter.numpy(), (area_pred + area_lab - area_inter).numpy()
+# The metric step after the forward runs on the device (lseg_hip.metrics -> lseg_op_seg_stats): one pass over the
+# [B,K,H,W] scores instead of the reference's argmax + numpy histograms on the host
+# ([3P] encoding.utils.batch_pix_accuracy / batch_intersection_union, lsegmentation_module.py:49-50,59-60).
+from lseg_hip.metrics import batch_pix_accuracy, batch_intersection_union      # noqa: E402
 
 
 class LSegmentationModule(_Base):

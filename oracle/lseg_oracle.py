@@ -245,9 +245,14 @@ def correlate(image_features: Tensor, text_features: Tensor, logit_scale: float 
 
 def lseg_forward(sd: Dict[str, Tensor], x: Tensor, text: Tensor, cfg,
                  emulate_fp16: bool = True, text_features: Optional[Tensor] = None,
-                 return_intermediates: bool = False):
+                 return_intermediates: bool = False, labels_per_image: int = 0):
     """Full LSeg.forward.  sd keys are relative to `net.` (App. B of SURVEY.md);
-    x [B,3,H,W] fp32; text int64 [K, ctx].  Returns logits [B,K,H,W] fp32."""
+    x [B,3,H,W] fp32; text int64 [K, ctx].  Returns logits [B,K,H,W] fp32.
+
+    labels_per_image = k > 0 restates the zero-shot network instead (LSegNetZS.forward,
+    modules/models/lseg_net_zs.py:177-214): text holds B*k rows, image b is correlated with ITS rows
+    [b*k, (b+1)*k) only (:198-208: per-image lists of features, one GEMM per image, torch.cat) and the
+    result is [B,k,H,W]; no head blocks on that path."""
     inter = {}
     B, _, H, W = x.shape
     gh, gw = H // cfg.patch, W // cfg.patch
@@ -264,10 +269,18 @@ def lseg_forward(sd: Dict[str, Tensor], x: Tensor, text: Tensor, cfg,
     image_features = F.conv2d(path_1, sd["scratch.head1.weight"], sd["scratch.head1.bias"])  # :185
     imshape = image_features.shape
     imf = image_features.permute(0, 2, 3, 1).reshape(-1, imshape[1])  # :188
-    logits = correlate(imf, text_features, LOGIT_SCALE, emulate_fp16)  # :191-194
-    out = logits.view(imshape[0], imshape[2], imshape[3], -1).permute(0, 3, 1, 2)  # :196
+    if labels_per_image > 0:                                          # lseg_net_zs.py:198-208
+        k, P = labels_per_image, imshape[2] * imshape[3]
+        assert text_features.shape[0] == imshape[0] * k
+        per_image = [correlate(imf[b * P:(b + 1) * P], text_features[b * k:(b + 1) * k], LOGIT_SCALE, emulate_fp16)
+                     for b in range(imshape[0])]
+        outs = [l.view(1, imshape[2], imshape[3], -1).permute(0, 3, 1, 2) for l in per_image]
+        out = torch.cat(outs, dim=0)
+    else:
+        logits = correlate(imf, text_features, LOGIT_SCALE, emulate_fp16)  # :191-194
+        out = logits.view(imshape[0], imshape[2], imshape[3], -1).permute(0, 3, 1, 2)  # :196
     lowres = out
-    if cfg.arch_option in (1, 2):                                     # :198-201
+    if cfg.arch_option in (1, 2) and labels_per_image == 0:           # :198-201
         for _ in range(cfg.block_depth - 1):
             out = head_block(sd, cfg, out)
         out = head_block(sd, cfg, out, False)
@@ -277,3 +290,41 @@ def lseg_forward(sd: Dict[str, Tensor], x: Tensor, text: Tensor, cfg,
                      image_features=image_features, text_features=text_features, lowres=lowres)
         return out, inter
     return out
+
+
+# ---- the step after the path: metrics and loss value ([3P] torch-encoding @331ecdd) --------------
+def batch_pix_accuracy(output: Tensor, target: Tensor):
+    """encoding/utils/metrics.py batch_pix_accuracy (call sites modules/lsegmentation_module.py:49,59):
+    predict = argmax(output, 1) + 1; target = target + 1; labeled = sum(target > 0);
+    correct = sum((predict == target) * (target > 0))."""
+    predict = torch.max(output, 1)[1].long() + 1
+    tgt = target.long() + 1
+    labeled = int((tgt > 0).sum())
+    correct = int(((predict == tgt) & (tgt > 0)).sum())
+    return correct, labeled
+
+
+def batch_intersection_union(output: Tensor, target: Tensor, nclass: int):
+    """encoding/utils/metrics.py batch_intersection_union (call sites :50,60): predict = (argmax + 1) * (target + 1 > 0);
+    intersection = predict * (predict == target + 1); np.histogram(., bins=nclass, range=(1, nclass)) of
+    intersection / predict / target; union = pred + lab - inter.  Returns int64 tensors [nclass]."""
+    import numpy as np
+    predict = (torch.max(output, 1)[1].long() + 1).numpy()
+    tgt = (target.long() + 1).numpy()
+    predict = predict * (tgt > 0).astype(predict.dtype)
+    intersection = predict * (predict == tgt)
+    area_inter, _ = np.histogram(intersection, bins=nclass, range=(1, nclass))
+    area_pred, _ = np.histogram(predict, bins=nclass, range=(1, nclass))
+    area_lab, _ = np.histogram(tgt, bins=nclass, range=(1, nclass))
+    area_union = area_pred + area_lab - area_inter
+    return torch.from_numpy(area_inter.astype("int64")), torch.from_numpy(area_union.astype("int64"))
+
+
+def cross_entropy_value(output: Tensor, target: Tensor, ignore_index: int = -1) -> float:
+    """encoding/nn/loss.py SegmentationLosses with se_loss=False, aux=False (every reference run) ==
+    nn.CrossEntropyLoss(weight=None, ignore_index)(output, target): mean over non-ignored pixels of
+    -log_softmax(output, 1)[target] (call site modules/lsegmentation_module.py:72)."""
+    lsm = torch.log_softmax(output.double(), dim=1)
+    valid = target != ignore_index
+    picked = lsm.gather(1, target.clamp_min(0).unsqueeze(1)).squeeze(1)
+    return float(-(picked[valid]).sum() / valid.sum())

@@ -39,6 +39,26 @@ FULL = {
 }
 
 
+# zero-shot network (LSegNetZS.forward, lseg_net_zs.py:177-214): name -> (backbone, H, W, class_info, seed)
+FSS = os.path.join(ROOT, "lang-seg_amd", "label_files", "fewshot_fss.txt")
+ZS_CASES = {
+    "tiny16_64x64_zs": ("tiny16", 64, 64, (3, 0, 7), 5),
+}
+
+
+def run_zs_case(spec):
+    bb, H, W, class_info, seed = spec
+    cfg = get_config(bb, arch_option=0, block_depth=0, activation="lrelu")
+    sd = synthetic_state_dict(cfg, seed=seed)
+    names = read_labels(FSS)
+    # self.texts[class_i] = clip.tokenize(['others', label_list[class_i]])   (lseg_net_zs.py:170-176)
+    tok = torch.cat([synthetic_tokens(["others", names[c]], cfg.text.vocab, cfg.text.ctx) for c in class_info], 0)
+    x = synthetic_images(len(class_info), H, W, seed=seed)
+    with torch.no_grad():
+        out, inter = lseg_forward(sd, x, tok, cfg, return_intermediates=True, labels_per_image=2)
+    return cfg, sd, x, tok, out, inter
+
+
 def run_case(spec):
     bb, H, W, B, K, seed, arch, depth = spec
     cfg = get_config(bb, arch_option=arch, block_depth=depth, activation="lrelu")
@@ -64,6 +84,11 @@ def main():
                     "lowres": inter["lowres"].to(torch.float16),
                     "acts_mean_abs": [float(a.abs().mean()) for a in inter["acts"]],
                     "paths_mean_abs": [float(p.abs().mean()) for p in inter["paths"]]},
+                   os.path.join(gd, name + ".pt"))
+        print(name, tuple(out.shape), float(out.abs().mean()))
+    for name, spec in ZS_CASES.items():
+        cfg, sd, x, tok, out, inter = run_zs_case(spec)
+        torch.save({"spec": spec, "logits": out.clone(), "text_features": inter["text_features"].to(torch.float16)},
                    os.path.join(gd, name + ".pt"))
         print(name, tuple(out.shape), float(out.abs().mean()))
     if args.full:

@@ -230,3 +230,37 @@ def test_text_truncation_is_bit_exact():
         feats.append(eng.encode_text().clone())
         eng.close()
     assert torch.equal(feats[0], feats[1])
+
+
+def test_zero_shot_network_matches_oracle_and_golden(golden_dir):
+    """LSegNetZS.forward(x, class_info) (modules/models/lseg_net_zs.py:177-214) through the drop-in class:
+    every image is scored against its own ['others', class] pair; equals the oracle's restatement and the
+    committed golden, and equals the shared-label engine run image by image."""
+    import warnings
+    warnings.simplefilter("ignore")
+    from modules.models.lseg_net_zs import LSegNetZS
+    name = "tiny16_64x64_zs"
+    spec = MG.ZS_CASES[name]
+    cfg, sd, x, tok, ref, inter = MG.run_zs_case(spec)
+    names = read_labels(MG.FSS)
+    net = LSegNetZS(label_list=names[:16], backbone="tiny16", features=cfg.features, arch_option=0, block_depth=0,
+                    activation="lrelu")
+    net.load_state_dict(sd)
+    net = net.eval().cuda()
+    class_info = torch.tensor(spec[3])
+    with torch.no_grad():
+        out = net(x.cuda(), class_info)
+    assert out.shape == (len(spec[3]), 2, 64, 64) and out.dtype == torch.float32
+    g = torch.load(os.path.join(golden_dir, name + ".pt"))
+    assert (out.cpu() - ref).abs().max().item() <= LOGIT_TOL
+    assert (out.cpu() - g["logits"]).abs().max().item() <= LOGIT_TOL
+    # same numbers as the shared-label path run on each image alone with its pair
+    eng = HipEngine(cfg, 64, 64, max_batch=1, max_labels=2)
+    eng.load_state_dict(sd)
+    for b in range(x.shape[0]):
+        eng.set_tokens(tok[2 * b:2 * b + 2])
+        single = eng.forward(x[b:b + 1].cuda())
+        assert torch.equal(single[0], out[b])
+    # a wrong number of class ids is an error, not a silent broadcast
+    with pytest.raises(ValueError):
+        net(x.cuda(), class_info[:1])

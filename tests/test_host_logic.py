@@ -149,3 +149,25 @@ def test_shard_ranges_cover_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(e - s for s, e in spans) - min(e - s for s, e in spans) <= 1
+
+
+def test_zero_shot_module_surface(repo_root):
+    """LSegModuleZS / LSegNetZS keep the reference's constructor and attribute surface (modules/lseg_module_zs.py:20-73,
+    modules/models/lseg_net_zs.py:217-240): one ['others', <class>] token pair per class, same state-dict keys as LSegNet."""
+    import warnings
+    warnings.simplefilter("ignore")
+    import torch
+    from modules.lseg_module_zs import LSegModuleZS
+    from modules.models.lseg_net import LSegNet
+    from modules.models.lseg_net_zs import LSegNetZS, LSegRNNetZS
+    m = LSegModuleZS("nowhere", "fss", 1, 0.01, 1, backbone="tiny16", num_features=64, arch_option=0, block_depth=0,
+                     activation="lrelu", use_pretrained="False", aux=False)
+    assert isinstance(m.net, LSegNetZS) and m.len_dataloader == 1000 and len(m.net.texts) == 1000
+    assert tuple(m.net.texts[0].shape) == (2, 77) and m.net.texts[0].dtype == torch.int64
+    assert torch.equal(m.net.texts[0][0], m.net.texts[5][0])             # row 0 is always 'others'
+    ref = LSegNet(labels=["a"], backbone="tiny16", features=64, arch_option=0, block_depth=0, activation="lrelu")
+    assert list(m.net.state_dict().keys()) == list(ref.state_dict().keys())
+    with pytest.raises(RuntimeError):                                    # no CPU path
+        m(torch.zeros(1, 3, 64, 64), [0])
+    with pytest.raises(NotImplementedError):
+        LSegRNNetZS()

@@ -47,3 +47,18 @@ def test_correlation_is_left_associative():
     assert torch.equal(ours, left)
     assert not torch.equal(ours, right)
     assert ours.dtype == torch.float32 and torch.equal(ours, r16(ours))
+
+
+@pytest.mark.parametrize("name", sorted(MG.ZS_CASES))
+def test_zero_shot_case_matches_golden_and_the_shared_label_path(name, golden_dir):
+    """LSegNetZS.forward (lseg_net_zs.py:177-214): image b against its own ['others', class] pair.  Must equal
+    running the shared-label forward on image b alone with those two labels."""
+    from oracle.lseg_oracle import lseg_forward
+    g = torch.load(os.path.join(golden_dir, name + ".pt"))
+    cfg, sd, x, tok, out, inter = MG.run_zs_case(MG.ZS_CASES[name])
+    assert out.shape == g["logits"].shape == (x.shape[0], 2, x.shape[2], x.shape[3])
+    assert torch.allclose(out, g["logits"], atol=2e-3, rtol=0)
+    for b in range(x.shape[0]):
+        with torch.no_grad():
+            single = lseg_forward(sd, x[b:b + 1], tok[2 * b:2 * b + 2], cfg)
+        assert torch.allclose(single[0], out[b], atol=2e-3, rtol=0)
