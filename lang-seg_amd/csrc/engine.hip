@@ -214,7 +214,7 @@ int Engine::pack_conv3(const std::string& wkey, const std::string& bnp, const st
     }
     if (!out.w) ALLOC(out.w, uint16_t, (size_t)cop * 9 * cip);          // zero-initialised: padding stays 0
     const bool has_bias = bw || cb;
-    if (has_bias && !out.b) ALLOC(out.b, float, cop);
+    if (!out.b) ALLOC(out.b, float, cop);          // bias-less convs (layerN_rn) get zeros: keeps them on the specialised epilogue
     out.n = cop; out.k = 9 * cip;
     return launch_pack_conv3x3((const float*)w.ptr, bw, bb, bm, bv, 1e-5f, cb, out.w, has_bias ? out.b : nullptr, co, ci, cip, img_dt_, st);
 }

@@ -337,6 +337,7 @@ enum Epi {
     EPI_LIN16_GELU = 2,   // C[m*ldc+n] = T(gelu(acc + bias))                (MLP fc1)
     EPI_RES32 = 3,        // C[m*ldc+n] = res[m*ldc+n] + acc + bias, fp32    (attention proj / MLP fc2 on the residual stream)
     EPI_QKV16 = 4,        // MAP_QKV, q,k -> [b,head,t,d], v -> [b,head,d,t]
+    EPI_PAD16 = 5,        // MAP_PADDED NHWC (1-pixel zero border), T(act(acc + bias) [+ res [+ res2]]): the DPT head's 3x3 convs
 };
 
 // two adjacent 16-column sub-tiles (4 columns per lane each) -> 8 contiguous columns (16 bytes) per lane
@@ -410,6 +411,54 @@ __device__ __forceinline__ void fast_epilogue(const GemmArgs& g, f32x4_t (&acc)[
                         *reinterpret_cast<float4*>(p + i * 16) =
                             make_float4(v[0] + rv[jl][i].x, v[1] + rv[jl][i].y, v[2] + rv[jl][i].z, v[3] + rv[jl][i].w);
                 });
+            });
+        });
+    } else if constexpr (EPI == EPI_PAD16) {
+        // m = (b, y, x) on the (ho, wo) output grid -> row of the padded NHWC map; columns are contiguous channels.
+        // Residuals (the RCU skip input and, for the fusion add, the other path) live at the destination offsets.
+        const bool relu = g.act == ACT_RELU, has_res = g.res_mode == RES_DEST, has_res2 = has_res && g.res2 != nullptr;
+        const int hw = g.ho * g.wo;
+        static_for<0, MI>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int m = mrow0 + j * 16 + ml;
+            const int mm = m < g.M ? m : g.M - 1;
+            const int b = mm / hw, p = mm - b * hw;
+            const int y = p / g.wo, x = p - y * g.wo;
+            const size_t r0 = ((size_t)(b * (g.ho + 2) + y + 1) * (g.wo + 2) + x + 1) * g.ldc + ncol0;
+            uint2 rv[NI], rv2[NI];
+            if (has_res) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) rv[i] = *reinterpret_cast<const uint2*>((const uint16_t*)g.res + r0 + i * 16 + r16 * 4);
+                if (has_res2) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) rv2[i] = *reinterpret_cast<const uint2*>((const uint16_t*)g.res2 + r0 + i * 16 + r16 * 4);
+                }
+            }
+            uint16_t* prow = (uint16_t*)g.C + r0 + cw;
+            static_for<0, NI / 2>([&](auto pc) {
+                constexpr int i = 2 * decltype(pc)::value;
+                float x4[2][4];
+                biased(std::integral_constant<int, i>{}, jc, x4[0]);
+                biased(std::integral_constant<int, i + 1>{}, jc, x4[1]);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (relu) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) x4[q][r] = x4[q][r] > 0.f ? x4[q][r] : 0.f;
+                    }
+                    if (has_res) {
+                        const uint2 u = rv[i + q];
+                        x4[q][0] += to_f32<T>((uint16_t)u.x); x4[q][1] += to_f32<T>((uint16_t)(u.x >> 16));
+                        x4[q][2] += to_f32<T>((uint16_t)u.y); x4[q][3] += to_f32<T>((uint16_t)(u.y >> 16));
+                        if (has_res2) {
+                            const uint2 u2 = rv2[i + q];
+                            x4[q][0] += to_f32<T>((uint16_t)u2.x); x4[q][1] += to_f32<T>((uint16_t)(u2.x >> 16));
+                            x4[q][2] += to_f32<T>((uint16_t)u2.y); x4[q][3] += to_f32<T>((uint16_t)(u2.y >> 16));
+                        }
+                    }
+                }
+                const uint4 o = widen16<T>(x4[0], x4[1]);
+                if (m < g.M) *reinterpret_cast<uint4*>(prow + i * 16) = o;
             });
         });
     } else if constexpr (EPI == EPI_QKV16) {
@@ -1141,7 +1190,7 @@ int pick_tile(const GemmArgs& g, hipStream_t stream) {
     const long t_mid = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
     static const int force = getenv("LSEG_GEMM_TILE") ? atoi(getenv("LSEG_GEMM_TILE")) : 0;   // 1 small 2 mid (3 big 4 ping-pong)
     int pick = t_mid >= 192 ? 2 : 1;
-    if (!CONV && EPI != EPI_GENERIC && pick == 2) {
+    if (EPI != EPI_GENERIC && pick == 2) {
         // 256x256 tiles (one 8-wave workgroup per CU) move half the operand bytes per MFMA through the
         // CU's L1/LDS-DMA path and run ~12% faster per flop than two 128x128 workgroups -- when the
         // tile count quantises well over the 256 CUs.  Persistent schedules: ceil(tiles / slots) rounds.
@@ -1151,7 +1200,7 @@ int pick_tile(const GemmArgs& g, hipStream_t stream) {
         if (time_huge < time_mid) pick = 6;
     }
     if (force) pick = force;
-    if constexpr (!CONV && EPI != EPI_GENERIC) {
+    if constexpr (EPI != EPI_GENERIC) {
         if (pick == 6) return launch_one<T, CfgHuge, CONV, RELU_IN, EPI, TAG>(g, stream);
     }
     if (pick == 6) pick = 2;
@@ -1167,8 +1216,14 @@ template <typename T>
 int select_epi(const GemmArgs& g) {
     constexpr int dt = std::is_same<T, BF16>::value ? DT_BF16 : DT_F16;
     static const bool off = getenv("LSEG_GEMM_GENERIC_EPI") != nullptr;       // A/B switch (tools)
-    if (off || (g.dbg & 3) || !g.bias || g.bias_mod || g.round_mid || (g.res2 && !(g.dbg & 4)) || (g.N % 128) != 0) return EPI_GENERIC;
+    if (off || (g.dbg & 3) || !g.bias || g.bias_mod || g.round_mid || (g.N % 128) != 0) return EPI_GENERIC;
+    if (g.res2 && !(g.dbg & 4) && g.map_mode != MAP_PADDED) return EPI_GENERIC;
     if ((reinterpret_cast<uintptr_t>(g.C) & 15) || (reinterpret_cast<uintptr_t>(g.bias) & 15)) return EPI_GENERIC;
+    if (g.map_mode == MAP_PADDED && g.out_dtype == dt && (g.ldc % 8) == 0 && (g.act == ACT_NONE || g.act == ACT_RELU) &&
+        (g.res_mode == RES_NONE || (g.res_mode == RES_DEST && g.res_dtype == dt &&
+                                    !((reinterpret_cast<uintptr_t>(g.res) | reinterpret_cast<uintptr_t>(g.res2)) & 7))))
+        return EPI_PAD16;
+    if (g.conv) return EPI_GENERIC;
     if (g.map_mode == MAP_LINEAR && g.res_mode == RES_NONE && g.out_dtype == dt && (g.ldc % 8) == 0) {
         if (g.act == ACT_NONE) return EPI_LIN16;
         if (g.act == ACT_GELU) return EPI_LIN16_GELU;
@@ -1191,12 +1246,18 @@ int dispatch(const GemmArgs& g, hipStream_t stream) {
             return set_error(LSEG_ERR_UNSUPPORTED, "fused head needs a plain GEMM with N == 512 and a bias");
         return launch_one<T, CfgRow, false, false, EPI_GENERIC, 0>(g, stream);
     }
+    const int epi = select_epi<T>(g);
     if (g.conv) {
+        if (epi == EPI_PAD16) {
+            if (g.relu_in) return pick_tile<T, true, true, EPI_PAD16, 0>(g, stream);
+            return pick_tile<T, true, false, EPI_PAD16, 0>(g, stream);
+        }
         if (g.relu_in) return pick_tile<T, true, true, EPI_GENERIC, 0>(g, stream);
         return pick_tile<T, true, false, EPI_GENERIC, 0>(g, stream);
     }
     if (g.relu_in) return set_error(LSEG_ERR_UNSUPPORTED, "gemm: relu_in is only implemented for the conv path");
-    switch (select_epi<T>(g)) {
+    switch (epi) {
+        case EPI_PAD16: return pick_tile<T, false, false, EPI_PAD16, 0>(g, stream);
         case EPI_LIN16: return pick_tile<T, false, false, EPI_LIN16, 0>(g, stream);
         case EPI_LIN16_GELU:
             if (g.tag == 1) return pick_tile<T, false, false, EPI_LIN16_GELU, 1>(g, stream);
