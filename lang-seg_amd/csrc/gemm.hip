@@ -286,6 +286,7 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& g, int m, const int
     if (wide) {
 #pragma unroll
         for (int i = 0; i < NI; i += 2) {
+            if (ncol[i] >= g.N) continue;      // whole 32-column pair beyond N (wave-uniform: N % 32 == 0), e.g. N = 64 on a 128-wide tile
             if (cpw[i / 2].which == 2) {       // V^T of MAP_QKV: strided, scalar stores
 #pragma unroll
                 for (int q = i; q < i + 2; ++q)
@@ -462,39 +463,36 @@ __device__ __forceinline__ void fast_epilogue(const GemmArgs& g, f32x4_t (&acc)[
             });
         });
     } else if constexpr (EPI == EPI_QKV16) {
-        // a wave's 64 columns are one head of one of q / k / v (wave-uniform)
-        const int which = ncol0 / g.qkv_dim;
-        const int head = (ncol0 - which * g.qkv_dim) >> 6;
-        const int d0 = (ncol0 - which * g.qkv_dim) & 63;      // 0 for 64-wide wave tiles, 0|32 for the 32-wide ones
+        // every 32-column pair of a wave lies inside one head of one of q / k / v (wave-uniform per pair); a wave's
+        // 64 or 128 columns may span two heads (128-wide wave tiles) or a q|k|v boundary (dim not a multiple of WN)
         static_for<0, MI>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             const int m = mrow0 + j * 16 + ml;
             const int mm = m < g.M ? m : g.M - 1;
             const int b = mm / g.qkv_ntok, t = mm - b * g.qkv_ntok;
-            const size_t bh = (size_t)b * g.qkv_heads + head;
-            if (which < 2) {
-                uint16_t* p = (uint16_t*)(which ? g.Ck : g.C) + (bh * g.qkv_npad + t) * 64 + d0 + cw;
-                static_for<0, NI / 2>([&](auto pc) {
-                    constexpr int i = 2 * decltype(pc)::value;
-                    float x[4], y[4];
-                    biased(std::integral_constant<int, i>{}, jc, x);
-                    biased(std::integral_constant<int, i + 1>{}, jc, y);
+            static_for<0, NI / 2>([&](auto pc) {
+                constexpr int i = 2 * decltype(pc)::value;
+                const int c0 = ncol0 + i * 16;                            // first column of the pair
+                const int which = c0 / g.qkv_dim, rem = c0 - which * g.qkv_dim;
+                const int head = rem >> 6, d0 = rem & 63;                 // d0 in {0, 32}
+                const size_t bh = (size_t)b * g.qkv_heads + head;
+                float x[4], y[4];
+                biased(std::integral_constant<int, i>{}, jc, x);
+                biased(std::integral_constant<int, i + 1>{}, jc, y);
+                if (which < 2) {
+                    uint16_t* p = (uint16_t*)(which ? g.Ck : g.C) + (bh * g.qkv_npad + t) * 64 + d0 + cw;
                     const uint4 o = widen16<T>(x, y);
-                    if (m < g.M) *reinterpret_cast<uint4*>(p + i * 16) = o;
-                });
-            } else {
-                // V^T [b, head, d, t]: t is the contiguous axis; 16 lanes write 16 consecutive tokens
-                uint16_t* p = (uint16_t*)g.Cv + (bh * 64 + d0 + r16 * 4) * g.qkv_npad + t;
-                static_for<0, NI>([&](auto ic) {
-                    constexpr int i = decltype(ic)::value;
-                    float v[4];
-                    biased(ic, jc, v);
-                    if (m < g.M) {
+                    if (m < g.M) *reinterpret_cast<uint4*>(p) = o;
+                } else if (m < g.M) {
+                    // V^T [b, head, d, t]: t is the contiguous axis; 16 lanes write 16 consecutive tokens
+                    uint16_t* p = (uint16_t*)g.Cv + (bh * 64 + d0 + r16 * 4) * g.qkv_npad + t;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) p[(size_t)(i * 16 + r) * g.qkv_npad] = from_f32<T>(v[r]);
+                    for (int r = 0; r < 4; ++r) {
+                        p[(size_t)r * g.qkv_npad] = from_f32<T>(x[r]);
+                        p[(size_t)(16 + r) * g.qkv_npad] = from_f32<T>(y[r]);
                     }
-                });
-            }
+                }
+            });
         });
     }
 }
@@ -1200,6 +1198,7 @@ int pick_tile(const GemmArgs& g, hipStream_t stream) {
         if (time_huge < time_mid) pick = 6;
     }
     if (force) pick = force;
+    if (pick == 6 && (g.N % 256) != 0) pick = 2;      // the specialised epilogues write whole tile rows: N must be a multiple of BN
     if constexpr (EPI != EPI_GENERIC) {
         if (pick == 6) return launch_one<T, CfgHuge, CONV, RELU_IN, EPI, TAG>(g, stream);
     }

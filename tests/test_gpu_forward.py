@@ -264,3 +264,25 @@ def test_zero_shot_network_matches_oracle_and_golden(golden_dir):
     # a wrong number of class ids is an error, not a silent broadcast
     with pytest.raises(ValueError):
         net(x.cuda(), class_info[:1])
+
+
+def test_vitl16_batch_of_8_equals_single_image_runs():
+    """The tile configuration follows the problem size (256x256 tiles once M = B*901 is large), so a batch must be
+    checked against the single-image runs that the oracle comparison above validates: every GEMM accumulates K in the
+    same order whatever the tile, so the logits have to agree to fp32 round-off."""
+    spec = MG.FULL["vitl16_480_k150"]
+    bb, H, W, _, K, seed, arch, depth = spec
+    cfg = get_config(bb, arch_option=arch, block_depth=depth, activation="lrelu")
+    sd = synthetic_state_dict(cfg, seed=seed)
+    tok = synthetic_tokens(read_labels(MG.LABELS)[:K], cfg.text.vocab, cfg.text.ctx)
+    x = synthetic_images(8, H, W, seed=seed + 7).cuda()
+    eng = HipEngine(cfg, H, W, max_batch=8, max_labels=K)
+    eng.load_state_dict(sd)
+    eng.set_tokens(tok)
+    batch = eng.forward(x, want_logits=False, want_argmax=True)
+    low8 = eng.intermediate("lowres", (8, K, H // 2, W // 2))
+    for b in (0, 5):
+        am1 = eng.forward(x[b:b + 1], want_logits=False, want_argmax=True)
+        low1 = eng.intermediate("lowres", (1, K, H // 2, W // 2))
+        assert (low1[0] - low8[b]).abs().max().item() <= 1e-3
+        assert (am1[0] != batch[b]).float().mean().item() <= 1e-4
