@@ -3,7 +3,7 @@
 
 Workload (config.workload): BASELINE.json configs[1] -- ViT-L/16 + DPT head + CLIP text tower,
 480x480, K=150 ADE20K labels, bf16 MFMA inference -- `--batch` images per GPU per step
-(default 8), synthetic seeded weights and images (no network: no checkpoints/datasets).
+(default 32), synthetic seeded weights and images (no network: no checkpoints/datasets).
 One "step" = one LSegNet.forward call on one batch, INCLUDING the CLIP text tower, which the
 reference re-runs on every forward (modules/models/lseg_net.py:183); `--cache-text` reports the
 cached variant in an extra field but never changes `value`.
@@ -120,6 +120,16 @@ def main():
     eng.set_profiling(False)
     dt = D.max_over_ranks(dt, device="cuda")
     assert torch.isfinite(out).all(), "non-finite logits"
+    # Self-check outside the timed region: the tile configuration follows the problem size, so the batch the bench
+    # times is checked against a single-image run of the same engine -- the configuration the oracle-parity tests
+    # validate (tests/test_gpu_forward.py).  A mismatch voids the number.
+    h2 = args.size // 2
+    low_b = eng.intermediate("lowres", (B, K, h2, h2))[0].clone()
+    eng.forward(x[:1], want_logits=False, want_argmax=True)
+    low_1 = eng.intermediate("lowres", (1, K, h2, h2))[0]
+    selfcheck = (low_b - low_1).abs().max().item()
+    if not selfcheck <= 1e-2:
+        raise SystemExit(f"bench self-check failed: batch-of-{B} logits differ from the single-image run by {selfcheck}")
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -138,7 +148,8 @@ def main():
         if fc1["launches"]:
             avg_ms = fc1["total_ms"] / fc1["launches"]
             ach = fc1["flops_per_launch"] / (avg_ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "kernel": "lseg_gemm_kernel<bf16,128,128,tag=1> (ViT MLP fc1 + bias + GELU)",
+            roof = {"bound": "mfma", "kernel": "lseg_gemm_kernel<BF16, TileCfg<256,256,..> | <128,128,..>, EPI_LIN16_GELU, TAG=1> "
+                                             "(ViT MLP fc1 + bias + GELU; tile by problem size)",
                     "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "avg_launch_ms": round(avg_ms, 5), "launches": fc1["launches"],
@@ -158,6 +169,7 @@ def main():
             "path_frac_of_mfma_peak": round(gf_step / (ms * 1e-3) / 1e3 / PEAK_BF16_TFLOPS, 4),
             "engine_forward_ms_hip_events": round(fwd["total_ms"] / max(1, fwd["launches"]), 4),
             "roofline": roof,
+            "selfcheck_batch_vs_single_max_abs": round(selfcheck, 6),
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or min(32, os.cpu_count() or 1)

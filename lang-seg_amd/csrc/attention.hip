@@ -91,12 +91,14 @@ __global__ __launch_bounds__(256, 3) void lseg_attention_kernel(const AttnArgs a
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
     float m_run = -1e30f, l_run = 0.f;
     const int qrow = q0 + ql;
+    const bool live = q0 < a.ntok;      // wave-uniform (ntok = 901: 3 of the last block's 4 waves are padding only)
 
     issue(0, 0);
     for (int t = 0; t < n_tiles; ++t) {
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         if (t + 1 < n_tiles) issue(t + 1, (t + 1) & 1);
+        if (!live) continue;            // this wave's 32 query rows are all padding: it only streams K/V for the others
         const char* sk = smem + (t & 1) * STAGE;
         const char* sv = sk + TILE;
 
