@@ -5,10 +5,12 @@ HBM-side traffic of the profiled MLP fc1 GEMM (the TAG=1 kernel symbol), per lau
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "profiles", "summary.json")
-batch = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 36
 pmc = json.load(open(src))["pmc"]
 name = [k for k in pmc if "lseg_gemm_kernel" in k and k.rstrip().endswith(", 1>(lseg::GemmArgs)")]
-assert len(name) == 1, name
+# the bench's self-check adds one single-image forward (a smaller tile configuration of the same tagged kernel):
+# the timed batch is the instance with the larger per-launch MFMA count
+name.sort(key=lambda k: -pmc[k].get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0))
 c = pmc[name[0]]
 M, N, K = batch * 901, 4096, 1024
 out = {"mlp_fc1_gemm": {
