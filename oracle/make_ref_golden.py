@@ -1,0 +1,122 @@
+"""Golden vectors from the REFERENCE'S OWN CODE (tests/golden/ref_*.pt).  TEST INFRASTRUCTURE.
+
+Runs /root/reference/modules/models/{lseg_net,lseg_net_zs}.py -- LSegNet / LSegNetZS construction, forward_vit /
+forward_flex / _resize_pos_embed, the activation hooks, ProjectReadout, act_postprocess, scratch.layerN_rn, the four
+FeatureFusionBlock_custom, head1, the normalise + left-associative fp16 correlation, the head blocks, output_conv --
+on CPU with seeded synthetic weights, and stores inputs' seeds + outputs.  The reference imports timm / clip /
+torchvision, which are not installed: oracle/ref_stubs/ provides stand-ins for exactly the symbols it touches (a timm
+0.4.12 VisionTransformer module tree; CLIP's text tower on torch's nn.MultiheadAttention, fp16 weights).  Everything
+else executing here is reference code, unmodified, loaded from where it lies.
+
+Only runs in the build container (needs /root/reference); the fixtures travel.  tests/test_oracle_ref_golden.py checks
+the oracle against them (CPU) and tests/test_gpu_forward.py the HIP engine (GPU).
+
+    python oracle/make_ref_golden.py
+"""
+import importlib
+import os
+import sys
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.path.insert(0, os.path.join(ROOT, "oracle", "ref_stubs"))        # timm, clip, torchvision stand-ins
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "lang-seg_amd"))
+
+from lseg_hip.config import get_config                                    # noqa: E402
+from lseg_hip.synth import synthetic_state_dict, synthetic_images, read_labels   # noqa: E402
+
+LABELS = os.path.join(ROOT, "lang-seg_amd", "label_files", "ade20k_objectInfo150.txt")
+FSS = os.path.join(ROOT, "lang-seg_amd", "label_files", "fewshot_fss.txt")
+
+# name -> (backbone, H, W, B, K, seed, arch_option, block_depth)
+REF_CASES = {
+    "ref_vitl16_96x96_k5": ("clip_vitl16_384", 96, 96, 1, 5, 11, 0, 0),
+    "ref_vitl16_64x96_k7_b2": ("clip_vitl16_384", 64, 96, 2, 7, 12, 0, 0),
+    "ref_vitb32_128x128_k7": ("clip_vitb32_384", 128, 128, 1, 7, 13, 0, 0),
+    "ref_vitl16_96x96_k5_arch1": ("clip_vitl16_384", 96, 96, 1, 5, 14, 1, 2),
+    "ref_vitl16_96x96_k5_arch2": ("clip_vitl16_384", 96, 96, 1, 5, 15, 2, 2),
+}
+# zero-shot: name -> (backbone, H, W, class_info, seed)
+REF_ZS_CASES = {
+    "ref_vitl16_96x96_zs": ("clip_vitl16_384", 96, 96, (4, 0, 9), 16),
+}
+
+
+def reference_models():
+    """The reference's modules/models directory as a synthetic package `refmodels` (it has no __init__.py, and our
+    own drop-in package is also called `modules`)."""
+    if "refmodels" not in sys.modules:
+        pkg = types.ModuleType("refmodels")
+        pkg.__path__ = [os.path.join(REF, "modules", "models")]
+        sys.modules["refmodels"] = pkg
+    return importlib.import_module("refmodels.lseg_net"), importlib.import_module("refmodels.lseg_net_zs")
+
+
+def load_synthetic(net, sd):
+    res = net.load_state_dict(sd, strict=False)
+    missing = [k for k in res.missing_keys if not k.startswith("clip_pretrained.visual.")]
+    unexpected = [k for k in res.unexpected_keys if not k.startswith("clip_pretrained.visual.")]
+    assert not missing and not unexpected, (missing[:8], unexpected[:8])     # App. B key layout == the reference's module tree
+    return net.eval()
+
+
+def run_ref_case(spec):
+    bb, H, W, B, K, seed, arch, depth = spec
+    lseg_net, _ = reference_models()
+    cfg = get_config(bb, arch_option=arch, block_depth=depth, activation="lrelu")
+    sd = synthetic_state_dict(cfg, seed=seed)
+    labels = read_labels(LABELS)[:K]
+    net = lseg_net.LSegNet(labels=labels, backbone=bb, features=cfg.features, crop_size=H, arch_option=arch,
+                           block_depth=depth, activation="lrelu")
+    load_synthetic(net, sd)
+    x = synthetic_images(B, H, W, seed=seed)
+    taps = {}
+    net.scratch.head1.register_forward_hook(lambda m, i, o: taps.__setitem__("image_features", o.detach().clone()))
+    net.scratch.refinenet1.register_forward_hook(lambda m, i, o: taps.__setitem__("path_1", o.detach().clone()))
+    enc = net.clip_pretrained.encode_text
+    net.clip_pretrained.encode_text = lambda t: taps.setdefault("text_features", enc(t).detach().clone())
+    with torch.no_grad():
+        out = net(x)
+    acts = [net.pretrained.activations[str(i)].detach().clone() for i in (1, 2, 3, 4)]
+    return cfg, sd, x, net.text, out, taps, acts
+
+
+def run_ref_zs_case(spec):
+    bb, H, W, class_info, seed = spec
+    _, lseg_net_zs = reference_models()
+    cfg = get_config(bb, arch_option=0, block_depth=0, activation="lrelu")
+    sd = synthetic_state_dict(cfg, seed=seed)
+    names = read_labels(FSS)[:16]
+    net = lseg_net_zs.LSegNetZS(label_list=names, backbone=bb, features=cfg.features, aux=False, use_pretrained=False,
+                                arch_option=0, block_depth=0, activation="lrelu")
+    load_synthetic(net, sd)
+    x = synthetic_images(len(class_info), H, W, seed=seed)
+    with torch.no_grad():
+        out = net(x, list(class_info))
+    tok = torch.cat([net.texts[c] for c in class_info], 0)
+    return cfg, sd, x, tok, out
+
+
+def main():
+    gd = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(gd, exist_ok=True)
+    for name, spec in REF_CASES.items():
+        cfg, sd, x, text, out, taps, acts = run_ref_case(spec)
+        torch.save({"spec": spec, "tokens": text.clone(), "logits": out.clone(),
+                    "text_features": taps["text_features"].to(torch.float16),
+                    "path_1_sub4": taps["path_1"][:, :, ::4, ::4].to(torch.float16).clone(),
+                    "acts": [a.to(torch.float16) for a in acts]},
+                   os.path.join(gd, name + ".pt"))
+        print(name, tuple(out.shape), float(out.abs().mean()))
+    for name, spec in REF_ZS_CASES.items():
+        cfg, sd, x, tok, out = run_ref_zs_case(spec)
+        torch.save({"spec": spec, "tokens": tok.clone(), "logits": out.clone()}, os.path.join(gd, name + ".pt"))
+        print(name, tuple(out.shape), float(out.abs().mean()))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,59 @@
+"""The oracle against fixtures produced by the REFERENCE'S OWN CODE (tests/golden/ref_*.pt, generator
+oracle/make_ref_golden.py: /root/reference/modules/models/lseg_net.py + lseg_net_zs.py executed on CPU with the
+third-party imports stood in by oracle/ref_stubs).  This is what pins the restatement of everything that lives in the
+reference repository: LSegNet/LSegNetZS.forward orchestration, forward_flex + pos-embed resize, hooks, ProjectReadout,
+act_postprocess, layerN_rn, FeatureFusionBlock_custom/ResidualConvUnit_custom (eval BatchNorm), head1, normalise +
+left-associative fp16 correlation, bottleneck/depthwise head blocks, output_conv.  Tolerances: fp32 stages 1e-3
+relative (different summation order only); fp16-valued tensors a few fp16 ulps (torch's CPU half kernels vs the
+oracle's round-after-fp32 emulation)."""
+import os
+
+import pytest
+import torch
+
+from lseg_hip.config import get_config
+from lseg_hip.synth import synthetic_state_dict, synthetic_images
+from oracle.lseg_oracle import lseg_forward
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+REF = sorted(f[:-3] for f in os.listdir(GOLD) if f.startswith("ref_") and not f.endswith("_zs.pt"))
+REF_ZS = sorted(f[:-3] for f in os.listdir(GOLD) if f.startswith("ref_") and f.endswith("_zs.pt"))
+
+
+def relerr(a, b):
+    return ((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-12)).item()
+
+
+@pytest.mark.parametrize("name", REF)
+def test_oracle_matches_reference_code(name):
+    g = torch.load(os.path.join(GOLD, name + ".pt"))
+    bb, H, W, B, K, seed, arch, depth = g["spec"]
+    cfg = get_config(bb, arch_option=arch, block_depth=depth, activation="lrelu")
+    sd = synthetic_state_dict(cfg, seed=seed)
+    x = synthetic_images(B, H, W, seed=seed)
+    with torch.no_grad():
+        out, inter = lseg_forward(sd, x, g["tokens"], cfg, return_intermediates=True)
+    for l in range(4):                                                   # hooked activations (fp32 tower)
+        assert relerr(inter["acts"][l], g["acts"][l]) < 2e-3, (name, l)  # fixture stored as fp16
+    assert relerr(inter["paths"][0][:, :, ::4, ::4], g["path_1_sub4"]) < 2e-3
+    assert (inter["text_features"].float() - g["text_features"].float()).abs().max() <= 2e-2 * g["text_features"].float().abs().max()
+    assert out.shape == g["logits"].shape
+    scale = g["logits"].abs().max().item()
+    assert (out - g["logits"]).abs().max().item() <= 4e-3 * max(1.0, scale), (name, (out - g["logits"]).abs().max().item())
+    # arg-max masks of the final logits: identical except where the reference's own top-2 margin is within the tolerance
+    top2 = g["logits"].topk(2, dim=1).values
+    decisive = (top2[:, 0] - top2[:, 1]) > 8e-3 * max(1.0, scale)
+    assert torch.equal(out.argmax(1)[decisive], g["logits"].argmax(1)[decisive])
+
+
+@pytest.mark.parametrize("name", REF_ZS)
+def test_oracle_zero_shot_matches_reference_code(name):
+    g = torch.load(os.path.join(GOLD, name + ".pt"))
+    bb, H, W, class_info, seed = g["spec"]
+    cfg = get_config(bb, arch_option=0, block_depth=0, activation="lrelu")
+    sd = synthetic_state_dict(cfg, seed=seed)
+    x = synthetic_images(len(class_info), H, W, seed=seed)
+    with torch.no_grad():
+        out = lseg_forward(sd, x, g["tokens"], cfg, labels_per_image=2)
+    assert out.shape == g["logits"].shape == (len(class_info), 2, H, W)
+    assert (out - g["logits"]).abs().max().item() <= 4e-3 * max(1.0, g["logits"].abs().max().item())
