@@ -127,7 +127,7 @@ def main():
     # validate (tests/test_gpu_forward.py).  A mismatch voids the number.
     h2 = args.size // 2
     low_b = eng.intermediate("lowres", (B, K, h2, h2))[0].clone()
-    eng.forward(x[:1], want_logits=False, want_argmax=True)
+    eng.forward(x[:1])
     low_1 = eng.intermediate("lowres", (1, K, h2, h2))[0]
     selfcheck = (low_b - low_1).abs().max().item()
     if not selfcheck <= 1e-2:
