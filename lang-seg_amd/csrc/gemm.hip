@@ -922,245 +922,6 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
     wait_vmcnt<0>();     // drain the never-consumed tail loads before the LDS is released
 }
 
-#ifdef LSEG_GEMM_EXPERIMENTAL   // kept for reference: slower than CfgMid at every ViT shape
-// ================================================================================================
-// "Ping-pong" kernel for large problems: 256x128 tile, 8 waves, 3-stage LDS ring (144 KB, one
-// workgroup per CU).  The workgroup is two 4-wave groups (G0 = waves 0-3 -> tile rows 0-127,
-// G1 = waves 4-7 -> rows 128-255; waves w and w+4 share a SIMD).  Time is cut into segments
-// separated by workgroup barriers; in every segment one group runs COMPUTE (32 MFMAs straight from
-// registers) while the other runs LOAD (its 6 direct-to-LDS loads of K-step L+2, then the 16
-// fragment reads of K-step L into registers).  The groups are one segment out of phase, so each
-// SIMD's matrix pipe always has exactly one wave feeding it while its partner does the memory work
-// -- the role split that the two-independent-workgroups kernel above only gets by accident.
-//
-//   segment 2T   : G0 COMPUTE(T)      | G1 LOAD(T)         -> every wave: vmcnt(6), barrier
-//   segment 2T+1 : G0 LOAD(T+1)       | G1 COMPUTE(T)      -> barrier
-//
-// Hazards (X = K-step, stage X%3):  RAW -- step X is issued in LOAD(X-2) segments (2X-5 by G0,
-// 2X-4 by G1) and first read in segment 2X-1; every wave waits vmcnt(6) (= all but its newest
-// share) before the barrier that closes segment 2X-2.  WAR -- stage X%3 is last read in segment 2X
-// (G1) and first refilled in segment 2X+1 (G0's LOAD(X+1) issues step X+3); the fragment reads are
-// drained (lgkmcnt(0)) before the closing barrier of their segment.
-// ================================================================================================
-template <typename T, bool CONV, bool RELU_IN, int TAG>
-__global__ __launch_bounds__(512, 2) void lseg_gemm_pp_kernel(const GemmArgs g) {
-    constexpr int BM = 256, BN = 128, NS = 3, NW = 8, WM = 64, WN = 64, MI = 4, NI = 4;
-    constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128, A_SPW = 4, W_SPW = 2, SPW = 6;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const GemmArgs& gk = *reinterpret_cast<const GemmArgs*>((const void*)__builtin_amdgcn_kernarg_segment_ptr());
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0..7, wave-uniform
-    const int grp = w >> 2, wm2 = (w >> 1) & 1, wn = w & 1;
-
-    const int tiles_n = (g.N + BN - 1) / BN;
-    const int tiles_m = (g.M + BM - 1) / BM;
-    const int total = tiles_m * tiles_n;
-    const int wpx = gridDim.x >> 3;
-    int tile, tile_end;
-    {
-        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-        const int q = total >> 3, r = total & 7;
-        const int xs = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-        tile = xs + idx;
-        tile_end = xs + q + (xcd < r ? 1 : 0);
-    }
-    if (tile >= tile_end) return;
-
-    // ---- load side state: walks (tile, K-step) in order, two K-steps ahead of the fragment reads ----
-    uint32_t a_off[A_SPW], w_off[W_SPW];
-    const int lrow = lane >> 3;
-    auto setup = [&](int t) {
-        int mb, nb;
-        tile_coords(t, tiles_m, tiles_n, mb, nb);
-        const int m0 = mb * BM, n0 = nb * BN;
-#pragma unroll
-        for (int s = 0; s < A_SPW; ++s) {
-            const int r = (s * NW + w) * 8 + lrow;
-            int m = m0 + r;
-            if (m > g.M - 1) m = g.M - 1;
-            uint32_t e;
-            if (CONV) {
-                const int hw = g.ho * g.wo;
-                const int b = m / hw, p = m - b * hw;
-                const int y = p / g.wo, x = p - y * g.wo;
-                e = (uint32_t)(((b * g.hp + y * g.stride) * g.wp + x * g.stride) * g.cin);
-            } else {
-                e = (uint32_t)m * (uint32_t)g.lda;
-            }
-            a_off[s] = (e + (((lane & 7) ^ swz(r)) << 3)) * 2u;
-        }
-#pragma unroll
-        for (int s = 0; s < W_SPW; ++s) {
-            const int r = (s * NW + w) * 8 + lrow;
-            int n = n0 + r;
-            if (n > g.N - 1) n = g.N - 1;
-            w_off[s] = ((uint32_t)n * (uint32_t)g.ldw + (((lane & 7) ^ swz(r)) << 3)) * 2u;
-        }
-    };
-    const int nk = g.K >> 6;
-    const int cpt = CONV ? (g.cin >> 6) : 1;
-    int itile = tile, ikt = 0, istage = 0;
-    bool idone = false;                   // nothing left to issue (past the last tile of this workgroup)
-    setup(itile);
-    auto issue_next = [&]() {             // this wave's 6-load share of the next K-step in sequence
-        if (idone) return;
-        char* sa = smem + istage * STAGE;
-        char* sw = sa + A_BYTES;
-        int koff_a;
-        if (CONV) {
-            const int tap = ikt / cpt, ci0 = (ikt - tap * cpt) << 6;
-            const int ky = tap / 3, kx = tap - ky * 3;
-            koff_a = (ky * g.wp + kx) * g.cin + ci0;
-        } else {
-            koff_a = ikt << 6;
-        }
-        const char* abase = reinterpret_cast<const char*>(g.A + koff_a);
-        const char* wbase = reinterpret_cast<const char*>(g.W + (ikt << 6));
-#pragma unroll
-        for (int s = 0; s < A_SPW; ++s) glds_slab_off(abase, a_off[s], sa + (s * NW + w) * 1024);
-#pragma unroll
-        for (int s = 0; s < W_SPW; ++s) glds_slab_off(wbase, w_off[s], sw + (s * NW + w) * 1024);
-        istage = istage == NS - 1 ? 0 : istage + 1;
-        if (++ikt == nk) {
-            ikt = 0;
-            if (itile + wpx < tile_end) { itile += wpx; setup(itile); }
-            else idone = true;
-        }
-    };
-
-    // ---- fragment registers + accumulators -----------------------------------------------------------
-    f32x4_t acc[NI][MI];
-    i32x4_t wf0[NI], af0[MI], wf1[NI], af1[MI];
-    const int frow = lane & 15;
-    const int foff0 = tile_off(frow, lane >> 4), foff1 = tile_off(frow, 4 + (lane >> 4));
-    const int wbase_off = A_BYTES + wn * WN * 128, abase_off = (grp * 128 + wm2 * WM) * 128;
-    int rstage = 0;                      // stage of the next K-step this wave reads fragments from
-
-    auto load_seg = [&]() {              // LOAD(L): issue step L+2, read the fragments of step L
-        issue_next();
-        const char* st = smem + rstage * STAGE;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) wf0[i] = *reinterpret_cast<const i32x4_t*>(st + wbase_off + i * 2048 + foff0);
-#pragma unroll
-        for (int j = 0; j < MI; ++j) af0[j] = *reinterpret_cast<const i32x4_t*>(st + abase_off + j * 2048 + foff0);
-#pragma unroll
-        for (int i = 0; i < NI; ++i) wf1[i] = *reinterpret_cast<const i32x4_t*>(st + wbase_off + i * 2048 + foff1);
-#pragma unroll
-        for (int j = 0; j < MI; ++j) af1[j] = *reinterpret_cast<const i32x4_t*>(st + abase_off + j * 2048 + foff1);
-        rstage = rstage == NS - 1 ? 0 : rstage + 1;
-        wait_lgkmcnt0();                 // reads drained before the stage can be refilled
-        if (RELU_IN) {
-#pragma unroll
-            for (int j = 0; j < MI; ++j) { af0[j] = relu_frag(af0[j]); af1[j] = relu_frag(af1[j]); }
-        }
-    };
-    auto compute_seg = [&]() {           // 32 MFMAs, registers only
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int j = 0; j < MI; ++j) acc[i][j] = mfma16<T>(wf0[i], af0[j], acc[i][j]);
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int j = 0; j < MI; ++j) acc[i][j] = mfma16<T>(wf1[i], af1[j], acc[i][j]);
-        __builtin_amdgcn_s_setprio(0);
-    };
-    auto seg_end = [&](bool vm_wait) {   // close a segment
-        __builtin_amdgcn_sched_barrier(0);
-        if (vm_wait) {
-            if (idone) wait_vmcnt<0>(); else wait_vmcnt<SPW>();
-        }
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto epilogue = [&](int t) {
-        int mbc, nbc;
-        tile_coords(t, tiles_m, tiles_n, mbc, nbc);
-        const int m0c = mbc * BM, n0c = nbc * BN;
-        int ncol[NI];
-        ColPart cp[NI], cpw[NI / 2];
-        float4 bias[NI];
-        const bool wide = epilogue_cols<NI>(g, n0c + wn * WN + (lane >> 4) * 4, lane, ncol, cp, cpw, bias);
-#pragma unroll 1
-        for (int j = 0; j < MI; ++j) {
-            f32x4_t row[NI];
-            static_for<0, MI>([&](auto jc) {
-                constexpr int js = decltype(jc)::value;
-                if (j == js) {
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) row[i] = acc[i][js];
-                }
-            });
-            const int m = m0c + grp * 128 + wm2 * WM + j * 16 + (lane & 15);
-            if (m < g.M) epilogue_row<T, NI>(g, m, ncol, cp, cpw, wide, bias, row);
-        }
-    };
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int j = 0; j < MI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    };
-
-    // ---- prologue: K-steps 0 and 1 in flight, step 0 landed ------------------------------------------
-    issue_next();
-    issue_next();
-    if (idone) wait_vmcnt<0>(); else wait_vmcnt<SPW>();
-    __builtin_amdgcn_s_barrier();
-    // Both groups run the SAME loop [LOAD ; barrier ; COMPUTE ; barrier]; G1 simply starts one
-    // barrier later (and G0 pays it back at the end), which puts the two groups one segment out of
-    // phase.  The vmcnt wait sits in front of the barrier that closes the EVEN segments: after
-    // COMPUTE for G0, after LOAD for G1.
-    if (grp == 1) __builtin_amdgcn_s_barrier();
-    int prev = -1;
-    while (true) {
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt == 0) {
-                if (prev >= 0) {
-                    epilogue(prev);                // overlaps the other group's COMPUTE segment
-                    // Explicit drain: bias/residual loads whose consumer was predicated off (tail
-                    // rows) would otherwise stay "pending" in the compiler's scoreboard, and it
-                    // protects their registers with a vmcnt(0) inside every K-step.
-                    wait_vmcnt<0>();
-                }
-                zero_acc();
-            }
-            load_seg();
-            if (grp == 1) seg_end(true); else seg_end(false);
-            compute_seg();
-            if (grp == 0) seg_end(true); else seg_end(false);
-        }
-        prev = tile;
-        if (tile + wpx >= tile_end) break;
-        tile += wpx;
-    }
-    epilogue(prev);
-    if (grp == 0) __builtin_amdgcn_s_barrier();
-    wait_vmcnt<0>();
-}
-
-template <typename T, bool CONV, bool RELU_IN, int TAG>
-int launch_pp(const GemmArgs& g, hipStream_t stream) {
-    const int tiles = ((g.M + 255) / 256) * ((g.N + 127) / 128);
-    const size_t lds = 3 * (256 + 128) * 128;
-    int grid = ((tiles + 7) / 8) * 8;
-    if (grid > 256) grid = 256;
-    auto kern = lseg_gemm_pp_kernel<T, CONV, RELU_IN, TAG>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        LSEG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, g);
-    LSEG_HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-#endif  // LSEG_GEMM_EXPERIMENTAL
-
 template <typename T, typename CFG, bool CONV, bool RELU_IN, int EPI, int TAG>
 int launch_one(const GemmArgs& g, hipStream_t stream) {
     const int tiles = ((g.M + CFG::BM - 1) / CFG::BM) * ((g.N + CFG::BN - 1) / CFG::BN);
@@ -1186,7 +947,7 @@ int launch_one(const GemmArgs& g, hipStream_t stream) {
 template <typename T, bool CONV, bool RELU_IN, int EPI, int TAG>
 int pick_tile(const GemmArgs& g, hipStream_t stream) {
     const long t_mid = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
-    static const int force = getenv("LSEG_GEMM_TILE") ? atoi(getenv("LSEG_GEMM_TILE")) : 0;   // 1 small 2 mid (3 big 4 ping-pong)
+    static const int force = getenv("LSEG_GEMM_TILE") ? atoi(getenv("LSEG_GEMM_TILE")) : 0;   // tools/tests: 1 = 64x64, 2 = 128x128, 6 = 256x256
     int pick = t_mid >= 192 ? 2 : 1;
     if (EPI != EPI_GENERIC && pick == 2) {
         // 256x256 tiles (one 8-wave workgroup per CU) move half the operand bytes per MFMA through the
@@ -1203,9 +964,6 @@ int pick_tile(const GemmArgs& g, hipStream_t stream) {
         if (pick == 6) return launch_one<T, CfgHuge, CONV, RELU_IN, EPI, TAG>(g, stream);
     }
     if (pick == 6) pick = 2;
-#ifdef LSEG_GEMM_EXPERIMENTAL
-    if (pick == 4) return launch_pp<T, CONV, RELU_IN, TAG>(g, stream);
-#endif
     if (pick == 2) return launch_one<T, CfgMid, CONV, RELU_IN, EPI, TAG>(g, stream);
     return launch_one<T, CfgSmall, CONV, RELU_IN, EPI, TAG>(g, stream);
 }
