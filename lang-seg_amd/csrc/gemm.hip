@@ -8,13 +8,14 @@
 //   CLIP text Linear layers ([3P] clip/model.py ResidualAttentionBlock) in fp16
 //   the pixel x text correlation (lseg_net.py:194) in fp16
 //
-// Structure (cdna_hip_programming.md §5): BMxBNx64 tile, 4 waves (2x2), each wave a
-// (BM/2)x(BN/2) sub-tile of v_mfma_f32_16x16x32 tiles; operands stream HBM -> LDS with
-// direct-to-LDS loads (global_load_lds_dwordx4, 16 B/lane), two LDS stages, one barrier
-// per K-step; XOR swizzle applied on the source address (LDS image stays lane-linear);
-// XCD-aware tile rasterisation.  The MFMA is issued "swapped" (weights as the row
-// operand) so each lane ends up with 4 consecutive output channels of one row ->
-// 8/16-byte epilogue stores and float4 bias/residual loads.
+// Structure: BMxBNx64 tiles (64x64, 128x128 with 4 waves; 256x256 with 8 waves; 64x512 for the fused head),
+// each wave a 32x32 .. 64x128 sub-tile of v_mfma_f32_16x16x32 tiles; operands stream HBM -> LDS with direct-to-LDS
+// loads (global_load_lds_dwordx4, 16 B/lane) into SEPARATE rings for A (3 K-steps) and W (2), counted vmcnt;
+// software-pipelined K-loop with one barrier per K-step; XOR swizzle applied on the source address (LDS image
+// stays lane-linear); persistent XCD-aware grouped tile rasterisation; compile-time epilogues for the hot shapes.
+// The MFMA is issued "swapped" (weights as the row operand) so each lane ends up with 4 consecutive output
+// channels of one row -> 8/16-byte epilogue stores and float4 bias/residual loads.  DESIGN.md §3.1 has the
+// measurements behind each of these choices.
 #include <cstdlib>
 #include <type_traits>
 
@@ -497,11 +498,11 @@ __device__ __forceinline__ void fast_epilogue(const GemmArgs& g, f32x4_t (&acc)[
     }
 }
 
-// Tile configuration: BM x BN block tile, WGM x WGN waves (each wave owns a 64x64 sub-tile built
-// from 4x4 v_mfma_f32_16x16x32 tiles), NS LDS stages of BK = 64.
-//   Big   256x128, 4x2 waves, 3 stages (144 KB LDS, 1 workgroup/CU, loads fly two K-steps ahead)
-//   Mid   128x128, 2x2 waves, 2 stages ( 64 KB LDS, 2 workgroups/CU)
-//   Small  64x64,  2x2 waves (32x32 per wave), 2 stages: fills the chip when M*N is small
+// Tile configuration: BM x BN block tile of BK = 64, WGM x WGN waves (NS_ is unused since the operand rings).
+//   Huge  256x256, 4x2 waves (64x128 per wave, 128 accumulator registers), 160 KB LDS, 1 workgroup/CU
+//   Mid   128x128, 2x2 waves (64x64 per wave),  80 KB LDS, 2 workgroups/CU
+//   Small  64x64,  2x2 waves (32x32 per wave),  40 KB LDS: fills the chip when M*N is small
+//   Row    64x512, 1x4 waves (64x128 per wave), 152 KB + 1 KB: fused head1 + row L2-norm
 template <int BM_, int BN_, int WGM_, int WGN_, int NS_, int MINW_ = 2>
 struct TileCfg {
     static constexpr int BM = BM_, BN = BN_, WGM = WGM_, WGN = WGN_, NS = NS_, MINW = MINW_;
@@ -527,9 +528,9 @@ struct TileCfg {
 };
 using CfgMid = TileCfg<128, 128, 2, 2, 2>;
 using CfgSmall = TileCfg<64, 64, 2, 2, 2>;
-using CfgHuge = TileCfg<256, 256, 4, 2, 2, 1>;     // 8 waves, 64x128 per wave, 128 KB LDS: half the L1/TA load per MFMA of Mid
+using CfgHuge = TileCfg<256, 256, 4, 2, 2, 1>;     // half the operand bytes per MFMA through the CU's L1 / LDS-DMA path of Mid
 // Row config: one workgroup owns complete 512-wide output rows (fused head1 + L2-norm + fp16 casts);
-// 128 accumulator registers per lane -> one wave per SIMD, 144 KB LDS + 1 KB reduction scratch
+// 128 accumulator registers per lane, one wave per SIMD, 152 KB of rings + 1 KB reduction scratch
 using CfgRow = TileCfg<64, 512, 1, 4, 2, 1>;
 
 // Counted waits go through the BUILTIN, not inline asm: SIInsertWaitcnts understands a pre-existing
