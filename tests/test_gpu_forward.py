@@ -289,7 +289,7 @@ def test_vitl16_batch_of_8_equals_single_image_runs():
 
 
 _REF = sorted(f[:-3] for f in os.listdir(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
-              if f.startswith("ref_"))
+              if f.startswith("ref_") and not f.startswith("ref_eval_"))
 
 
 @pytest.mark.parametrize("name", _REF)

@@ -16,8 +16,8 @@ from lseg_hip.synth import synthetic_state_dict, synthetic_images
 from oracle.lseg_oracle import lseg_forward
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-REF = sorted(f[:-3] for f in os.listdir(GOLD) if f.startswith("ref_") and not f.endswith("_zs.pt"))
-REF_ZS = sorted(f[:-3] for f in os.listdir(GOLD) if f.startswith("ref_") and f.endswith("_zs.pt"))
+REF = sorted(f[:-3] for f in os.listdir(GOLD) if f.startswith("ref_vit") and not f.endswith("_zs.pt"))
+REF_ZS = sorted(f[:-3] for f in os.listdir(GOLD) if f.startswith("ref_vit") and f.endswith("_zs.pt"))
 
 
 def relerr(a, b):
