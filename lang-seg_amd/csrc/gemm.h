@@ -48,7 +48,8 @@ struct GemmArgs {
     void* Ck; void* Cv; int qkv_dim, qkv_ntok, qkv_npad, qkv_heads;
     float rn_scale;             // MAP_ROWNORM: logit scale
     int tag;                    // 0 generic, 1 = the profiled dominant instance (distinct symbol)
-    int dbg;                    // ablation knob (tools only): 1 = skip epilogue stores, 2 = skip the epilogue
+    int dbg;                    // tools only: bits 0-1 ablation (1 = skip epilogue stores, 2 = skip the epilogue), 4 = phase timing, 8 = no stagger
+    int group_m;                // row-blocks per rasterisation group (0 -> 8)
 };
 
 void gemm_args_init(GemmArgs& g);

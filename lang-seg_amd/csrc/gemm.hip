@@ -542,8 +542,7 @@ using CfgRow = TileCfg<64, 512, 1, 4, 2, 1>;
 // moving to the next column, so the ~64 tiles an XCD works on at any time form a ~8x8 patch
 // (A panels + W panels ~ 4 MB = one XCD's L2) instead of 2 full rows of the grid (all of W, which
 // does not fit): measured -2.2x L2->fabric fetch on the ViT MLP GEMM (profiles/).
-__device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int& mb, int& nb) {
-    constexpr int GROUP_M = 8;
+__device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int& mb, int& nb, int GROUP_M = 8) {
     const int per_group = GROUP_M * tiles_n;
     const int gid = t / per_group;
     const int first_m = gid * GROUP_M;
@@ -596,7 +595,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
     const int lrow = lane >> 3;                           // row inside an 8-row slab
     auto setup_a = [&](int t) {
         int mb, nb;
-        tile_coords(t, tiles_m, tiles_n, mb, nb);
+        tile_coords(t, tiles_m, tiles_n, mb, nb, g.group_m);
         const int m0 = mb * BM;
 #pragma unroll
         for (int s = 0; s < A_SPW; ++s) {
@@ -617,7 +616,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
     };
     auto setup_w = [&](int t) {
         int mb, nb;
-        tile_coords(t, tiles_m, tiles_n, mb, nb);
+        tile_coords(t, tiles_m, tiles_n, mb, nb, g.group_m);
         const int n0 = nb * BN;
 #pragma unroll
         for (int s = 0; s < W_SPW; ++s) {
@@ -813,7 +812,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
         int pm0, pn0;
         {   // this tile's origin and, for the specialised epilogues, its bias (consumed after the K-loop)
             int mbc, nbc;
-            tile_coords(tile, tiles_m, tiles_n, mbc, nbc);
+            tile_coords(tile, tiles_m, tiles_n, mbc, nbc, g.group_m);
             pm0 = mbc * BM; pn0 = nbc * BN;
             if constexpr (EPI != EPI_GENERIC && BIAS_PREFETCH) {
 #pragma unroll
@@ -1032,6 +1031,8 @@ int launch_gemm(const GemmArgs& g_in, int ab_dtype, hipStream_t stream) {
     GemmArgs g = g_in;
     static const int dbg = getenv("LSEG_GEMM_DBG") ? atoi(getenv("LSEG_GEMM_DBG")) : 0;
     g.dbg = dbg;
+    static const int group_m = getenv("LSEG_GEMM_GROUP_M") ? atoi(getenv("LSEG_GEMM_GROUP_M")) : 8;   // tools: L2 locality sweeps
+    g.group_m = group_m > 0 ? group_m : 8;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return set_error(LSEG_ERR_INVALID, "gemm: empty problem %dx%dx%d", g.M, g.N, g.K);
     if (g.K % 64 != 0) return set_error(LSEG_ERR_UNSUPPORTED, "gemm: K=%d must be a multiple of 64", g.K);
     if (g.conv && (g.cin % 64 != 0)) return set_error(LSEG_ERR_UNSUPPORTED, "conv: Cin=%d must be a multiple of 64", g.cin);
