@@ -23,6 +23,8 @@ What is restated (all paths relative to /root/reference):
   modules/models/lseg_blocks.py:60-110   scratch.layerN_rn
   modules/models/lseg_blocks.py:222-358  ResidualConvUnit_custom / FeatureFusionBlock_custom
   modules/models/lseg_net.py:29-79       head blocks (arch_option 1/2)
+  modules/models/lseg_net_zs.py:177-214  LSegNetZS.forward (labels_per_image)
+  modules/lsegmentation_module.py:66-81  training_step (loss + autograd gradients; pinned by tests/golden/ref_train_*.pt)
   [3P] timm==0.4.12 vision_transformer.py  Block / Attention / Mlp   
   [3P] openai/CLIP@04f4dc2 clip/model.py   encode_text               
 
@@ -131,10 +133,16 @@ def act_postprocess(sd, lvl: int, x: Tensor, gh: int, gw: int, cfg) -> Tensor:
 # --------------------------------------------------------------------------------------
 # DPT scratch head (lseg_blocks.py)
 # --------------------------------------------------------------------------------------
+BN_TRAIN = False      # set by lseg_forward(bn_train=True): nn.BatchNorm2d in train() mode (batch statistics; the training
+                      # step of modules/lsegmentation_module.py:66-81 runs the network in train mode)
+
+
 def residual_conv_unit(sd, p: str, x: Tensor) -> Tensor:
     """ResidualConvUnit_custom.forward (lseg_blocks.py:265-288) with bn=True
-    (lseg_net.py:213), activation = nn.ReLU(False) (lseg_net.py:97), eval-mode BN."""
+    (lseg_net.py:213), activation = nn.ReLU(False) (lseg_net.py:97); eval-mode BN unless BN_TRAIN."""
     def bn(t, q):
+        if BN_TRAIN:      # batch statistics over (N,H,W), biased variance for the normalisation; running stats untouched here
+            return F.batch_norm(t, None, None, sd[q + ".weight"], sd[q + ".bias"], True, 0.1, 1e-5)
         return F.batch_norm(t, sd[q + ".running_mean"], sd[q + ".running_var"],
                             sd[q + ".weight"], sd[q + ".bias"], False, 0.1, 1e-5)
     out = F.relu(x)
@@ -249,7 +257,7 @@ def correlate(image_features: Tensor, text_features: Tensor, logit_scale: float 
 
 def lseg_forward(sd: Dict[str, Tensor], x: Tensor, text: Tensor, cfg,
                  emulate_fp16: bool = True, text_features: Optional[Tensor] = None,
-                 return_intermediates: bool = False, labels_per_image: int = 0):
+                 return_intermediates: bool = False, labels_per_image: int = 0, bn_train: bool = False):
     """Full LSeg.forward.  sd keys are relative to `net.` (App. B of SURVEY.md);
     x [B,3,H,W] fp32; text int64 [K, ctx].  Returns logits [B,K,H,W] fp32.
 
@@ -257,6 +265,8 @@ def lseg_forward(sd: Dict[str, Tensor], x: Tensor, text: Tensor, cfg,
     modules/models/lseg_net_zs.py:177-214): text holds B*k rows, image b is correlated with ITS rows
     [b*k, (b+1)*k) only (:198-208: per-image lists of features, one GEMM per image, torch.cat) and the
     result is [B,k,H,W]; no head blocks on that path."""
+    global BN_TRAIN
+    BN_TRAIN = bool(bn_train)
     inter = {}
     B, _, H, W = x.shape
     gh, gw = H // cfg.patch, W // cfg.patch
@@ -289,6 +299,7 @@ def lseg_forward(sd: Dict[str, Tensor], x: Tensor, text: Tensor, cfg,
             out = head_block(sd, cfg, out)
         out = head_block(sd, cfg, out, False)
     out = F.interpolate(out, scale_factor=2, mode="bilinear", align_corners=True)  # :203
+    BN_TRAIN = False
     if return_intermediates:
         inter.update(acts=acts, layers=layers, rn=rn, paths=[path_1, path_2, path_3, path_4],
                      image_features=image_features, text_features=text_features, lowres=lowres)
@@ -332,3 +343,22 @@ def cross_entropy_value(output: Tensor, target: Tensor, ignore_index: int = -1) 
     valid = target != ignore_index
     picked = lsm.gather(1, target.clamp_min(0).unsqueeze(1)).squeeze(1)
     return float(-(picked[valid]).sum() / valid.sum())
+
+
+def training_step(sd: Dict[str, Tensor], x: Tensor, target: Tensor, text: Tensor, cfg, ignore_index: int = -1):
+    """LSegmentationModule.training_step (modules/lsegmentation_module.py:66-81) as loss + gradients: the network in
+    train() mode (BatchNorm batch statistics; no dropout anywhere on the path), `criterion` = SegmentationLosses with
+    se_loss=False, aux=False == CrossEntropyLoss(ignore_index) ([3P] encoding/nn/loss.py), autograd for the backward.
+    Like the reference, the fp16 CLIP text tower is part of the graph (its fp16 weights receive fp16 gradients).
+    Returns (loss, {state-dict key: gradient}) for every floating-point tensor that received one; parameters the forward
+    never touches (pretrained.model.norm/head, refinenet4.resConfUnit1, clip logit_scale / visual) get none, which is
+    why the reference needs DDP(find_unused_parameters=True).  Oracle for the backward kernels."""
+    bn_stats = ("running_mean", "running_var", "num_batches_tracked")
+    leaves = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items()
+              if v.is_floating_point() and not k.endswith(bn_stats)}
+    full = dict(sd)
+    full.update(leaves)
+    out = lseg_forward(full, x, text, cfg, bn_train=True)
+    loss = F.cross_entropy(out, target, ignore_index=ignore_index)
+    loss.backward()
+    return loss.detach(), {k: v.grad for k, v in leaves.items() if v.grad is not None}

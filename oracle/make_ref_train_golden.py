@@ -1,0 +1,69 @@
+"""Golden vectors for the TRAINING step from the REFERENCE'S OWN CODE (tests/golden/ref_train_*.pt).  TEST INFRASTRUCTURE;
+build container only (needs /root/reference).
+
+The reference's LSegNet (modules/models/lseg_net.py, loaded like oracle/make_ref_golden.py does) is put in train() mode,
+run on seeded synthetic images, the loss of LSegmentationModule.training_step (modules/lsegmentation_module.py:66-81:
+criterion = CrossEntropyLoss(ignore_index), [3P] encoding SegmentationLosses with se_loss=False, aux=False) is
+back-propagated with torch autograd, and for every parameter the gradient's L2 norm, sum and first 16 elements are stored
+(the full gradients are 1.2 GB).  Pins oracle.lseg_oracle.training_step, the oracle the backward kernels will be held to.
+
+    python oracle/make_ref_train_golden.py
+"""
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import oracle.make_ref_golden as M                                               # noqa: E402  (sets up the stand-ins)
+from lseg_hip.config import get_config                                            # noqa: E402
+from lseg_hip.synth import synthetic_state_dict, synthetic_images, read_labels    # noqa: E402
+
+# name -> (backbone, H, W, B, K, seed)
+TRAIN_CASES = {
+    "ref_train_vitl16_64x64_k5_b2": ("clip_vitl16_384", 64, 64, 2, 5, 21),
+    "ref_train_vitb32_128x128_k4_b2": ("clip_vitb32_384", 128, 128, 2, 4, 22),
+}
+
+
+def synthetic_target(B, H, W, K, seed):
+    g = torch.Generator().manual_seed(1000 + seed)
+    t = torch.randint(0, K, (B, H, W), generator=g)
+    t[torch.rand((B, H, W), generator=g) < 0.2] = -1            # ADE masks: label - 1, 0/other -> -1 = ignore_index
+    return t
+
+
+def run_ref_train_case(spec):
+    bb, H, W, B, K, seed = spec
+    lseg_net, _ = M.reference_models()
+    cfg = get_config(bb)
+    sd = synthetic_state_dict(cfg, seed=seed)
+    net = lseg_net.LSegNet(labels=read_labels(M.LABELS)[:K], backbone=bb, features=cfg.features, crop_size=H,
+                           arch_option=0, block_depth=0, activation="lrelu")
+    M.load_synthetic(net, sd)
+    net.train()
+    x = synthetic_images(B, H, W, seed=seed)
+    target = synthetic_target(B, H, W, K, seed)
+    out = net(x)
+    loss = F.cross_entropy(out, target, ignore_index=-1)
+    loss.backward()
+    grads = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
+    none = sorted(n for n, p in net.named_parameters() if p.grad is None)
+    return net.text.clone(), loss.detach(), grads, none
+
+
+def main():
+    gd = os.path.join(ROOT, "tests", "golden")
+    for name, spec in TRAIN_CASES.items():
+        tokens, loss, grads, none = run_ref_train_case(spec)
+        summ = {n: {"norm": float(g.float().norm()), "sum": float(g.float().sum()), "dtype": str(g.dtype),
+                    "head": g.flatten()[:16].float().clone()} for n, g in grads.items()}
+        torch.save({"spec": spec, "tokens": tokens, "loss": float(loss), "grads": summ, "no_grad": none},
+                   os.path.join(gd, name + ".pt"))
+        print(name, "loss", float(loss), len(summ), "gradients;", len(none), "parameters without")
+
+
+if __name__ == "__main__":
+    main()
