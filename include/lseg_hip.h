@@ -197,6 +197,16 @@ int lseg_op_head_features(const void* d_x_bf16, const void* d_w_bf16, const floa
 int lseg_op_seg_stats(const float* d_scores, const int64_t* d_target, int B, int K, int H, int W, int ignore_index,
                       int64_t* d_counts, double* d_nll, void* stream);
 
+/* Backward of one Linear layer y = x W^T + b -- first brick of the training step (the reference gets
+ * it from torch autograd under LSegmentationModule.training_step, lsegmentation_module.py:66-81).  bf16/fp16 operands,
+ * fp32 accumulate, both GEMMs on the forward MFMA kernel with the contraction dimension transposed onto the fast axis:
+ *   d_dx [M,K] (operand dtype)  = dY [M,N] . W [N,K]          (may be NULL)
+ *   d_dw [N,K] fp32             = dY^T [N,M] . X [M,K]         (may be NULL)
+ *   d_db [N]   fp32             = column sums of dY            (may be NULL)
+ * N and K multiples of 64. */
+int lseg_op_linear_backward(const void* d_dy, const void* d_x, const void* d_w, int ab_dtype, void* d_dx, float* d_dw,
+                            float* d_db, int M, int N, int K, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

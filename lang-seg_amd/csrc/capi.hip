@@ -206,4 +206,40 @@ int lseg_op_seg_stats(const float* d_scores, const int64_t* d_target, int B, int
                             d_nll, (hipStream_t)stream);
 }
 
+int lseg_op_linear_backward(const void* d_dy, const void* d_x, const void* d_w, int ab_dtype, void* d_dx, float* d_dw,
+                            float* d_db, int M, int N, int K, void* stream) {
+    int r = require_device(); if (r) return r;
+    int ab;
+    if ((r = op_dt(ab_dtype, &ab))) return r;
+    if (ab != DT_BF16 && ab != DT_F16) return set_error(LSEG_ERR_INVALID, "linear_backward: operands must be bf16 or fp16");
+    if (!d_dy || !d_x || !d_w) return set_error(LSEG_ERR_INVALID, "linear_backward: NULL operand");
+    if (M < 1 || (N % 64) || (K % 64) || N < 64 || K < 64)
+        return set_error(LSEG_ERR_UNSUPPORTED, "linear_backward: N=%d and K=%d must be multiples of 64 (M=%d >= 1)", N, K, M);
+    hipStream_t st = (hipStream_t)stream;
+    const int Mp = (M + 63) / 64 * 64;                    // wgrad contracts over M: pad to the GEMM's K-step with zeros
+    uint16_t *wt = nullptr, *dyt = nullptr, *xt = nullptr;
+    auto cleanup = [&]() { if (wt) (void)hipFreeAsync(wt, st); if (dyt) (void)hipFreeAsync(dyt, st); if (xt) (void)hipFreeAsync(xt, st); };
+    GemmArgs g;
+    if (d_dx) {     // dX[M,K] = dY[M,N] . W[N,K]      (A = dY, "weights" = W^T [K,N], contraction over N)
+        if (hipMallocAsync((void**)&wt, (size_t)K * N * 2, st) != hipSuccess) { cleanup(); return set_error(LSEG_ERR_HIP, "linear_backward: out of device memory"); }
+        if ((r = launch_transpose16(d_w, wt, N, K, K, N, st))) { cleanup(); return r; }
+        gemm_args_init(g);
+        g.A = (const uint16_t*)d_dy; g.W = wt; g.M = M; g.N = K; g.K = N; g.lda = N; g.ldw = N;
+        g.C = d_dx; g.out_dtype = ab; g.ldc = K; g.map_mode = MAP_LINEAR;
+        if ((r = launch_gemm(g, ab, st))) { cleanup(); return r; }
+    }
+    if (d_dw) {     // dW[N,K] = dY^T[N,M] . X[M,K]    (A = dY^T [N,Mp], "weights" = X^T [K,Mp], contraction over M)
+        if (hipMallocAsync((void**)&dyt, (size_t)N * Mp * 2, st) != hipSuccess ||
+            hipMallocAsync((void**)&xt, (size_t)K * Mp * 2, st) != hipSuccess) { cleanup(); return set_error(LSEG_ERR_HIP, "linear_backward: out of device memory"); }
+        if ((r = launch_transpose16(d_dy, dyt, M, N, N, Mp, st)) || (r = launch_transpose16(d_x, xt, M, K, K, Mp, st))) { cleanup(); return r; }
+        gemm_args_init(g);
+        g.A = dyt; g.W = xt; g.M = N; g.N = K; g.K = Mp; g.lda = Mp; g.ldw = Mp;
+        g.C = d_dw; g.out_dtype = DT_F32; g.ldc = K; g.map_mode = MAP_LINEAR;
+        if ((r = launch_gemm(g, ab, st))) { cleanup(); return r; }
+    }
+    if (d_db && (r = launch_colsum16(d_dy, ab, d_db, M, N, N, st))) { cleanup(); return r; }
+    cleanup();
+    return LSEG_OK;
+}
+
 }  // extern "C"

@@ -432,6 +432,35 @@ __global__ void argmax_planes_kernel(const float* in, uint8_t* out, int B, int K
     }
 }
 
+// ---- building blocks of the backward pass (first bricks of SURVEY.md §8 a17) -----------------------------------------
+// out[c, r] = in[r, c] for r < R (zero for R <= r < ldo): 16-bit matrices, 64x64 tiles through LDS.  Used to put the
+// contraction dimension of dgrad / wgrad GEMMs on the fast axis (dY^T, X^T with M padded to the GEMM's K-step).
+__global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
+                                                         int R, int C, int ldi, int ldo) {
+    __shared__ uint16_t t[64][66];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int rr = i >> 6, cc = i & 63, r = r0 + rr, c = c0 + cc;
+        t[rr][cc] = (r < R && c < C) ? in[(size_t)r * ldi + c] : (uint16_t)0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int cc = i >> 6, rr = i & 63, r = r0 + rr, c = c0 + cc;
+        if (c < C && r < ldo) out[(size_t)c * ldo + r] = t[rr][cc];
+    }
+}
+// out[c] += sum_r in[r, c] (bias gradient); out must be zeroed; fp32 atomics across row chunks
+__global__ void colsum16_kernel(const uint16_t* __restrict__ in, int dtype, float* __restrict__ out, int R, int C, int ld,
+                                int rows_per_block) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += load_as_f32(in, (size_t)r * ld + c, dtype);
+    atomicAdd(&out[c], s);
+}
+
 // ---- segmentation statistics on device -------------------------------------------------------------------------------
 // One pass over the [B,K,H,W] fp32 scores: per pixel the arg-max label, its log-sum-exp and the score at the target;
 // accumulates what the host-side metric code of the reference computes from the full logits tensor:
@@ -632,6 +661,21 @@ int launch_head_block(const float* in, float* out, const float* w9, const float*
 }
 int launch_argmax_planes(const float* in, uint8_t* out, int B, int K, int HW, hipStream_t st) {
     hipLaunchKernelGGL(argmax_planes_kernel, dim3(grid_for((size_t)B * HW)), dim3(256), 0, st, in, out, B, K, HW);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_transpose16(const void* in, void* out, int R, int C, int ldi, int ldo, hipStream_t st) {
+    dim3 grid((ldo + 63) / 64, (C + 63) / 64);
+    hipLaunchKernelGGL(transpose16_kernel, grid, dim3(256), 0, st, (const uint16_t*)in, (uint16_t*)out, R, C, ldi, ldo);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_colsum16(const void* in, int dtype, float* out, int R, int C, int ld, hipStream_t st) {
+    LSEG_HIP_TRY(hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st));
+    const int rpb = 256;
+    dim3 grid((C + 255) / 256, (R + rpb - 1) / rpb);
+    hipLaunchKernelGGL(colsum16_kernel, grid, dim3(256), 0, st, (const uint16_t*)in, dtype, out, R, C, ld, rpb);
     CHECK_LAUNCH();
     return 0;
 }

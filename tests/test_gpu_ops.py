@@ -225,3 +225,30 @@ def test_fused_head_features(lib, M, Fd):
     d = (out.float() - ref).abs()
     assert d.max().item() <= 2 ** -7                      # 1 fp16 ulp at |a| < 8 (fp32 summation order)
     assert (d > 0).float().mean().item() < 0.05
+
+
+@pytest.mark.parametrize("dtype,M,N,K", [(torch.bfloat16, 901, 1024, 1024), (torch.float16, 300, 128, 256),
+                                         (torch.bfloat16, 64, 64, 64), (torch.bfloat16, 1802, 4096, 1024),
+                                         (torch.bfloat16, 130, 192, 320)])
+def test_linear_backward(lib, dtype, M, N, K):
+    """Backward of y = x W^T + b (first brick of the training step): dX = dY W, dW = dY^T X, db = sum_m dY -- against
+    fp32 torch on the same 16-bit-rounded operands (what autograd computes under LSegmentationModule.training_step)."""
+    dy = rnd((M, N), dtype, 1, 0.5)
+    x = rnd((M, K), dtype, 2)
+    w = rnd((N, K), dtype, 3, 1.0 / math.sqrt(K))
+    dx = torch.empty((M, K), dtype=dtype, device="cuda")
+    dw = torch.empty((N, K), dtype=torch.float32, device="cuda")
+    db = torch.empty((N,), dtype=torch.float32, device="cuda")
+    _lib.check(lib.lseg_op_linear_backward(P(dy), P(x), P(w), DT[dtype], P(dx), P(dw), P(db), M, N, K, stream()))
+    torch.cuda.synchronize()
+    dyf, xf, wf = dy.float(), x.float(), w.float()
+    ref_dx, ref_dw, ref_db = dyf @ wf, dyf.t() @ xf, dyf.sum(0)
+    eps = 2 ** -8 if dtype == torch.bfloat16 else 2 ** -11
+    assert (dx.float() - ref_dx).abs().max().item() <= 2 * eps * ref_dx.abs().max().item() + 1e-6
+    assert (dw - ref_dw).abs().max().item() <= 2e-4 * ref_dw.abs().max().item() + 1e-6      # fp32 accumulation order only
+    assert (db - ref_db).abs().max().item() <= 2e-4 * max(1.0, ref_db.abs().max().item())
+    # partial calls: any output may be omitted
+    dw2 = torch.zeros_like(dw)
+    _lib.check(lib.lseg_op_linear_backward(P(dy), P(x), P(w), DT[dtype], None, P(dw2), None, M, N, K, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(dw2, dw)
