@@ -207,6 +207,12 @@ int lseg_op_seg_stats(const float* d_scores, const int64_t* d_target, int B, int
 int lseg_op_linear_backward(const void* d_dy, const void* d_x, const void* d_w, int ab_dtype, void* d_dx, float* d_dw,
                             float* d_db, int M, int N, int K, void* stream);
 
+/* Backward of LayerNorm over the last dimension (timm norm1/norm2 on the fp32 residual stream; autograd in the
+ * reference): d_dy [M,D] (fp32 / bf16 / fp16), d_x [M,D] fp32 (the forward input), d_gamma [D];
+ * d_dx [M,D] fp32 (= or += when accumulate_dx: the residual stream's gradient), d_dgamma / d_dbeta [D] fp32. */
+int lseg_op_layernorm_backward(const void* d_dy, int dy_dtype, const float* d_x, const float* d_gamma, float* d_dx,
+                               float* d_dgamma, float* d_dbeta, int M, int D, float eps, int accumulate_dx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -242,4 +242,14 @@ int lseg_op_linear_backward(const void* d_dy, const void* d_x, const void* d_w, 
     return LSEG_OK;
 }
 
+int lseg_op_layernorm_backward(const void* d_dy, int dy_dtype, const float* d_x, const float* d_gamma, float* d_dx,
+                               float* d_dgamma, float* d_dbeta, int M, int D, float eps, int accumulate_dx, void* stream) {
+    int r = require_device(); if (r) return r;
+    int dt;
+    if ((r = op_dt(dy_dtype, &dt))) return r;
+    if (!d_dy || !d_x || !d_gamma || !d_dx || !d_dgamma || !d_dbeta) return set_error(LSEG_ERR_INVALID, "layernorm_backward: NULL pointer");
+    if (M < 1) return set_error(LSEG_ERR_INVALID, "layernorm_backward: M=%d", M);
+    return launch_layernorm_backward(d_dy, dt, d_x, d_gamma, d_dx, d_dgamma, d_dbeta, M, D, eps, accumulate_dx, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -432,6 +432,94 @@ __global__ void argmax_planes_kernel(const float* in, uint8_t* out, int B, int K
     }
 }
 
+// LayerNorm backward (timm norm1/norm2, fp32 input x): one wave per row, rows strided over the grid so that a wave
+// keeps its dgamma / dbeta partial sums in registers and issues one atomic per column at the end.
+//   xh = (x - mean) * rstd ; g = dy * gamma ; dx = rstd * (g - mean(g) - xh * mean(g * xh)) ; dgamma += dy * xh ; dbeta += dy
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ dy, int dy_dtype, const float* __restrict__ x,
+                                                            const float* __restrict__ gamma, float* __restrict__ dx,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int M, int D, float eps, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int nv = D >> 2;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+    float4 ga[MAXV], dg[MAXV], db[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int g = lane + 64 * i;
+        ga[i] = g < nv ? reinterpret_cast<const float4*>(gamma)[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+        dg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        db[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int row = wave; row < M; row += nwaves) {
+        float4 xv[MAXV], gv[MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int g = lane + 64 * i;
+            if (g < nv) {
+                xv[i] = reinterpret_cast<const float4*>(x + (size_t)row * D)[g];
+                if (dy_dtype == DT_F32) {
+                    gv[i] = reinterpret_cast<const float4*>((const float*)dy + (size_t)row * D)[g];
+                } else {
+                    const uint2 u = reinterpret_cast<const uint2*>((const uint16_t*)dy + (size_t)row * D)[g];
+                    gv[i].x = load_as_f32(&u, 0, dy_dtype); gv[i].y = load_as_f32(&u, 1, dy_dtype);
+                    gv[i].z = load_as_f32(&u, 2, dy_dtype); gv[i].w = load_as_f32(&u, 3, dy_dtype);
+                }
+                s += xv[i].x + xv[i].y + xv[i].z + xv[i].w;
+            } else {
+                xv[i] = make_float4(0.f, 0.f, 0.f, 0.f); gv[i] = xv[i];
+            }
+        }
+        const float mean = wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            if (lane + 64 * i < nv) {
+                const float a = xv[i].x - mean, b = xv[i].y - mean, c = xv[i].z - mean, d = xv[i].w - mean;
+                q += a * a + b * b + c * c + d * d;
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            if (lane + 64 * i < nv) {
+                // xv <- xhat ; gv stays dy ; accumulate the parameter gradients ; t = dy * gamma
+                xv[i].x = (xv[i].x - mean) * rstd; xv[i].y = (xv[i].y - mean) * rstd;
+                xv[i].z = (xv[i].z - mean) * rstd; xv[i].w = (xv[i].w - mean) * rstd;
+                dg[i].x += gv[i].x * xv[i].x; dg[i].y += gv[i].y * xv[i].y; dg[i].z += gv[i].z * xv[i].z; dg[i].w += gv[i].w * xv[i].w;
+                db[i].x += gv[i].x; db[i].y += gv[i].y; db[i].z += gv[i].z; db[i].w += gv[i].w;
+                gv[i].x *= ga[i].x; gv[i].y *= ga[i].y; gv[i].z *= ga[i].z; gv[i].w *= ga[i].w;
+                sg += gv[i].x + gv[i].y + gv[i].z + gv[i].w;
+                sgx += gv[i].x * xv[i].x + gv[i].y * xv[i].y + gv[i].z * xv[i].z + gv[i].w * xv[i].w;
+            }
+        }
+        const float a = wave_sum(sg) / (float)D, b = wave_sum(sgx) / (float)D;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int g = lane + 64 * i;
+            if (g < nv) {
+                float4* o = reinterpret_cast<float4*>(dx + (size_t)row * D) + g;
+                float4 r = make_float4(rstd * (gv[i].x - a - xv[i].x * b), rstd * (gv[i].y - a - xv[i].y * b),
+                                       rstd * (gv[i].z - a - xv[i].z * b), rstd * (gv[i].w - a - xv[i].w * b));
+                if (accumulate) { const float4 p = *o; r.x += p.x; r.y += p.y; r.z += p.z; r.w += p.w; }
+                *o = r;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int g = lane + 64 * i;
+        if (g < nv) {
+            atomicAdd(dgamma + 4 * g + 0, dg[i].x); atomicAdd(dgamma + 4 * g + 1, dg[i].y);
+            atomicAdd(dgamma + 4 * g + 2, dg[i].z); atomicAdd(dgamma + 4 * g + 3, dg[i].w);
+            atomicAdd(dbeta + 4 * g + 0, db[i].x); atomicAdd(dbeta + 4 * g + 1, db[i].y);
+            atomicAdd(dbeta + 4 * g + 2, db[i].z); atomicAdd(dbeta + 4 * g + 3, db[i].w);
+        }
+    }
+}
+
 // ---- building blocks of the backward pass (first bricks of SURVEY.md §8 a17) -----------------------------------------
 // out[c, r] = in[r, c] for r < R (zero for R <= r < ldo): 16-bit matrices, 64x64 tiles through LDS.  Used to put the
 // contraction dimension of dgrad / wgrad GEMMs on the fast axis (dY^T, X^T with M padded to the GEMM's K-step).
@@ -661,6 +749,20 @@ int launch_head_block(const float* in, float* out, const float* w9, const float*
 }
 int launch_argmax_planes(const float* in, uint8_t* out, int B, int K, int HW, hipStream_t st) {
     hipLaunchKernelGGL(argmax_planes_kernel, dim3(grid_for((size_t)B * HW)), dim3(256), 0, st, in, out, B, K, HW);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_layernorm_backward(const void* dy, int dy_dtype, const float* x, const float* gamma, float* dx, float* dgamma,
+                              float* dbeta, int M, int D, float eps, int accumulate, hipStream_t st) {
+    if (D % 4 != 0 || D > 64 * 4 * 4) return set_error(LSEG_ERR_UNSUPPORTED, "layernorm backward: D=%d", D);
+    LSEG_HIP_TRY(hipMemsetAsync(dgamma, 0, (size_t)D * sizeof(float), st));
+    LSEG_HIP_TRY(hipMemsetAsync(dbeta, 0, (size_t)D * sizeof(float), st));
+    int blocks = (M + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+#define LN_BWD(V) hipLaunchKernelGGL(layernorm_bwd_kernel<V>, dim3(blocks), dim3(256), 0, st, dy, dy_dtype, x, gamma, dx, dgamma, dbeta, M, D, eps, accumulate)
+    if (D <= 256) LN_BWD(1); else if (D <= 512) LN_BWD(2); else LN_BWD(4);
+#undef LN_BWD
     CHECK_LAUNCH();
     return 0;
 }

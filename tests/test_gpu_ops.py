@@ -252,3 +252,28 @@ def test_linear_backward(lib, dtype, M, N, K):
     _lib.check(lib.lseg_op_linear_backward(P(dy), P(x), P(w), DT[dtype], None, P(dw2), None, M, N, K, stream()))
     torch.cuda.synchronize()
     assert torch.equal(dw2, dw)
+
+
+@pytest.mark.parametrize("dy_dtype,M,D", [(torch.float32, 901, 1024), (torch.bfloat16, 3604, 1024), (torch.float32, 37, 768),
+                                           (torch.bfloat16, 130, 128)])
+def test_layernorm_backward(lib, dy_dtype, M, D):
+    """LayerNorm backward (timm norm1/norm2, eps 1e-6) against torch autograd in fp32 on the same inputs; dx also in
+    accumulate mode (the residual stream's gradient receives the LN branch on top of the skip path)."""
+    x = rnd((M, D), torch.float32, 1, 2.0) + 0.5
+    gamma = (1.0 + 0.1 * rnd((D,), torch.float32, 2)).contiguous()
+    beta = 0.1 * rnd((D,), torch.float32, 3)
+    dy = rnd((M, D), dy_dtype, 4)
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    F.layer_norm(xr, (D,), gr, br, 1e-6).backward(dy.float())
+    dx = torch.empty_like(x)
+    dg, dbt = torch.empty_like(gamma), torch.empty_like(beta)
+    _lib.check(lib.lseg_op_layernorm_backward(P(dy), DT[dy_dtype], P(x), P(gamma), P(dx), P(dg), P(dbt), M, D, 1e-6, 0, stream()))
+    torch.cuda.synchronize()
+    assert (dx - xr.grad).abs().max().item() <= 2e-5 * max(1.0, xr.grad.abs().max().item())
+    assert (dg - gr.grad).abs().max().item() <= 2e-4 * max(1.0, gr.grad.abs().max().item())
+    assert (dbt - br.grad).abs().max().item() <= 2e-4 * max(1.0, br.grad.abs().max().item())
+    acc = torch.ones_like(x)
+    _lib.check(lib.lseg_op_layernorm_backward(P(dy), DT[dy_dtype], P(x), P(gamma), P(acc), P(dg), P(dbt), M, D, 1e-6, 1, stream()))
+    torch.cuda.synchronize()
+    assert (acc - (1.0 + xr.grad)).abs().max().item() <= 2e-5 * max(1.0, xr.grad.abs().max().item())
