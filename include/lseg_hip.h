@@ -213,6 +213,14 @@ int lseg_op_linear_backward(const void* d_dy, const void* d_x, const void* d_w, 
 int lseg_op_layernorm_backward(const void* d_dy, int dy_dtype, const float* d_x, const float* d_gamma, float* d_dx,
                                float* d_dgamma, float* d_dbeta, int M, int D, float eps, int accumulate_dx, void* stream);
 
+/* Backward of a stride-1 3x3 convolution in the padded-NHWC layout (the DPT head's convs, lseg_blocks.py:73-108,
+ * 237-255; autograd in the reference), bf16 operands, built on the forward kernels:
+ *   d_dx_pad [B,H+2,W+2,Cin] bf16, interior written (caller keeps the border zero) = conv3x3(dY, W flipped / channel-swapped)
+ *   d_dw     [Cout, 9*Cin]  fp32 (tap-major, like d_w_packed)            = dY^T x (9 row-shifted copies of X)^T, one GEMM
+ * d_dy_pad [B,H+2,W+2,Cout] bf16 with a ZERO border, d_x_pad the forward input.  Either output may be NULL. */
+int lseg_op_conv3x3_backward(const void* d_dy_pad, const void* d_x_pad, const void* d_w_packed, void* d_dx_pad, float* d_dw,
+                             int B, int H, int W, int Cin, int Cout, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

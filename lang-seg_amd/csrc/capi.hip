@@ -252,4 +252,41 @@ int lseg_op_layernorm_backward(const void* d_dy, int dy_dtype, const float* d_x,
     return launch_layernorm_backward(d_dy, dt, d_x, d_gamma, d_dx, d_dgamma, d_dbeta, M, D, eps, accumulate_dx, (hipStream_t)stream);
 }
 
+int lseg_op_conv3x3_backward(const void* d_dy_pad, const void* d_x_pad, const void* d_w_packed, void* d_dx_pad, float* d_dw,
+                             int B, int H, int W, int Cin, int Cout, void* stream) {
+    int r = require_device(); if (r) return r;
+    if (!d_dy_pad || !d_w_packed) return set_error(LSEG_ERR_INVALID, "conv3x3_backward: NULL operand");
+    if ((Cin % 64) || (Cout % 64)) return set_error(LSEG_ERR_UNSUPPORTED, "conv3x3_backward: Cin=%d, Cout=%d must be multiples of 64", Cin, Cout);
+    hipStream_t st = (hipStream_t)stream;
+    uint16_t *wd = nullptr, *dyt = nullptr, *xt9 = nullptr;
+    auto cleanup = [&]() { if (wd) (void)hipFreeAsync(wd, st); if (dyt) (void)hipFreeAsync(dyt, st); if (xt9) (void)hipFreeAsync(xt9, st); };
+    auto fail = [&](int code) { cleanup(); return code; };
+    if (d_dx_pad) {
+        // dX = conv3x3(dY, W flipped and channel-swapped): the forward implicit-GEMM kernel, roles of Cin / Cout exchanged
+        if (hipMallocAsync((void**)&wd, (size_t)Cin * 9 * Cout * 2, st) != hipSuccess) return fail(set_error(LSEG_ERR_HIP, "conv3x3_backward: out of device memory"));
+        if ((r = launch_conv_dgrad_pack(d_w_packed, wd, Cout, Cin, st))) return fail(r);
+        if ((r = lseg_op_conv3x3(d_dy_pad, wd, nullptr, nullptr, d_dx_pad, B, H, W, Cout, Cin, 1, 0, 0, stream))) return fail(r);
+    }
+    if (d_dw) {
+        // dW[co, tap, ci] = sum over padded positions m of dY[m, co] * X[m + shift(tap), ci]; dY's zero border removes the
+        // positions whose shifted partner falls outside the image.  One GEMM: dY^T [Co, Mp] x (9 shifted X^T) [9*Ci, Mp]^T.
+        if (!d_x_pad) return fail(set_error(LSEG_ERR_INVALID, "conv3x3_backward: wgrad needs the forward input"));
+        const int Mp = B * (H + 2) * (W + 2), Mpp = (Mp + 63) / 64 * 64;
+        if (hipMallocAsync((void**)&dyt, (size_t)Cout * Mpp * 2, st) != hipSuccess ||
+            hipMallocAsync((void**)&xt9, (size_t)9 * Cin * Mpp * 2, st) != hipSuccess) return fail(set_error(LSEG_ERR_HIP, "conv3x3_backward: out of device memory"));
+        if ((r = launch_transpose16(d_dy_pad, dyt, Mp, Cout, Cout, Mpp, st))) return fail(r);
+        for (int t = 0; t < 9; ++t) {
+            const int shift = (t / 3 - 1) * (W + 2) + (t % 3 - 1);
+            if ((r = launch_transpose16(d_x_pad, xt9 + (size_t)t * Cin * Mpp, Mp, Cin, Cin, Mpp, st, shift))) return fail(r);
+        }
+        GemmArgs g;
+        gemm_args_init(g);
+        g.A = dyt; g.W = xt9; g.M = Cout; g.N = 9 * Cin; g.K = Mpp; g.lda = Mpp; g.ldw = Mpp;
+        g.C = d_dw; g.out_dtype = DT_F32; g.ldc = 9 * Cin; g.map_mode = MAP_LINEAR;
+        if ((r = launch_gemm(g, DT_BF16, st))) return fail(r);
+    }
+    cleanup();
+    return LSEG_OK;
+}
+
 }  // extern "C"

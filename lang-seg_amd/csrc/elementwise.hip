@@ -523,18 +523,29 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
 // ---- building blocks of the backward pass (first bricks of SURVEY.md §8 a17) -----------------------------------------
 // out[c, r] = in[r, c] for r < R (zero for R <= r < ldo): 16-bit matrices, 64x64 tiles through LDS.  Used to put the
 // contraction dimension of dgrad / wgrad GEMMs on the fast axis (dY^T, X^T with M padded to the GEMM's K-step).
+// `shift`: out[c, r] = in[r + shift, c] (zero outside [0, R)) -- the 9 taps of a 3x3 conv's wgrad are row shifts of the
+// padded NHWC activation.
 __global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
-                                                         int R, int C, int ldi, int ldo) {
+                                                         int R, int C, int ldi, int ldo, int shift) {
     __shared__ uint16_t t[64][66];
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-        const int rr = i >> 6, cc = i & 63, r = r0 + rr, c = c0 + cc;
-        t[rr][cc] = (r < R && c < C) ? in[(size_t)r * ldi + c] : (uint16_t)0;
+        const int rr = i >> 6, cc = i & 63, r = r0 + rr + shift, c = c0 + cc;
+        t[rr][cc] = (r >= 0 && r < R && c < C) ? in[(size_t)r * ldi + c] : (uint16_t)0;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
         const int cc = i >> 6, rr = i & 63, r = r0 + rr, c = c0 + cc;
         if (c < C && r < ldo) out[(size_t)c * ldo + r] = t[rr][cc];
+    }
+}
+// 3x3 conv dgrad weights: Wd[ci, t', co] = Wp[co, 8 - t', ci]  (taps flipped, channels swapped) so that
+// dX = conv3x3(dY, Wd) runs on the forward implicit-GEMM kernel.  Wp [Co, 9, Ci] tap-major (16-bit).
+__global__ void conv_dgrad_pack_kernel(const uint16_t* __restrict__ wp, uint16_t* __restrict__ wd, int Co, int Ci) {
+    const size_t n = (size_t)Co * 9 * Ci;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Co), t = (int)((i / Co) % 9), ci = (int)(i / ((size_t)9 * Co));    // i indexes wd
+        wd[i] = wp[((size_t)co * 9 + (8 - t)) * Ci + ci];
     }
 }
 // out[c] += sum_r in[r, c] (bias gradient); out must be zeroed; fp32 atomics across row chunks
@@ -767,9 +778,14 @@ int launch_layernorm_backward(const void* dy, int dy_dtype, const float* x, cons
     return 0;
 }
 
-int launch_transpose16(const void* in, void* out, int R, int C, int ldi, int ldo, hipStream_t st) {
+int launch_transpose16(const void* in, void* out, int R, int C, int ldi, int ldo, hipStream_t st, int shift) {
     dim3 grid((ldo + 63) / 64, (C + 63) / 64);
-    hipLaunchKernelGGL(transpose16_kernel, grid, dim3(256), 0, st, (const uint16_t*)in, (uint16_t*)out, R, C, ldi, ldo);
+    hipLaunchKernelGGL(transpose16_kernel, grid, dim3(256), 0, st, (const uint16_t*)in, (uint16_t*)out, R, C, ldi, ldo, shift);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_conv_dgrad_pack(const void* wp, void* wd, int Co, int Ci, hipStream_t st) {
+    hipLaunchKernelGGL(conv_dgrad_pack_kernel, dim3(grid_for((size_t)Co * 9 * Ci)), dim3(256), 0, st, (const uint16_t*)wp, (uint16_t*)wd, Co, Ci);
     CHECK_LAUNCH();
     return 0;
 }

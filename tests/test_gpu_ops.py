@@ -277,3 +277,26 @@ def test_layernorm_backward(lib, dy_dtype, M, D):
     _lib.check(lib.lseg_op_layernorm_backward(P(dy), DT[dy_dtype], P(x), P(gamma), P(acc), P(dg), P(dbt), M, D, 1e-6, 1, stream()))
     torch.cuda.synchronize()
     assert (acc - (1.0 + xr.grad)).abs().max().item() <= 2e-5 * max(1.0, xr.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 15, 15, 64, 64), (1, 30, 30, 128, 256), (1, 12, 20, 256, 64)])
+def test_conv3x3_backward(lib, B, H, W, Cin, Cout):
+    """Backward of the padded-NHWC 3x3 conv (stride 1, no bias): dX through the forward implicit-GEMM kernel with
+    flipped / channel-swapped weights, dW as one GEMM over nine row-shifted transposes -- against torch autograd."""
+    dt = torch.bfloat16
+    x = rnd((B, Cin, H, W), dt, 50)
+    w = rnd((Cout, Cin, 3, 3), dt, 51, 1 / math.sqrt(9 * Cin))
+    dy = rnd((B, Cout, H, W), dt, 52)
+    xr, wr = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    F.conv2d(xr, wr, None, stride=1, padding=1).backward(dy.float())
+    xp, dyp = _pad_nhwc(x, dt), _pad_nhwc(dy, dt)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    dxp = torch.zeros((B, H + 2, W + 2, Cin), dtype=dt).cuda()
+    dw = torch.empty((Cout, 9 * Cin), dtype=torch.float32).cuda()
+    _lib.check(lib.lseg_op_conv3x3_backward(P(dyp), P(xp), P(wp), P(dxp), P(dw), B, H, W, Cin, Cout, stream()))
+    torch.cuda.synchronize()
+    got_dx = dxp[:, 1:-1, 1:-1].permute(0, 3, 1, 2).float()
+    assert (got_dx - xr.grad).abs().max().item() <= 2e-2 * max(1.0, xr.grad.abs().max().item())
+    ref_dw = wr.grad.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin)
+    assert (dw - ref_dw).abs().max().item() <= 2e-3 * max(1.0, ref_dw.abs().max().item())
+    assert dxp[:, 0].abs().max().item() == 0 and dxp[:, :, -1].abs().max().item() == 0       # border stays zero
