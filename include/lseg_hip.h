@@ -221,6 +221,16 @@ int lseg_op_layernorm_backward(const void* d_dy, int dy_dtype, const float* d_x,
 int lseg_op_conv3x3_backward(const void* d_dy_pad, const void* d_x_pad, const void* d_w_packed, void* d_dx_pad, float* d_dw,
                              int B, int H, int W, int Cin, int Cout, void* stream);
 
+/* More backward bricks (autograd in the reference; each checked against torch autograd in tests/test_gpu_ops.py):
+ *   gelu_backward           d_dx = d_dy * GELU'(d_pre), erf form (timm Mlp.act), bf16/fp16 [n]
+ *   upsample2x_nhwc_backward  transpose of lseg_op_upsample2x_nhwc: d_dout [B,2H,2W,C] bf16 -> d_din_pad [B,H+2,W+2,C] interior
+ *   softmax_ce_backward     d_dscores [B,K,H,W] fp32 = (softmax_k - 1[k = target]) / n_valid (0 at ignored pixels);
+ *                           d_nll = the double[2] written by lseg_op_seg_stats (n_valid in d_nll[1]) */
+int lseg_op_gelu_backward(const void* d_dy, const void* d_pre, void* d_dx, int64_t n, int dtype, void* stream);
+int lseg_op_upsample2x_nhwc_backward(const void* d_dout, void* d_din_pad, int B, int H, int W, int C, void* stream);
+int lseg_op_softmax_ce_backward(const float* d_scores, const int64_t* d_target, float* d_dscores, int B, int K, int H, int W,
+                                int ignore_index, const double* d_nll, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

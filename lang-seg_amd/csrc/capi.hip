@@ -289,4 +289,25 @@ int lseg_op_conv3x3_backward(const void* d_dy_pad, const void* d_x_pad, const vo
     return LSEG_OK;
 }
 
+int lseg_op_gelu_backward(const void* d_dy, const void* d_pre, void* d_dx, int64_t n, int dtype, void* stream) {
+    int r = require_device(); if (r) return r;
+    int dt;
+    if ((r = op_dt(dtype, &dt))) return r;
+    if (dt == DT_F32 || !d_dy || !d_pre || !d_dx || n < 1) return set_error(LSEG_ERR_INVALID, "gelu_backward: bf16/fp16 tensors, n >= 1");
+    return launch_gelu_backward(d_dy, d_pre, d_dx, (size_t)n, dt, (hipStream_t)stream);
+}
+
+int lseg_op_upsample2x_nhwc_backward(const void* d_dout, void* d_din_pad, int B, int H, int W, int C, void* stream) {
+    int r = require_device(); if (r) return r;
+    if (!d_dout || !d_din_pad || B < 1 || H < 2 || W < 2) return set_error(LSEG_ERR_INVALID, "upsample2x_nhwc_backward: bad arguments");
+    return launch_upsample2x_nhwc_backward(d_dout, d_din_pad, B, H, W, C, DT_BF16, (hipStream_t)stream);
+}
+
+int lseg_op_softmax_ce_backward(const float* d_scores, const int64_t* d_target, float* d_dscores, int B, int K, int H, int W,
+                                int ignore_index, const double* d_nll, void* stream) {
+    int r = require_device(); if (r) return r;
+    if (!d_scores || !d_target || !d_dscores || !d_nll || B < 1 || K < 1) return set_error(LSEG_ERR_INVALID, "softmax_ce_backward: bad arguments");
+    return launch_softmax_ce_backward(d_scores, d_target, d_dscores, B, K, H * W, ignore_index, d_nll, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -548,6 +548,84 @@ __global__ void conv_dgrad_pack_kernel(const uint16_t* __restrict__ wp, uint16_t
         wd[i] = wp[((size_t)co * 9 + (8 - t)) * Ci + ci];
     }
 }
+// GELU (erf form, timm Mlp.act) backward: dx = dy * (Phi(z) + z * phi(z)), z = the pre-activation (fc1 output + bias).
+__global__ void gelu_backward_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ pre, uint16_t* __restrict__ dx,
+                                     size_t n, int dtype) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float z = load_as_f32(pre, i, dtype), g = load_as_f32(dy, i, dtype);
+        const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752f));
+        const float pdf = 0.3989422804014327f * __expf(-0.5f * z * z);
+        store_from_f32(dx, i, dtype, g * (cdf + z * pdf));
+    }
+}
+// x2 bilinear (align_corners=True) backward, NHWC 16-bit: d_in (padded [B,H+2,W+2,C], interior written) gathers the
+// tent-weighted d_out [B,2H,2W,C] -- the transpose of upsample2x_nhwc_kernel (refinenet upsample, lseg_blocks.py:352-354).
+__global__ void upsample2x_nhwc_bwd_kernel(const uint16_t* __restrict__ dout, uint16_t* __restrict__ din, int B, int H, int W,
+                                           int C, int dtype) {
+    const int c8n = C / 8, Ho = 2 * H, Wo = 2 * W;
+    const unsigned total = (unsigned)B * H * W * c8n;
+    const float ry = (float)(H - 1) / (float)(Ho - 1), rx = (float)(W - 1) / (float)(Wo - 1);
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int c8 = (int)(idx % (unsigned)c8n);
+        unsigned p = idx / (unsigned)c8n;
+        const int x = (int)(p % (unsigned)W); p /= (unsigned)W;
+        const int y = (int)(p % (unsigned)H);
+        const int b = (int)(p / (unsigned)H);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // output rows whose source coordinate lies within one pixel of y (forward: y0 = floor(sy), weights 1-ly / ly)
+        const int ya = max(0, 2 * y - 2), yb = min(Ho - 1, 2 * y + 3), xa = max(0, 2 * x - 2), xb = min(Wo - 1, 2 * x + 3);
+        for (int yo = ya; yo <= yb; ++yo) {
+            const float sy = ry * (float)yo;
+            const int y0 = (int)sy, y1 = y0 + (y0 < H - 1);
+            const float ly = sy - (float)y0;
+            const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int xo = xa; xo <= xb; ++xo) {
+                const float sx = rx * (float)xo;
+                const int x0 = (int)sx, x1 = x0 + (x0 < W - 1);
+                const float lx = sx - (float)x0;
+                const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+                if (wx == 0.f) continue;
+                const uint4 v = *reinterpret_cast<const uint4*>(dout + (((size_t)b * Ho + yo) * Wo + xo) * C + (size_t)c8 * 8);
+                const uint16_t* e = reinterpret_cast<const uint16_t*>(&v);
+                const float wgt = wy * wx;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[k] += wgt * load_as_f32(e, k, dtype);
+            }
+        }
+        uint32_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = pack2_dt(acc[2 * k], acc[2 * k + 1], dtype);
+        *reinterpret_cast<uint4*>(din + (((size_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * C + (size_t)c8 * 8) =
+            make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+// d logits of mean cross-entropy (CrossEntropyLoss(ignore_index) over [B,K,H,W]): (softmax_k - 1[k = t]) / n_valid, 0 at
+// ignored pixels.  One thread per pixel, two passes over the K planes.
+__global__ void softmax_ce_backward_kernel(const float* __restrict__ scores, const long long* __restrict__ target, float* __restrict__ dz,
+                                           int K, int HW, size_t npix, int ignore_index, const double* __restrict__ nll) {
+    const float inv_n = nll[1] > 0.0 ? (float)(1.0 / nll[1]) : 0.f;          // nll[1] = number of valid pixels (seg_stats)
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i % HW);
+        const size_t b = i / HW;
+        const float* col = scores + b * (size_t)K * HW + p;
+        float* out = dz + b * (size_t)K * HW + p;
+        const long long t = target[i];
+        const bool valid = t != (long long)ignore_index && t >= 0 && t < K;
+        if (!valid) {
+            for (int k = 0; k < K; ++k) out[(size_t)k * HW] = 0.f;
+            continue;
+        }
+        float m = -INFINITY, ssum = 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float v = col[(size_t)k * HW];
+            if (v > m) { ssum = ssum * __expf(m - v) + 1.f; m = v; } else { ssum += __expf(v - m); }
+        }
+        const float inv_s = 1.f / ssum;
+        for (int k = 0; k < K; ++k)
+            out[(size_t)k * HW] = (__expf(col[(size_t)k * HW] - m) * inv_s - (k == t ? 1.f : 0.f)) * inv_n;
+    }
+}
 // out[c] += sum_r in[r, c] (bias gradient); out must be zeroed; fp32 atomics across row chunks
 __global__ void colsum16_kernel(const uint16_t* __restrict__ in, int dtype, float* __restrict__ out, int R, int C, int ld,
                                 int rows_per_block) {
@@ -786,6 +864,26 @@ int launch_transpose16(const void* in, void* out, int R, int C, int ldi, int ldo
 }
 int launch_conv_dgrad_pack(const void* wp, void* wd, int Co, int Ci, hipStream_t st) {
     hipLaunchKernelGGL(conv_dgrad_pack_kernel, dim3(grid_for((size_t)Co * 9 * Ci)), dim3(256), 0, st, (const uint16_t*)wp, (uint16_t*)wd, Co, Ci);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_gelu_backward(const void* dy, const void* pre, void* dx, size_t n, int dtype, hipStream_t st) {
+    hipLaunchKernelGGL(gelu_backward_kernel, dim3(grid_for(n)), dim3(256), 0, st, (const uint16_t*)dy, (const uint16_t*)pre, (uint16_t*)dx, n, dtype);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_upsample2x_nhwc_backward(const void* dout, void* din, int B, int H, int W, int C, int dtype, hipStream_t st) {
+    if (C % 8) return set_error(LSEG_ERR_UNSUPPORTED, "upsample2x_nhwc backward: C=%d", C);
+    const size_t total = (size_t)B * H * W * (C / 8);
+    hipLaunchKernelGGL(upsample2x_nhwc_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, st, (const uint16_t*)dout, (uint16_t*)din, B, H, W, C, dtype);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_softmax_ce_backward(const float* scores, const int64_t* target, float* dz, int B, int K, int HW, int ignore_index,
+                               const double* nll, hipStream_t st) {
+    const size_t npix = (size_t)B * HW;
+    hipLaunchKernelGGL(softmax_ce_backward_kernel, dim3(grid_for(npix)), dim3(256), 0, st, scores,
+                       reinterpret_cast<const long long*>(target), dz, K, HW, npix, ignore_index, nll);
     CHECK_LAUNCH();
     return 0;
 }

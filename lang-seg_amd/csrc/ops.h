@@ -35,6 +35,10 @@ int launch_argmax_planes(const float* in, uint8_t* out, int B, int K, int HW, hi
 int launch_layernorm_backward(const void* dy, int dy_dtype, const float* x, const float* gamma, float* dx, float* dgamma,
                               float* dbeta, int M, int D, float eps, int accumulate, hipStream_t st);
 int launch_transpose16(const void* in, void* out, int R, int C, int ldi, int ldo, hipStream_t st, int shift = 0);
+int launch_gelu_backward(const void* dy, const void* pre, void* dx, size_t n, int dtype, hipStream_t st);
+int launch_upsample2x_nhwc_backward(const void* dout, void* din, int B, int H, int W, int C, int dtype, hipStream_t st);
+int launch_softmax_ce_backward(const float* scores, const int64_t* target, float* dz, int B, int K, int HW, int ignore_index,
+                               const double* nll, hipStream_t st);
 int launch_conv_dgrad_pack(const void* wp, void* wd, int Co, int Ci, hipStream_t st);
 int launch_colsum16(const void* in, int dtype, float* out, int R, int C, int ld, hipStream_t st);
 int launch_seg_stats(const float* scores, const int64_t* target, int B, int K, int HW, int ignore_index,

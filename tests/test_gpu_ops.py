@@ -300,3 +300,50 @@ def test_conv3x3_backward(lib, B, H, W, Cin, Cout):
     ref_dw = wr.grad.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin)
     assert (dw - ref_dw).abs().max().item() <= 2e-3 * max(1.0, ref_dw.abs().max().item())
     assert dxp[:, 0].abs().max().item() == 0 and dxp[:, :, -1].abs().max().item() == 0       # border stays zero
+
+
+def test_gelu_backward(lib):
+    dt = torch.bfloat16
+    pre, dy = rnd((4099,), dt, 60, 2.0), rnd((4099,), dt, 61)
+    pr = pre.float().requires_grad_(True)
+    F.gelu(pr).backward(dy.float())
+    dx = torch.empty_like(pre)
+    _lib.check(lib.lseg_op_gelu_backward(P(dy), P(pre), P(dx), 4099, DT[dt], stream()))
+    torch.cuda.synchronize()
+    assert (dx.float() - pr.grad).abs().max().item() <= 2 ** -7 * max(1.0, pr.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("B,H,W,Cc", [(2, 15, 15, 64), (1, 8, 20, 256), (1, 2, 2, 8)])
+def test_upsample2x_nhwc_backward(lib, B, H, W, Cc):
+    """Transpose of the x2 bilinear (align_corners=True) NHWC upsample against torch autograd."""
+    dt = torch.bfloat16
+    dout = rnd((B, Cc, 2 * H, 2 * W), dt, 62)
+    xr = torch.zeros((B, Cc, H, W), device="cuda", requires_grad=True)
+    F.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=True).backward(dout.float())
+    din = torch.zeros((B, H + 2, W + 2, Cc), dtype=dt).cuda()
+    dout_nhwc = dout.permute(0, 2, 3, 1).contiguous()
+    _lib.check(lib.lseg_op_upsample2x_nhwc_backward(P(dout_nhwc), P(din), B, H, W, Cc, stream()))
+    torch.cuda.synchronize()
+    got = din[:, 1:-1, 1:-1].permute(0, 3, 1, 2).float()
+    assert (got - xr.grad).abs().max().item() <= 2e-2 * max(1.0, xr.grad.abs().max().item())
+    assert din[:, 0].abs().max().item() == 0 and din[:, :, 0].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("B,K,H,W", [(2, 7, 24, 20), (1, 150, 32, 32)])
+def test_softmax_ce_backward(lib, B, K, H, W):
+    """d logits of CrossEntropyLoss(ignore_index=-1) (mean over valid pixels), chained behind lseg_op_seg_stats."""
+    g = torch.Generator().manual_seed(K)
+    scores = (torch.randn((B, K, H, W), generator=g) * 3).cuda()
+    target = torch.randint(0, K, (B, H, W), generator=g)
+    target[torch.rand((B, H, W), generator=g) < 0.25] = -1
+    target = target.cuda()
+    sr = scores.clone().requires_grad_(True)
+    F.cross_entropy(sr, target, ignore_index=-1).backward()
+    counts = torch.empty(2 + 3 * K, dtype=torch.int64, device="cuda")
+    nll = torch.empty(2, dtype=torch.float64, device="cuda")
+    _lib.check(lib.lseg_op_seg_stats(P(scores), P(target), B, K, H, W, -1, P(counts), P(nll), stream()))
+    dz = torch.empty_like(scores)
+    _lib.check(lib.lseg_op_softmax_ce_backward(P(scores), P(target), P(dz), B, K, H, W, -1, P(nll), stream()))
+    torch.cuda.synchronize()
+    assert (dz - sr.grad).abs().max().item() <= 1e-5 * max(1e-3, sr.grad.abs().max().item()) + 1e-9
+    assert dz[(target < 0).unsqueeze(1).expand_as(dz)].abs().max().item() == 0
