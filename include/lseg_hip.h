@@ -231,6 +231,15 @@ int lseg_op_upsample2x_nhwc_backward(const void* d_dout, void* d_din_pad, int B,
 int lseg_op_softmax_ce_backward(const float* d_scores, const int64_t* d_target, float* d_dscores, int B, int K, int H, int W,
                                 int ignore_index, const double* d_nll, void* stream);
 
+/* Backward of lseg_op_attention (softmax(Q K^T * scale) V, head_dim 64, no mask), flash-style recomputation; the
+ * reference gets it from autograd through [3P] timm Attention.forward (lseg_vit.py:196-197).
+ * d_q,d_k [BH,Npad,64], d_vt [BH,64,Npad], d_o / d_do [B,Ntok,H*64] (forward layouts, bf16/fp16);
+ * d_lse2 [BH,Npad] fp32 = log2 of each query row's sum_k exp2(s_k * scale * log2e)  (the forward's running statistics);
+ * outputs fp32 d_dq, d_dk, d_dv [BH,Npad,64] (rows >= Ntok of dk/dv are zero; dq is zeroed here, then accumulated). */
+int lseg_op_attention_backward(const void* d_q, const void* d_k, const void* d_vt, const void* d_o, const void* d_do,
+                               const float* d_lse2, float* d_dq, float* d_dk, float* d_dv, int B, int H, int Ntok, int Npad,
+                               int dtype, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

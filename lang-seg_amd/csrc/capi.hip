@@ -310,4 +310,18 @@ int lseg_op_softmax_ce_backward(const float* d_scores, const int64_t* d_target, 
     return launch_softmax_ce_backward(d_scores, d_target, d_dscores, B, K, H * W, ignore_index, d_nll, (hipStream_t)stream);
 }
 
+int lseg_op_attention_backward(const void* d_q, const void* d_k, const void* d_vt, const void* d_o, const void* d_do,
+                               const float* d_lse2, float* d_dq, float* d_dk, float* d_dv, int B, int H, int Ntok, int Npad,
+                               int dtype, float scale, void* stream) {
+    int r = require_device(); if (r) return r;
+    int dt;
+    if ((r = op_dt(dtype, &dt))) return r;
+    if (!d_q || !d_k || !d_vt || !d_o || !d_do || !d_lse2 || !d_dq || !d_dk || !d_dv)
+        return set_error(LSEG_ERR_INVALID, "attention_backward: NULL pointer");
+    if (B < 1 || H < 1 || Ntok < 1) return set_error(LSEG_ERR_INVALID, "attention_backward: bad shape");
+    if (hipMemsetAsync(d_dq, 0, (size_t)B * H * Npad * 64 * sizeof(float), (hipStream_t)stream) != hipSuccess)
+        return set_error(LSEG_ERR_HIP, "attention_backward: memset failed");
+    return launch_attention_backward(d_q, d_k, d_vt, d_o, d_do, d_lse2, d_dq, d_dk, d_dv, B, H, Ntok, Npad, dt, scale, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -35,6 +35,9 @@ int launch_argmax_planes(const float* in, uint8_t* out, int B, int K, int HW, hi
 int launch_layernorm_backward(const void* dy, int dy_dtype, const float* x, const float* gamma, float* dx, float* dgamma,
                               float* dbeta, int M, int D, float eps, int accumulate, hipStream_t st);
 int launch_transpose16(const void* in, void* out, int R, int C, int ldi, int ldo, hipStream_t st, int shift = 0);
+int launch_attention_backward(const void* q, const void* k, const void* vt, const void* o, const void* d_o, const float* lse2,
+                              float* dq, float* dk, float* dv, int B, int H, int ntok, int npad, int dtype, float scale,
+                              hipStream_t stream);
 int launch_gelu_backward(const void* dy, const void* pre, void* dx, size_t n, int dtype, hipStream_t st);
 int launch_upsample2x_nhwc_backward(const void* dout, void* din, int B, int H, int W, int C, int dtype, hipStream_t st);
 int launch_softmax_ce_backward(const float* scores, const int64_t* target, float* dz, int B, int K, int HW, int ignore_index,
