@@ -240,6 +240,11 @@ int lseg_op_attention_backward(const void* d_q, const void* d_k, const void* d_v
                                const float* d_lse2, float* d_dq, float* d_dk, float* d_dv, int B, int H, int Ntok, int Npad,
                                int dtype, float scale, void* stream);
 
+/* d(qkv Linear output) [B*Ntok, 3*H*64] (bf16/fp16) from the attention backward's fp32 d_dq, d_dk, d_dv [BH,Npad,64]:
+ * the inverse of the QKV GEMM epilogue's head-major scatter; feeds lseg_op_linear_backward of the qkv layer. */
+int lseg_op_qkv_grad_pack(const float* d_dq, const float* d_dk, const float* d_dv, void* d_dqkv, int B, int H, int Ntok, int Npad,
+                          int out_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

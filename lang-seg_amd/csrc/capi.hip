@@ -324,4 +324,13 @@ int lseg_op_attention_backward(const void* d_q, const void* d_k, const void* d_v
     return launch_attention_backward(d_q, d_k, d_vt, d_o, d_do, d_lse2, d_dq, d_dk, d_dv, B, H, Ntok, Npad, dt, scale, (hipStream_t)stream);
 }
 
+int lseg_op_qkv_grad_pack(const float* d_dq, const float* d_dk, const float* d_dv, void* d_dqkv, int B, int H, int Ntok, int Npad,
+                          int out_dtype, void* stream) {
+    int r = require_device(); if (r) return r;
+    int dt;
+    if ((r = op_dt(out_dtype, &dt))) return r;
+    if (dt == DT_F32 || !d_dq || !d_dk || !d_dv || !d_dqkv) return set_error(LSEG_ERR_INVALID, "qkv_grad_pack: bf16/fp16 output, non-NULL pointers");
+    return launch_qkv_grad_pack(d_dq, d_dk, d_dv, d_dqkv, B, H, Ntok, Npad, dt, (hipStream_t)stream);
+}
+
 }  // extern "C"

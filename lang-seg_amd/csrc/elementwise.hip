@@ -626,6 +626,21 @@ __global__ void softmax_ce_backward_kernel(const float* __restrict__ scores, con
             out[(size_t)k * HW] = (__expf(col[(size_t)k * HW] - m) * inv_s - (k == t ? 1.f : 0.f)) * inv_n;
     }
 }
+// Gradient of the QKV projection's output from the attention backward's head-major fp32 tensors: the inverse of the
+// QKV GEMM epilogue's scatter (q,k,v [BH, Npad, 64] -> row m = (b, t), column which*D + head*64 + d), 16-bit out.
+__global__ void qkv_grad_pack_kernel(const float* __restrict__ dq, const float* __restrict__ dk, const float* __restrict__ dv,
+                                     uint16_t* __restrict__ out, int B, int H, int ntok, int npad, int dtype) {
+    const int D = H * 64;
+    const size_t n = (size_t)B * ntok * 3 * D;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int col = (int)(i % (3 * D));
+        const size_t m = i / (3 * D);
+        const int t = (int)(m % ntok), b = (int)(m / ntok);
+        const int which = col / D, rem = col - which * D, h = rem >> 6, d = rem & 63;
+        const float* src = which == 0 ? dq : (which == 1 ? dk : dv);
+        store_from_f32(out, i, dtype, src[(((size_t)b * H + h) * npad + t) * 64 + d]);
+    }
+}
 // out[c] += sum_r in[r, c] (bias gradient); out must be zeroed; fp32 atomics across row chunks
 __global__ void colsum16_kernel(const uint16_t* __restrict__ in, int dtype, float* __restrict__ out, int R, int C, int ld,
                                 int rows_per_block) {
@@ -884,6 +899,13 @@ int launch_softmax_ce_backward(const float* scores, const int64_t* target, float
     const size_t npix = (size_t)B * HW;
     hipLaunchKernelGGL(softmax_ce_backward_kernel, dim3(grid_for(npix)), dim3(256), 0, st, scores,
                        reinterpret_cast<const long long*>(target), dz, K, HW, npix, ignore_index, nll);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_qkv_grad_pack(const float* dq, const float* dk, const float* dv, void* out, int B, int H, int ntok, int npad, int dtype,
+                         hipStream_t st) {
+    hipLaunchKernelGGL(qkv_grad_pack_kernel, dim3(grid_for((size_t)B * ntok * 3 * H * 64)), dim3(256), 0, st, dq, dk, dv,
+                       (uint16_t*)out, B, H, ntok, npad, dtype);
     CHECK_LAUNCH();
     return 0;
 }
