@@ -245,6 +245,18 @@ int lseg_op_attention_backward(const void* d_q, const void* d_k, const void* d_v
 int lseg_op_qkv_grad_pack(const float* d_dq, const float* d_dk, const float* d_dv, void* d_dqkv, int B, int H, int Ntok, int Npad,
                           int out_dtype, void* stream);
 
+/* Train-mode BatchNorm2d on the padded-NHWC bf16 maps (ResidualConvUnit_custom bn1/bn2 under net.train(),
+ * lseg_blocks.py:276-283; the reference runs SyncBatchNorm, i.e. d_stats / the backward sums are what a multi-GPU step
+ * all-reduces).  Maps are [B,H+2,W+2,C] with a zero border; statistics over the B*H*W image pixels, biased variance.
+ *   forward : d_stats [2C] fp32 = {sum x, sum x^2}; d_y_pad (may be NULL: statistics only) = gamma*(x-mean)*rstd + beta
+ *   backward: d_dx_pad = gamma*rstd*(dy - mean(dy) - xhat*mean(dy*xhat)); d_dgamma_dbeta [2C] = {dbeta = sum dy, dgamma = sum dy*xhat}
+ * relu_backward: d_dx = d_dy where d_x > 0 (bf16/fp16, n elements). */
+int lseg_op_bn_train_forward(const void* d_x_pad, void* d_y_pad, float* d_stats, const float* d_gamma, const float* d_beta,
+                             int B, int H, int W, int C, float eps, void* stream);
+int lseg_op_bn_train_backward(const void* d_dy_pad, const void* d_x_pad, const float* d_stats, const float* d_gamma, void* d_dx_pad,
+                              float* d_dgamma_dbeta, int B, int H, int W, int C, float eps, void* stream);
+int lseg_op_relu_backward(const void* d_dy, const void* d_x, void* d_dx, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

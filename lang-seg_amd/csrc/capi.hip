@@ -333,4 +333,24 @@ int lseg_op_qkv_grad_pack(const float* d_dq, const float* d_dk, const float* d_d
     return launch_qkv_grad_pack(d_dq, d_dk, d_dv, d_dqkv, B, H, Ntok, Npad, dt, (hipStream_t)stream);
 }
 
+int lseg_op_bn_train_forward(const void* d_x_pad, void* d_y_pad, float* d_stats, const float* d_gamma, const float* d_beta,
+                             int B, int H, int W, int C, float eps, void* stream) {
+    int r = require_device(); if (r) return r;
+    if (!d_x_pad || !d_stats || (d_y_pad && (!d_gamma || !d_beta))) return set_error(LSEG_ERR_INVALID, "bn_train_forward: NULL pointer");
+    return launch_bn_train_forward(d_x_pad, d_y_pad, d_stats, d_gamma, d_beta, B, H, W, C, eps, DT_BF16, (hipStream_t)stream);
+}
+
+int lseg_op_bn_train_backward(const void* d_dy_pad, const void* d_x_pad, const float* d_stats, const float* d_gamma, void* d_dx_pad,
+                              float* d_dgamma_dbeta, int B, int H, int W, int C, float eps, void* stream) {
+    int r = require_device(); if (r) return r;
+    if (!d_dy_pad || !d_x_pad || !d_stats || !d_gamma || !d_dx_pad || !d_dgamma_dbeta) return set_error(LSEG_ERR_INVALID, "bn_train_backward: NULL pointer");
+    return launch_bn_train_backward(d_dy_pad, d_x_pad, d_stats, d_gamma, d_dx_pad, d_dgamma_dbeta, B, H, W, C, eps, DT_BF16, (hipStream_t)stream);
+}
+
+int lseg_op_relu_backward(const void* d_dy, const void* d_x, void* d_dx, int64_t n, void* stream) {
+    int r = require_device(); if (r) return r;
+    if (!d_dy || !d_x || !d_dx || n < 1) return set_error(LSEG_ERR_INVALID, "relu_backward: bad arguments");
+    return launch_relu_backward(d_dy, d_x, d_dx, (size_t)n, (hipStream_t)stream);
+}
+
 }  // extern "C"

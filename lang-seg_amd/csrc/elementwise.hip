@@ -641,6 +641,79 @@ __global__ void qkv_grad_pack_kernel(const float* __restrict__ dq, const float* 
         store_from_f32(out, i, dtype, src[(((size_t)b * H + h) * npad + t) * 64 + d]);
     }
 }
+// ---- train-mode BatchNorm2d on the padded-NHWC maps (DPT ResidualConvUnit bn1/bn2, lseg_blocks.py:276-283, train()) ----
+// The maps carry a zero border, so per-channel sums over ALL padded positions equal the sums over the image; n = B*H*W.
+// stats[0..C) = sum_x, stats[C..2C) = sum_x^2   (fp32 atomics over row chunks; zeroed by the launcher)
+__global__ void bn_stats_kernel(const uint16_t* __restrict__ x, int dtype, float* __restrict__ stats, int Mp, int C, int rows_per_block) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(Mp, r0 + rows_per_block);
+    float s = 0.f, q = 0.f;
+    for (int r = r0; r < r1; ++r) { const float v = load_as_f32(x, (size_t)r * C + c, dtype); s += v; q += v * v; }
+    atomicAdd(&stats[c], s);
+    atomicAdd(&stats[C + c], q);
+}
+// y = gamma * (x - mean) * rstd + beta on the interior pixels (the border stays zero); mean/var from bn_stats (biased var)
+__global__ void bn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, const float* __restrict__ stats,
+                                const float* __restrict__ gamma, const float* __restrict__ beta, int B, int H, int W, int C,
+                                float eps, int dtype) {
+    const size_t n = (size_t)B * H * W * C;
+    const float inv_n = 1.0f / (float)((size_t)B * H * W);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t p = i / C;
+        const int xx = (int)(p % W); p /= W;
+        const int yy = (int)(p % H);
+        const int b = (int)(p / H);
+        const size_t off = (((size_t)b * (H + 2) + yy + 1) * (W + 2) + xx + 1) * C + c;
+        const float mean = stats[c] * inv_n;
+        const float var = fmaxf(stats[C + c] * inv_n - mean * mean, 0.f);
+        store_from_f32(y, off, dtype, gamma[c] * (load_as_f32(x, off, dtype) - mean) * rsqrtf(var + eps) + beta[c]);
+    }
+}
+// backward sums: bstats[0..C) = sum dy, bstats[C..2C) = sum dy * xhat
+__global__ void bn_bwd_stats_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x, const float* __restrict__ stats,
+                                    float* __restrict__ bstats, int Mp, int C, float inv_n, float eps, int dtype, int rows_per_block) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mean = stats[c] * inv_n;
+    const float rstd = rsqrtf(fmaxf(stats[C + c] * inv_n - mean * mean, 0.f) + eps);
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(Mp, r0 + rows_per_block);
+    float s = 0.f, q = 0.f;
+    for (int r = r0; r < r1; ++r) {
+        const float g = load_as_f32(dy, (size_t)r * C + c, dtype);
+        s += g;
+        q += g * (load_as_f32(x, (size_t)r * C + c, dtype) - mean) * rstd;      // border: g = 0
+    }
+    atomicAdd(&bstats[c], s);
+    atomicAdd(&bstats[C + c], q);
+}
+// dx = gamma * rstd * (dy - mean(dy) - xhat * mean(dy * xhat)) on the interior
+__global__ void bn_bwd_apply_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x, uint16_t* __restrict__ dx,
+                                    const float* __restrict__ stats, const float* __restrict__ bstats, const float* __restrict__ gamma,
+                                    int B, int H, int W, int C, float eps, int dtype) {
+    const size_t n = (size_t)B * H * W * C;
+    const float inv_n = 1.0f / (float)((size_t)B * H * W);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t p = i / C;
+        const int xx = (int)(p % W); p /= W;
+        const int yy = (int)(p % H);
+        const int b = (int)(p / H);
+        const size_t off = (((size_t)b * (H + 2) + yy + 1) * (W + 2) + xx + 1) * C + c;
+        const float mean = stats[c] * inv_n;
+        const float rstd = rsqrtf(fmaxf(stats[C + c] * inv_n - mean * mean, 0.f) + eps);
+        const float xh = (load_as_f32(x, off, dtype) - mean) * rstd;
+        store_from_f32(dx, off, dtype, gamma[c] * rstd * (load_as_f32(dy, off, dtype) - bstats[c] * inv_n - xh * bstats[C + c] * inv_n));
+    }
+}
+// ReLU backward: dx = dy where x > 0 (16-bit tensors of any shape)
+__global__ void relu_backward_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x, uint16_t* __restrict__ dx, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint16_t v = x[i];
+        dx[i] = (v != 0 && !(v & 0x8000)) ? dy[i] : (uint16_t)0;       // positive <=> sign bit clear and not zero (bf16 and fp16)
+    }
+}
 // out[c] += sum_r in[r, c] (bias gradient); out must be zeroed; fp32 atomics across row chunks
 __global__ void colsum16_kernel(const uint16_t* __restrict__ in, int dtype, float* __restrict__ out, int R, int C, int ld,
                                 int rows_per_block) {
@@ -906,6 +979,37 @@ int launch_qkv_grad_pack(const float* dq, const float* dk, const float* dv, void
                          hipStream_t st) {
     hipLaunchKernelGGL(qkv_grad_pack_kernel, dim3(grid_for((size_t)B * ntok * 3 * H * 64)), dim3(256), 0, st, dq, dk, dv,
                        (uint16_t*)out, B, H, ntok, npad, dtype);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_bn_train_forward(const void* x, void* y, float* stats, const float* gamma, const float* beta, int B, int H, int W, int C,
+                            float eps, int dtype, hipStream_t st) {
+    const int Mp = B * (H + 2) * (W + 2), rpb = 128;
+    LSEG_HIP_TRY(hipMemsetAsync(stats, 0, (size_t)2 * C * sizeof(float), st));
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((C + 255) / 256, (Mp + rpb - 1) / rpb), dim3(256), 0, st, (const uint16_t*)x, dtype, stats, Mp, C, rpb);
+    CHECK_LAUNCH();
+    if (y) {
+        hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for((size_t)B * H * W * C)), dim3(256), 0, st, (const uint16_t*)x, (uint16_t*)y,
+                           stats, gamma, beta, B, H, W, C, eps, dtype);
+        CHECK_LAUNCH();
+    }
+    return 0;
+}
+int launch_bn_train_backward(const void* dy, const void* x, const float* stats, const float* gamma, void* dx, float* bstats,
+                             int B, int H, int W, int C, float eps, int dtype, hipStream_t st) {
+    const int Mp = B * (H + 2) * (W + 2), rpb = 128;
+    const float inv_n = 1.0f / (float)((size_t)B * H * W);
+    LSEG_HIP_TRY(hipMemsetAsync(bstats, 0, (size_t)2 * C * sizeof(float), st));
+    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((C + 255) / 256, (Mp + rpb - 1) / rpb), dim3(256), 0, st, (const uint16_t*)dy,
+                       (const uint16_t*)x, stats, bstats, Mp, C, inv_n, eps, dtype, rpb);
+    CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((size_t)B * H * W * C)), dim3(256), 0, st, (const uint16_t*)dy,
+                       (const uint16_t*)x, (uint16_t*)dx, stats, bstats, gamma, B, H, W, C, eps, dtype);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_relu_backward(const void* dy, const void* x, void* dx, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(relu_backward_kernel, dim3(grid_for(n)), dim3(256), 0, st, (const uint16_t*)dy, (const uint16_t*)x, (uint16_t*)dx, n);
     CHECK_LAUNCH();
     return 0;
 }

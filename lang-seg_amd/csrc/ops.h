@@ -38,6 +38,11 @@ int launch_transpose16(const void* in, void* out, int R, int C, int ldi, int ldo
 int launch_attention_backward(const void* q, const void* k, const void* vt, const void* o, const void* d_o, const float* lse2,
                               float* dq, float* dk, float* dv, int B, int H, int ntok, int npad, int dtype, float scale,
                               hipStream_t stream);
+int launch_bn_train_forward(const void* x, void* y, float* stats, const float* gamma, const float* beta, int B, int H, int W, int C,
+                            float eps, int dtype, hipStream_t st);
+int launch_bn_train_backward(const void* dy, const void* x, const float* stats, const float* gamma, void* dx, float* bstats,
+                             int B, int H, int W, int C, float eps, int dtype, hipStream_t st);
+int launch_relu_backward(const void* dy, const void* x, void* dx, size_t n, hipStream_t st);
 int launch_qkv_grad_pack(const float* dq, const float* dk, const float* dv, void* out, int B, int H, int ntok, int npad, int dtype,
                          hipStream_t st);
 int launch_gelu_backward(const void* dy, const void* pre, void* dx, size_t n, int dtype, hipStream_t st);

@@ -378,3 +378,37 @@ def test_attention_backward(lib, dtype, B, H, N):
         err = (g - want).abs().max().item()
         assert math.isfinite(err) and err <= tol * max(1.0, want.abs().max().item()), (name, err, want.abs().max().item())
     assert dk[:, N:((N + 63) // 64) * 64].abs().max().item() == 0 if N % 64 else True      # masked keys get no gradient
+
+
+@pytest.mark.parametrize("B,H,W,Cc", [(2, 15, 15, 64), (1, 12, 20, 256)])
+def test_batchnorm_train_forward_backward(lib, B, H, W, Cc):
+    """Train-mode BatchNorm2d (batch statistics, biased variance) on the padded-NHWC bf16 maps and its backward against
+    torch autograd; plus the ReLU mask."""
+    dt = torch.bfloat16
+    x = rnd((B, Cc, H, W), dt, 80, 1.5) + 0.25
+    dy = rnd((B, Cc, H, W), dt, 81)
+    gamma = (1.0 + 0.1 * rnd((Cc,), torch.float32, 82)).contiguous()
+    beta = (0.1 * rnd((Cc,), torch.float32, 83)).contiguous()
+    xr, gr, br = x.float().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yr = F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5)
+    yr.backward(dy.float())
+    xp, dyp = _pad_nhwc(x, dt), _pad_nhwc(dy, dt)
+    yp, dxp = torch.zeros_like(xp), torch.zeros_like(xp)
+    stats = torch.empty(2 * Cc, dtype=torch.float32).cuda()
+    bst = torch.empty(2 * Cc, dtype=torch.float32).cuda()
+    _lib.check(lib.lseg_op_bn_train_forward(P(xp), P(yp), P(stats), P(gamma), P(beta), B, H, W, Cc, 1e-5, stream()))
+    _lib.check(lib.lseg_op_bn_train_backward(P(dyp), P(xp), P(stats), P(gamma), P(dxp), P(bst), B, H, W, Cc, 1e-5, stream()))
+    torch.cuda.synchronize()
+    n = B * H * W
+    assert (stats[:Cc] / n - x.float().mean(dim=(0, 2, 3))).abs().max().item() <= 1e-4
+    got_y = yp[:, 1:-1, 1:-1].permute(0, 3, 1, 2).float()
+    assert (got_y - yr.detach()).abs().max().item() <= 2e-2 * max(1.0, yr.abs().max().item())
+    got_dx = dxp[:, 1:-1, 1:-1].permute(0, 3, 1, 2).float()
+    assert (got_dx - xr.grad).abs().max().item() <= 2e-2 * max(1.0, xr.grad.abs().max().item())
+    assert (bst[:Cc] - br.grad).abs().max().item() <= 2e-3 * max(1.0, br.grad.abs().max().item())
+    assert (bst[Cc:] - gr.grad).abs().max().item() <= 2e-3 * max(1.0, gr.grad.abs().max().item())
+    assert yp[:, 0].abs().max().item() == 0 and dxp[:, :, -1].abs().max().item() == 0          # borders stay zero
+    m = torch.empty_like(dyp)
+    _lib.check(lib.lseg_op_relu_backward(P(dyp), P(xp), P(m), xp.numel(), stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(m, torch.where(xp.float() > 0, dyp, torch.zeros_like(dyp)))
