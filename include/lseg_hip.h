@@ -257,6 +257,16 @@ int lseg_op_bn_train_backward(const void* d_dy_pad, const void* d_x_pad, const f
                               float* d_dgamma_dbeta, int B, int H, int W, int C, float eps, void* stream);
 int lseg_op_relu_backward(const void* d_dy, const void* d_x, void* d_dx, int64_t n, void* stream);
 
+/* Head-side backward bricks (lseg_net.py:185-203 under autograd):
+ *   upsample2x_planes_backward_rows  d_dout [B,K,2H,2W] fp32 (d of the output logits) -> d_rows [B*H*W, ldk] bf16/fp16, columns
+ *                                    0..K-1 (the rest pre-zeroed by the caller): transpose of output_conv's x2 bilinear, already in
+ *                                    the row layout the correlation backward (lseg_op_linear_backward with N = ldk) consumes
+ *   l2norm_scale_backward            d_dx [M,C] = (scale/||x||) (d_da - xh (xh . d_da)), xh = x/||x||; x fp32, da/dx bf16|fp16 */
+int lseg_op_upsample2x_planes_backward_rows(const float* d_dout, void* d_rows, int B, int K, int H, int W, int ldk, int out_dtype,
+                                            void* stream);
+int lseg_op_l2norm_scale_backward(const void* d_da, int da_dtype, const float* d_x, void* d_dx, int dx_dtype, int M, int C, float scale,
+                                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

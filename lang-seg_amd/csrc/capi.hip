@@ -353,4 +353,22 @@ int lseg_op_relu_backward(const void* d_dy, const void* d_x, void* d_dx, int64_t
     return launch_relu_backward(d_dy, d_x, d_dx, (size_t)n, (hipStream_t)stream);
 }
 
+int lseg_op_upsample2x_planes_backward_rows(const float* d_dout, void* d_rows, int B, int K, int H, int W, int ldk, int out_dtype,
+                                            void* stream) {
+    int r = require_device(); if (r) return r;
+    int dt;
+    if ((r = op_dt(out_dtype, &dt))) return r;
+    if (dt == DT_F32 || !d_dout || !d_rows || B < 1 || K < 1 || H < 2 || W < 2) return set_error(LSEG_ERR_INVALID, "upsample2x_planes_backward_rows: bad arguments");
+    return launch_upsample2x_planes_backward_rows(d_dout, d_rows, B, K, H, W, ldk, dt, (hipStream_t)stream);
+}
+
+int lseg_op_l2norm_scale_backward(const void* d_da, int da_dtype, const float* d_x, void* d_dx, int dx_dtype, int M, int C, float scale,
+                                  void* stream) {
+    int r = require_device(); if (r) return r;
+    int a, b;
+    if ((r = op_dt(da_dtype, &a)) || (r = op_dt(dx_dtype, &b))) return r;
+    if (a == DT_F32 || b == DT_F32 || !d_da || !d_x || !d_dx || M < 1) return set_error(LSEG_ERR_INVALID, "l2norm_scale_backward: 16-bit da/dx, fp32 x");
+    return launch_l2norm_scale_backward(d_da, a, d_x, d_dx, b, M, C, scale, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -714,6 +714,79 @@ __global__ void relu_backward_kernel(const uint16_t* __restrict__ dy, const uint
         dx[i] = (v != 0 && !(v & 0x8000)) ? dy[i] : (uint16_t)0;       // positive <=> sign bit clear and not zero (bf16 and fp16)
     }
 }
+// ---- head-side backward bricks (lseg_net.py:185-203 under autograd) ----------------------------------------------------
+// x2 bilinear (align_corners=True) backward of the logit planes, written straight as the GEMM operand of the correlation
+// backward: d_low_rows[(b*h*w + p), k] (16-bit, leading dimension ldk >= K; padding columns must be pre-zeroed) from
+// d_out [B,K,2h,2w] fp32 -- the transpose of upsample2x_planes_kernel (output_conv) fused with the planes->rows re-layout.
+__global__ void upsample2x_planes_bwd_rows_kernel(const float* __restrict__ dout, uint16_t* __restrict__ rows, int B, int K, int H, int W,
+                                                  int ldk, int dtype) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const size_t n = (size_t)B * K * H * W;
+    const float ry = (float)(H - 1) / (float)(Ho - 1), rx = (float)(W - 1) / (float)(Wo - 1);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        size_t p = i / W;
+        const int y = (int)(p % H); p /= H;
+        const int k = (int)(p % K);
+        const int b = (int)(p / K);
+        const float* plane = dout + ((size_t)b * K + k) * Ho * Wo;
+        float acc = 0.f;
+        const int ya = max(0, 2 * y - 2), yb = min(Ho - 1, 2 * y + 3), xa = max(0, 2 * x - 2), xb = min(Wo - 1, 2 * x + 3);
+        for (int yo = ya; yo <= yb; ++yo) {
+            const float sy = ry * (float)yo;
+            const int y0 = (int)sy, y1 = y0 + (y0 < H - 1);
+            const float ly = sy - (float)y0;
+            const float wy = (y0 == y ? 1.f - ly : 0.f) + (y1 == y ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int xo = xa; xo <= xb; ++xo) {
+                const float sx = rx * (float)xo;
+                const int x0 = (int)sx, x1 = x0 + (x0 < W - 1);
+                const float lx = sx - (float)x0;
+                const float wx = (x0 == x ? 1.f - lx : 0.f) + (x1 == x ? lx : 0.f);
+                if (wx != 0.f) acc += wy * wx * plane[(size_t)yo * Wo + xo];
+            }
+        }
+        store_from_f32(rows, ((size_t)b * H * W + (size_t)y * W + x) * ldk + k, dtype, acc);
+    }
+}
+// backward of a = scale * x / ||x||_2 (row-wise; the fp16 roundings of the forward are treated as identity):
+//   dx = (scale / ||x||) * (da - xh * (xh . da)),  xh = x / ||x||      x fp32 [M,C], da 16-bit, dx 16-bit
+template <int MAXV>
+__global__ __launch_bounds__(256) void l2norm_scale_bwd_kernel(const uint16_t* __restrict__ da, int da_dtype, const float* __restrict__ x,
+                                                               uint16_t* __restrict__ dx, int dx_dtype, int M, int C, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = C >> 2;
+    float4 xv[MAXV], gv[MAXV];
+    float s = 0.f, d = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int g = lane + 64 * i;
+        if (g < nv) {
+            xv[i] = reinterpret_cast<const float4*>(x + (size_t)row * C)[g];
+            const uint2 u = reinterpret_cast<const uint2*>(da + (size_t)row * C)[g];
+            gv[i].x = load_as_f32(&u, 0, da_dtype); gv[i].y = load_as_f32(&u, 1, da_dtype);
+            gv[i].z = load_as_f32(&u, 2, da_dtype); gv[i].w = load_as_f32(&u, 3, da_dtype);
+            s += xv[i].x * xv[i].x + xv[i].y * xv[i].y + xv[i].z * xv[i].z + xv[i].w * xv[i].w;
+            d += xv[i].x * gv[i].x + xv[i].y * gv[i].y + xv[i].z * gv[i].z + xv[i].w * gv[i].w;
+        }
+    }
+    const float n2 = wave_sum(s);
+    const float inv = rsqrtf(n2), proj = wave_sum(d) / n2;          // xh . da / ||x|| = (x . da) / ||x||^2 ... applied to x below
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int g = lane + 64 * i;
+        if (g < nv) {
+            const float r[4] = {scale * inv * (gv[i].x - xv[i].x * proj), scale * inv * (gv[i].y - xv[i].y * proj),
+                                scale * inv * (gv[i].z - xv[i].z * proj), scale * inv * (gv[i].w - xv[i].w * proj)};
+            uint2 pk;
+            pk.x = pack2_dt(r[0], r[1], dx_dtype);
+            pk.y = pack2_dt(r[2], r[3], dx_dtype);
+            reinterpret_cast<uint2*>(dx + (size_t)row * C)[g] = pk;
+        }
+    }
+}
 // out[c] += sum_r in[r, c] (bias gradient); out must be zeroed; fp32 atomics across row chunks
 __global__ void colsum16_kernel(const uint16_t* __restrict__ in, int dtype, float* __restrict__ out, int R, int C, int ld,
                                 int rows_per_block) {
@@ -1010,6 +1083,22 @@ int launch_bn_train_backward(const void* dy, const void* x, const float* stats, 
 }
 int launch_relu_backward(const void* dy, const void* x, void* dx, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(relu_backward_kernel, dim3(grid_for(n)), dim3(256), 0, st, (const uint16_t*)dy, (const uint16_t*)x, (uint16_t*)dx, n);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_upsample2x_planes_backward_rows(const float* dout, void* rows, int B, int K, int H, int W, int ldk, int dtype, hipStream_t st) {
+    if (ldk < K) return set_error(LSEG_ERR_INVALID, "upsample2x_planes backward: ldk=%d < K=%d", ldk, K);
+    hipLaunchKernelGGL(upsample2x_planes_bwd_rows_kernel, dim3(grid_for((size_t)B * K * H * W)), dim3(256), 0, st, dout, (uint16_t*)rows,
+                       B, K, H, W, ldk, dtype);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_l2norm_scale_backward(const void* da, int da_dtype, const float* x, void* dx, int dx_dtype, int M, int C, float scale, hipStream_t st) {
+    if (C % 4 != 0 || C > 64 * 4 * 4) return set_error(LSEG_ERR_UNSUPPORTED, "l2norm backward: C=%d", C);
+    const int blocks = (M + 3) / 4;
+#define L2B(V) hipLaunchKernelGGL(l2norm_scale_bwd_kernel<V>, dim3(blocks), dim3(256), 0, st, (const uint16_t*)da, da_dtype, x, (uint16_t*)dx, dx_dtype, M, C, scale)
+    if (C <= 256) L2B(1); else if (C <= 512) L2B(2); else L2B(4);
+#undef L2B
     CHECK_LAUNCH();
     return 0;
 }

@@ -43,6 +43,8 @@ int launch_bn_train_forward(const void* x, void* y, float* stats, const float* g
 int launch_bn_train_backward(const void* dy, const void* x, const float* stats, const float* gamma, void* dx, float* bstats,
                              int B, int H, int W, int C, float eps, int dtype, hipStream_t st);
 int launch_relu_backward(const void* dy, const void* x, void* dx, size_t n, hipStream_t st);
+int launch_upsample2x_planes_backward_rows(const float* dout, void* rows, int B, int K, int H, int W, int ldk, int dtype, hipStream_t st);
+int launch_l2norm_scale_backward(const void* da, int da_dtype, const float* x, void* dx, int dx_dtype, int M, int C, float scale, hipStream_t st);
 int launch_qkv_grad_pack(const float* dq, const float* dk, const float* dv, void* out, int B, int H, int ntok, int npad, int dtype,
                          hipStream_t st);
 int launch_gelu_backward(const void* dy, const void* pre, void* dx, size_t n, int dtype, hipStream_t st);

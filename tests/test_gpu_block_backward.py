@@ -188,3 +188,54 @@ def test_residual_conv_unit_backward_through_the_bricks(B, H, W, Cc):
     print({k: round(v, 4) for k, v in report.items()})
     # bf16 maps between the bricks: <= 2 % on the tensors, 4 % on the BN shift gradients (sums with cancellation)
     assert all(v < (4e-2 if k.startswith("db") else 2e-2) for k, v in report.items()), report
+
+
+@pytest.mark.parametrize("B,h,w,K,Fd", [(2, 12, 12, 7, 64), (1, 10, 16, 150, 128)])
+def test_head_backward_through_the_bricks(B, h, w, K, Fd):
+    """The path after the refinenets (lseg_net.py:185-203): head1 -> L2-normalise * logit_scale -> correlation with the text
+    features -> x2 bilinear -> CrossEntropyLoss(ignore_index), back-propagated through the bricks (seg_stats,
+    softmax_ce_backward, upsample2x_planes_backward_rows, linear_backward x2, l2norm_scale_backward) vs torch autograd."""
+    lib = _lib.load()
+    Cc, M, Kp, s = 512, B * h * w, ((K + 63) // 64) * 64, 14.285714
+    g = torch.Generator().manual_seed(5 + K)
+    rn = lambda *sh, scale=1.0: torch.randn(sh, generator=g) * scale
+    p1 = rn(M, Fd).to(BF).cuda()
+    wh = rn(Cc, Fd, scale=1 / math.sqrt(Fd)).to(BF).cuda()
+    bh = (0.1 * rn(Cc)).cuda()
+    t = rn(K, Cc)
+    t = (t / t.norm(dim=-1, keepdim=True)).to(BF).cuda()
+    target = torch.randint(0, K, (B, 2 * h, 2 * w), generator=g)
+    target[torch.rand((B, 2 * h, 2 * w), generator=g) < 0.2] = -1
+    target = target.cuda()
+    # reference under autograd (fp32)
+    pr, wr, br, tr = (v.float().clone().requires_grad_(True) for v in (p1, wh, bh, t))
+    f = pr @ wr.t() + br
+    a = s * f / f.norm(dim=-1, keepdim=True)
+    low = (a @ tr.t()).reshape(B, h, w, K).permute(0, 3, 1, 2)
+    up = F.interpolate(low, scale_factor=2, mode="bilinear", align_corners=True)
+    F.cross_entropy(up, target, ignore_index=-1).backward()
+    with torch.no_grad():
+        st = _st()
+        f32 = (p1.float() @ wh.float().t() + bh).contiguous()
+        a16 = (s * f32 / f32.norm(dim=-1, keepdim=True)).to(BF).contiguous()
+        upc = up.detach().contiguous()
+        counts = torch.empty(2 + 3 * K, dtype=torch.int64, device="cuda")
+        nll = torch.empty(2, dtype=torch.float64, device="cuda")
+        _lib.check(lib.lseg_op_seg_stats(P(upc), P(target), B, K, 2 * h, 2 * w, -1, P(counts), P(nll), st))
+        dz = torch.empty_like(upc)
+        _lib.check(lib.lseg_op_softmax_ce_backward(P(upc), P(target), P(dz), B, K, 2 * h, 2 * w, -1, P(nll), st))
+        d_rows = torch.zeros((M, Kp), dtype=BF, device="cuda")
+        _lib.check(lib.lseg_op_upsample2x_planes_backward_rows(P(dz), P(d_rows), B, K, h, w, Kp, _lib.LSEG_BF16, st))
+        tp = torch.zeros((Kp, Cc), dtype=BF, device="cuda"); tp[:K] = t
+        d_a, d_t, _ = _lin_bwd(lib, d_rows, a16, tp)                       # correlation: logits = a t^T
+        d_f = torch.empty((M, Cc), dtype=BF, device="cuda")
+        _lib.check(lib.lseg_op_l2norm_scale_backward(P(d_a), _lib.LSEG_BF16, P(f32), P(d_f), _lib.LSEG_BF16, M, Cc, s, st))
+        d_p1, d_wh, d_bh = _lin_bwd(lib, d_f, p1, wh)
+        torch.cuda.synchronize()
+
+    def rel(x, y):
+        return ((x.float() - y.float()).norm() / y.float().norm().clamp_min(1e-12)).item()
+    report = {"d_path1": rel(d_p1, pr.grad), "d_head1_w": rel(d_wh, wr.grad), "d_head1_b": rel(d_bh, br.grad),
+              "d_text": rel(d_t[:K], tr.grad)}
+    print({k: round(v, 4) for k, v in report.items()})
+    assert all(v < 3e-2 for v in report.values()), report
