@@ -227,6 +227,7 @@ int lseg_op_conv3x3_backward(const void* d_dy_pad, const void* d_x_pad, const vo
  *   softmax_ce_backward     d_dscores [B,K,H,W] fp32 = (softmax_k - 1[k = target]) / n_valid (0 at ignored pixels);
  *                           d_nll = the double[2] written by lseg_op_seg_stats (n_valid in d_nll[1]) */
 int lseg_op_gelu_backward(const void* d_dy, const void* d_pre, void* d_dx, int64_t n, int dtype, void* stream);
+int lseg_op_quickgelu_backward(const void* d_dy, const void* d_pre, void* d_dx, int64_t n, int dtype, void* stream);   /* CLIP: x*sigmoid(1.702x) */
 int lseg_op_upsample2x_nhwc_backward(const void* d_dout, void* d_din_pad, int B, int H, int W, int C, void* stream);
 int lseg_op_softmax_ce_backward(const float* d_scores, const int64_t* d_target, float* d_dscores, int B, int K, int H, int W,
                                 int ignore_index, const double* d_nll, void* stream);
@@ -238,7 +239,7 @@ int lseg_op_softmax_ce_backward(const float* d_scores, const int64_t* d_target, 
  * outputs fp32 d_dq, d_dk, d_dv [BH,Npad,64] (rows >= Ntok of dk/dv are zero; dq is zeroed here, then accumulated). */
 int lseg_op_attention_backward(const void* d_q, const void* d_k, const void* d_vt, const void* d_o, const void* d_do,
                                const float* d_lse2, float* d_dq, float* d_dk, float* d_dv, int B, int H, int Ntok, int Npad,
-                               int dtype, float scale, void* stream);
+                               int dtype, int causal, float scale, void* stream);
 
 /* d(qkv Linear output) [B*Ntok, 3*H*64] (bf16/fp16) from the attention backward's fp32 d_dq, d_dk, d_dv [BH,Npad,64]:
  * the inverse of the QKV GEMM epilogue's head-major scatter; feeds lseg_op_linear_backward of the qkv layer. */

@@ -1,4 +1,4 @@
-// attention_bwd.hip -- backward of softmax(Q K^T * scale) V, head_dim 64, gfx950.  First (correctness-first) version of
+// attention_bwd.hip -- backward of softmax(Q K^T * scale [+ causal mask]) V, head_dim 64, gfx950.  First (correctness-first) version of
 // the attention brick of the training step (the reference gets it from torch autograd through
 // [3P] timm Attention.forward, invoked at lseg_vit.py:196-197).
 //
@@ -24,7 +24,7 @@ struct AttnBwdArgs {
     const uint16_t *q, *k, *vt, *o, *d_o;
     const float* lse2;
     float *dq, *dk, *dv;
-    int B, H, ntok, npad;
+    int B, H, ntok, npad, causal;
     float scale, scale_log2e;
 };
 
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void lseg_attention_bwd_kernel(const AttnBwdAr
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int kc = wn * 32 + i * 16 + (lane >> 4) * 4 + r;
-                    const bool ok = qok && (k0 + kc < a.ntok);
+                    const bool ok = qok && (k0 + kc < a.ntok) && (!a.causal || k0 + kc <= q0 + qr);   // CLIP's causal -inf mask
                     const float p = ok ? __builtin_amdgcn_exp2f(s_acc[i][j][r] * a.scale_log2e - l2) : 0.f;
                     const float ds = p * (p_acc[i][j][r] - dd) * a.scale;
                     const uint16_t pb = from_f32<T>(p), dsb = from_f32<T>(ds);
@@ -183,13 +183,13 @@ __global__ __launch_bounds__(256) void lseg_attention_bwd_kernel(const AttnBwdAr
 }  // namespace
 
 int launch_attention_backward(const void* q, const void* k, const void* vt, const void* o, const void* d_o, const float* lse2,
-                              float* dq, float* dk, float* dv, int B, int H, int ntok, int npad, int dtype, float scale,
+                              float* dq, float* dk, float* dv, int B, int H, int ntok, int npad, int dtype, int causal, float scale,
                               hipStream_t stream) {
     if (npad % 64 != 0 || npad < ntok) return set_error(LSEG_ERR_INVALID, "attention backward: npad=%d must be a multiple of 64 and >= ntok=%d", npad, ntok);
     AttnBwdArgs a;
     a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.vt = (const uint16_t*)vt; a.o = (const uint16_t*)o; a.d_o = (const uint16_t*)d_o;
     a.lse2 = lse2; a.dq = dq; a.dk = dk; a.dv = dv;
-    a.B = B; a.H = H; a.ntok = ntok; a.npad = npad; a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
+    a.B = B; a.H = H; a.ntok = ntok; a.npad = npad; a.causal = causal; a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
     const size_t lds = 10 * sizeof(Tile) + 2 * 64 * sizeof(float);
     dim3 grid((ntok + 63) / 64, B * H);
     if (dtype == DT_BF16) {

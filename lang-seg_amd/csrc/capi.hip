@@ -289,6 +289,14 @@ int lseg_op_conv3x3_backward(const void* d_dy_pad, const void* d_x_pad, const vo
     return LSEG_OK;
 }
 
+int lseg_op_quickgelu_backward(const void* d_dy, const void* d_pre, void* d_dx, int64_t n, int dtype, void* stream) {
+    int r = require_device(); if (r) return r;
+    int dt;
+    if ((r = op_dt(dtype, &dt))) return r;
+    if (dt == DT_F32 || !d_dy || !d_pre || !d_dx || n < 1) return set_error(LSEG_ERR_INVALID, "quickgelu_backward: bf16/fp16 tensors, n >= 1");
+    return launch_gelu_backward(d_dy, d_pre, d_dx, (size_t)n, dt, (hipStream_t)stream, 1);
+}
+
 int lseg_op_gelu_backward(const void* d_dy, const void* d_pre, void* d_dx, int64_t n, int dtype, void* stream) {
     int r = require_device(); if (r) return r;
     int dt;
@@ -312,7 +320,7 @@ int lseg_op_softmax_ce_backward(const float* d_scores, const int64_t* d_target, 
 
 int lseg_op_attention_backward(const void* d_q, const void* d_k, const void* d_vt, const void* d_o, const void* d_do,
                                const float* d_lse2, float* d_dq, float* d_dk, float* d_dv, int B, int H, int Ntok, int Npad,
-                               int dtype, float scale, void* stream) {
+                               int dtype, int causal, float scale, void* stream) {
     int r = require_device(); if (r) return r;
     int dt;
     if ((r = op_dt(dtype, &dt))) return r;
@@ -321,7 +329,7 @@ int lseg_op_attention_backward(const void* d_q, const void* d_k, const void* d_v
     if (B < 1 || H < 1 || Ntok < 1) return set_error(LSEG_ERR_INVALID, "attention_backward: bad shape");
     if (hipMemsetAsync(d_dq, 0, (size_t)B * H * Npad * 64 * sizeof(float), (hipStream_t)stream) != hipSuccess)
         return set_error(LSEG_ERR_HIP, "attention_backward: memset failed");
-    return launch_attention_backward(d_q, d_k, d_vt, d_o, d_do, d_lse2, d_dq, d_dk, d_dv, B, H, Ntok, Npad, dt, scale, (hipStream_t)stream);
+    return launch_attention_backward(d_q, d_k, d_vt, d_o, d_do, d_lse2, d_dq, d_dk, d_dv, B, H, Ntok, Npad, dt, causal, scale, (hipStream_t)stream);
 }
 
 int lseg_op_qkv_grad_pack(const float* d_dq, const float* d_dk, const float* d_dv, void* d_dqkv, int B, int H, int Ntok, int Npad,

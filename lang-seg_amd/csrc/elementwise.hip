@@ -549,13 +549,19 @@ __global__ void conv_dgrad_pack_kernel(const uint16_t* __restrict__ wp, uint16_t
     }
 }
 // GELU (erf form, timm Mlp.act) backward: dx = dy * (Phi(z) + z * phi(z)), z = the pre-activation (fc1 output + bias).
+// quick != 0: CLIP's QuickGELU x * sigmoid(1.702 x): d/dx = sg * (1 + 1.702 x (1 - sg)), sg = sigmoid(1.702 x)
 __global__ void gelu_backward_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ pre, uint16_t* __restrict__ dx,
-                                     size_t n, int dtype) {
+                                     size_t n, int dtype, int quick) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float z = load_as_f32(pre, i, dtype), g = load_as_f32(dy, i, dtype);
-        const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752f));
-        const float pdf = 0.3989422804014327f * __expf(-0.5f * z * z);
-        store_from_f32(dx, i, dtype, g * (cdf + z * pdf));
+        float d;
+        if (quick) {
+            const float sg = 1.0f / (1.0f + __expf(-1.702f * z));
+            d = sg * (1.0f + 1.702f * z * (1.0f - sg));
+        } else {
+            d = 0.5f * (1.0f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z);
+        }
+        store_from_f32(dx, i, dtype, g * d);
     }
 }
 // x2 bilinear (align_corners=True) backward, NHWC 16-bit: d_in (padded [B,H+2,W+2,C], interior written) gathers the
@@ -1028,8 +1034,8 @@ int launch_conv_dgrad_pack(const void* wp, void* wd, int Co, int Ci, hipStream_t
     CHECK_LAUNCH();
     return 0;
 }
-int launch_gelu_backward(const void* dy, const void* pre, void* dx, size_t n, int dtype, hipStream_t st) {
-    hipLaunchKernelGGL(gelu_backward_kernel, dim3(grid_for(n)), dim3(256), 0, st, (const uint16_t*)dy, (const uint16_t*)pre, (uint16_t*)dx, n, dtype);
+int launch_gelu_backward(const void* dy, const void* pre, void* dx, size_t n, int dtype, hipStream_t st, int quick) {
+    hipLaunchKernelGGL(gelu_backward_kernel, dim3(grid_for(n)), dim3(256), 0, st, (const uint16_t*)dy, (const uint16_t*)pre, (uint16_t*)dx, n, dtype, quick);
     CHECK_LAUNCH();
     return 0;
 }

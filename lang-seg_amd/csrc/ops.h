@@ -36,7 +36,7 @@ int launch_layernorm_backward(const void* dy, int dy_dtype, const float* x, cons
                               float* dbeta, int M, int D, float eps, int accumulate, hipStream_t st);
 int launch_transpose16(const void* in, void* out, int R, int C, int ldi, int ldo, hipStream_t st, int shift = 0);
 int launch_attention_backward(const void* q, const void* k, const void* vt, const void* o, const void* d_o, const float* lse2,
-                              float* dq, float* dk, float* dv, int B, int H, int ntok, int npad, int dtype, float scale,
+                              float* dq, float* dk, float* dv, int B, int H, int ntok, int npad, int dtype, int causal, float scale,
                               hipStream_t stream);
 int launch_bn_train_forward(const void* x, void* y, float* stats, const float* gamma, const float* beta, int B, int H, int W, int C,
                             float eps, int dtype, hipStream_t st);
@@ -47,7 +47,7 @@ int launch_upsample2x_planes_backward_rows(const float* dout, void* rows, int B,
 int launch_l2norm_scale_backward(const void* da, int da_dtype, const float* x, void* dx, int dx_dtype, int M, int C, float scale, hipStream_t st);
 int launch_qkv_grad_pack(const float* dq, const float* dk, const float* dv, void* out, int B, int H, int ntok, int npad, int dtype,
                          hipStream_t st);
-int launch_gelu_backward(const void* dy, const void* pre, void* dx, size_t n, int dtype, hipStream_t st);
+int launch_gelu_backward(const void* dy, const void* pre, void* dx, size_t n, int dtype, hipStream_t st, int quick = 0);
 int launch_upsample2x_nhwc_backward(const void* dout, void* din, int B, int H, int W, int C, int dtype, hipStream_t st);
 int launch_softmax_ce_backward(const float* scores, const int64_t* target, float* dz, int B, int K, int HW, int ignore_index,
                                const double* nll, hipStream_t st);

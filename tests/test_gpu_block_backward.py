@@ -99,7 +99,7 @@ def test_vit_block_backward_through_the_bricks(B, N, H):
         d_o, dwp, dbp = _lin_bwd(lib, dx1.to(BF), o2.contiguous(), wb["wp"])
         dq, dk, dv = (torch.empty((B * H, Npad, 64), dtype=torch.float32, device="cuda") for _ in range(3))
         _lib.check(lib.lseg_op_attention_backward(P(qp), P(kp), P(vt), P(o), P(d_o.reshape(B, N, D).contiguous()), P(lse2),
-                                                  P(dq), P(dk), P(dv), B, H, N, Npad, _lib.LSEG_BF16, 0.125, _st()))
+                                                  P(dq), P(dk), P(dv), B, H, N, Npad, _lib.LSEG_BF16, 0, 0.125, _st()))
         d_qkv = torch.empty((M, 3 * D), dtype=BF, device="cuda")
         _lib.check(lib.lseg_op_qkv_grad_pack(P(dq), P(dk), P(dv), P(d_qkv), B, H, N, Npad, _lib.LSEG_BF16, _st()))
         d_ln1, dwqkv, dbqkv = _lin_bwd(lib, d_qkv, ln1, wb["wqkv"])

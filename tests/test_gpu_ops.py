@@ -302,13 +302,16 @@ def test_conv3x3_backward(lib, B, H, W, Cin, Cout):
     assert dxp[:, 0].abs().max().item() == 0 and dxp[:, :, -1].abs().max().item() == 0       # border stays zero
 
 
-def test_gelu_backward(lib):
-    dt = torch.bfloat16
+@pytest.mark.parametrize("quick", [False, True])
+def test_gelu_backward(lib, quick):
+    """erf GELU (timm Mlp) and CLIP's QuickGELU x*sigmoid(1.702x)."""
+    dt = torch.float16 if quick else torch.bfloat16
     pre, dy = rnd((4099,), dt, 60, 2.0), rnd((4099,), dt, 61)
     pr = pre.float().requires_grad_(True)
-    F.gelu(pr).backward(dy.float())
+    (pr * torch.sigmoid(1.702 * pr) if quick else F.gelu(pr)).backward(dy.float())
     dx = torch.empty_like(pre)
-    _lib.check(lib.lseg_op_gelu_backward(P(dy), P(pre), P(dx), 4099, DT[dt], stream()))
+    fn = lib.lseg_op_quickgelu_backward if quick else lib.lseg_op_gelu_backward
+    _lib.check(fn(P(dy), P(pre), P(dx), 4099, DT[dt], stream()))
     torch.cuda.synchronize()
     assert (dx.float() - pr.grad).abs().max().item() <= 2 ** -7 * max(1.0, pr.grad.abs().max().item())
 
@@ -349,9 +352,10 @@ def test_softmax_ce_backward(lib, B, K, H, W):
     assert dz[(target < 0).unsqueeze(1).expand_as(dz)].abs().max().item() == 0
 
 
-@pytest.mark.parametrize("dtype,B,H,N", [(torch.bfloat16, 1, 2, 130), (torch.float16, 2, 3, 64), (torch.bfloat16, 1, 2, 901),
-                                         (torch.bfloat16, 1, 1, 37)])
-def test_attention_backward(lib, dtype, B, H, N):
+@pytest.mark.parametrize("dtype,B,H,N,causal", [(torch.bfloat16, 1, 2, 130, False), (torch.float16, 2, 3, 64, False),
+                                                (torch.bfloat16, 1, 2, 901, False), (torch.bfloat16, 1, 1, 37, False),
+                                                (torch.float16, 3, 8, 77, True), (torch.float16, 2, 2, 5, True)])
+def test_attention_backward(lib, dtype, B, H, N, causal):
     """Backward of the (unmasked) attention brick: flash-style recomputation from the forward's layouts and per-row
     log2-sum-exp, against torch autograd in fp32 on the same 16-bit-rounded q, k, v."""
     Npad = ((N + 127) // 128) * 128
@@ -361,16 +365,18 @@ def test_attention_backward(lib, dtype, B, H, N):
     kp = torch.zeros((B * H, Npad, 64), dtype=dtype).cuda(); kp[:, :N] = k.reshape(B * H, N, 64)
     vt = torch.zeros((B * H, 64, Npad), dtype=dtype).cuda(); vt[:, :, :N] = v.reshape(B * H, N, 64).transpose(1, 2)
     out = torch.zeros((B, N, H * 64), dtype=dtype).cuda()
-    _lib.check(lib.lseg_op_attention(P(qp), P(kp), P(vt), P(out), B, H, N, Npad, DT[dtype], 0, 0.125, stream()))
+    _lib.check(lib.lseg_op_attention(P(qp), P(kp), P(vt), P(out), B, H, N, Npad, DT[dtype], int(causal), 0.125, stream()))
     qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
     s = (qr @ kr.transpose(-1, -2)) * 0.125
+    if causal:                                           # CLIP text tower: -inf strictly above the diagonal
+        s = s + torch.full((N, N), float("-inf"), device=s.device).triu_(1)
     ref = (s.softmax(-1) @ vr).transpose(1, 2).reshape(B, N, H * 64)
     ref.backward(d_o.float())
     lse2 = torch.zeros((B * H, Npad), dtype=torch.float32).cuda()
     lse2[:, :N] = (torch.logsumexp(s.detach(), dim=-1) * 1.4426950408889634).reshape(B * H, N)
     dq, dk, dv = (torch.full((B * H, Npad, 64), float("nan"), dtype=torch.float32).cuda() for _ in range(3))
     _lib.check(lib.lseg_op_attention_backward(P(qp), P(kp), P(vt), P(out), P(d_o), P(lse2), P(dq), P(dk), P(dv),
-                                              B, H, N, Npad, DT[dtype], 0.125, stream()))
+                                              B, H, N, Npad, DT[dtype], int(causal), 0.125, stream()))
     torch.cuda.synchronize()
     tol = 3e-2 if dtype == torch.bfloat16 else 6e-3
     for got, want, name in ((dq, qr.grad, "dq"), (dk, kr.grad, "dk"), (dv, vr.grad, "dv")):
