@@ -54,3 +54,54 @@ def cross_entropy(output: torch.Tensor, target: torch.Tensor, ignore_index: int 
     """Forward value of nn.CrossEntropyLoss(ignore_index=ignore_index)(output, target) (mean over valid pixels)."""
     r = seg_stats(output, target, ignore_index)
     return r["nll_sum"] / r["nll_count"] if r["nll_count"] else float("nan")
+
+
+class SegmentationMetric:
+    """Device-side stand-in for `encoding.utils.SegmentationMetric(nclass)` as test_lseg.py uses it (:319, 385-388):
+    `update(labels, preds)`, `get() -> (pixAcc, mIoU)`, `get_all() -> (pixAcc, mIoU, total_inter, total_union)`, `reset()`.
+    `preds` are score tensors [B,K,H,W] (or a list of them, like the evaluator's per-image outputs), `labels` the int64
+    masks; the per-image statistics come from ONE pass over the scores on the GPU (lseg_op_seg_stats) instead of an
+    arg-max + numpy histograms per image on the host.  `all_reduce()` sums the counters over data-parallel ranks."""
+
+    def __init__(self, nclass: int):
+        self.nclass = nclass
+        self.reset()
+
+    def reset(self):
+        self.total_inter = torch.zeros(self.nclass, dtype=torch.int64)
+        self.total_union = torch.zeros(self.nclass, dtype=torch.int64)
+        self.total_correct = 0
+        self.total_label = 0
+
+    def _accumulate(self, correct: int, labeled: int, inter: torch.Tensor, union: torch.Tensor):
+        self.total_correct += int(correct)
+        self.total_label += int(labeled)
+        self.total_inter += inter.to(torch.int64).cpu()
+        self.total_union += union.to(torch.int64).cpu()
+
+    def update(self, labels, preds):
+        if torch.is_tensor(preds):
+            labels, preds = [labels], [preds]
+        for label, pred in zip(labels, preds):
+            if pred.dim() == 3:
+                pred, label = pred.unsqueeze(0), label.unsqueeze(0)
+            r = seg_stats(pred, label)
+            self._accumulate(r["correct"], r["labeled"], r["area_inter"], r["area_union"])
+
+    def all_reduce(self):
+        from . import dist as D
+        t = torch.cat([torch.tensor([self.total_correct, self.total_label], dtype=torch.int64), self.total_inter, self.total_union])
+        t = D.sum_over_ranks(t.cuda() if torch.cuda.is_available() and torch.distributed.is_initialized()
+                             and torch.distributed.get_backend() == "nccl" else t).cpu()
+        self.total_correct, self.total_label = int(t[0]), int(t[1])
+        self.total_inter, self.total_union = t[2:2 + self.nclass].clone(), t[2 + self.nclass:].clone()
+
+    def get_all(self):
+        eps = 2.220446049250313e-16                      # np.spacing(1), as in [3P] encoding/utils/metrics.py
+        pix_acc = 1.0 * self.total_correct / (eps + self.total_label)
+        iou = 1.0 * self.total_inter.double() / (eps + self.total_union.double())
+        return pix_acc, float(iou.mean()), self.total_inter.numpy(), self.total_union.numpy()
+
+    def get(self):
+        pix_acc, miou, _, _ = self.get_all()
+        return pix_acc, miou

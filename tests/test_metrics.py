@@ -52,3 +52,42 @@ def test_hip_seg_stats_matches_oracle(shape):
     assert np.array_equal(a, inter.numpy()) and np.array_equal(b, union.numpy())
     with pytest.raises(RuntimeError):
         metrics.seg_stats(scores, target)                                  # CPU tensors: no fallback
+
+
+def test_segmentation_metric_accumulation_and_formulas():
+    """SegmentationMetric.get(): pixAcc = correct / (eps + labeled), IoU = inter / (eps + union), mIoU = mean over classes
+    ([3P] encoding/utils/metrics.py SegmentationMetric.get, used at test_lseg.py:386-388) on oracle counts of two images."""
+    from lseg_hip.metrics import SegmentationMetric
+    K = 7
+    m = SegmentationMetric(K)
+    tot_c = tot_l = 0
+    ti, tu = torch.zeros(K, dtype=torch.int64), torch.zeros(K, dtype=torch.int64)
+    for seed in (1, 2):
+        scores, target = _case(1, K, 20, 24, seed=seed)
+        c, l = batch_pix_accuracy(scores, target)
+        i, u = batch_intersection_union(scores, target, K)
+        m._accumulate(c, l, i, u)
+        tot_c += c; tot_l += l; ti += i; tu += u
+    pix, miou = m.get()
+    assert abs(pix - tot_c / tot_l) < 1e-12
+    assert abs(miou - float((ti.double() / tu.double().clamp_min(1e-300)).mean())) < 1e-9
+    _, _, inter, union = m.get_all()
+    assert np.array_equal(inter, ti.numpy()) and np.array_equal(union, tu.numpy())
+    m.reset()
+    assert m.total_label == 0 and int(m.total_union.sum()) == 0
+
+
+@pytest.mark.gpu
+def test_segmentation_metric_update_on_device():
+    from lseg_hip.metrics import SegmentationMetric
+    K = 5
+    m = SegmentationMetric(K)
+    sc, tg = _case(2, K, 16, 16, seed=9)
+    m.update(tg.cuda(), sc.cuda())                               # batched tensors
+    m.update([tg[0].cuda()], [sc[0].cuda()])                     # list of per-image [K,H,W] scores
+    c, l = batch_pix_accuracy(sc, tg)
+    c0, l0 = batch_pix_accuracy(sc[:1], tg[:1])
+    assert (m.total_correct, m.total_label) == (c + c0, l + l0)
+    i, u = batch_intersection_union(sc, tg, K)
+    i0, u0 = batch_intersection_union(sc[:1], tg[:1], K)
+    assert torch.equal(m.total_inter, i + i0) and torch.equal(m.total_union, u + u0)
