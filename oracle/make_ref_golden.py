@@ -40,6 +40,12 @@ REF_CASES = {
     "ref_vitl16_96x96_k5_arch1": ("clip_vitl16_384", 96, 96, 1, 5, 14, 1, 2),
     "ref_vitl16_96x96_k5_arch2": ("clip_vitl16_384", 96, 96, 1, 5, 15, 2, 2),
 }
+# BASELINE.json configs[1] and configs[4] run through the reference's own LSegNet.forward at full size (CPU, ~10 s and
+# ~2 min): `python oracle/make_ref_golden.py --full`.  Stored sub-sampled (the full logits are 138 MB / 922 MB).
+REF_FULL_CASES = {
+    "ref_full_vitl16_480x480_k150": ("clip_vitl16_384", 480, 480, 1, 150, 21, 0, 0),
+    "ref_full_vitl16_480x480_k1000": ("clip_vitl16_384", 480, 480, 1, 1000, 22, 0, 0),
+}
 # zero-shot: name -> (backbone, H, W, class_info, seed)
 REF_ZS_CASES = {
     "ref_vitl16_96x96_zs": ("clip_vitl16_384", 96, 96, (4, 0, 9), 16),
@@ -56,6 +62,15 @@ def reference_models():
     return importlib.import_module("refmodels.lseg_net"), importlib.import_module("refmodels.lseg_net_zs")
 
 
+def case_labels(K):
+    """K <= 150: the first K ADE20K labels; above: the FSS-1000 class names (config 5's open-vocabulary prompts)."""
+    if K <= 150:
+        return read_labels(LABELS)[:K]
+    names = read_labels(FSS, skip_header=False)
+    assert len(names) >= K, (len(names), K)
+    return names[:K]
+
+
 def load_synthetic(net, sd):
     res = net.load_state_dict(sd, strict=False)
     missing = [k for k in res.missing_keys if not k.startswith("clip_pretrained.visual.")]
@@ -69,13 +84,14 @@ def run_ref_case(spec):
     lseg_net, _ = reference_models()
     cfg = get_config(bb, arch_option=arch, block_depth=depth, activation="lrelu")
     sd = synthetic_state_dict(cfg, seed=seed)
-    labels = read_labels(LABELS)[:K]
+    labels = case_labels(K)
     net = lseg_net.LSegNet(labels=labels, backbone=bb, features=cfg.features, crop_size=H, arch_option=arch,
                            block_depth=depth, activation="lrelu")
     load_synthetic(net, sd)
     x = synthetic_images(B, H, W, seed=seed)
     taps = {}
     net.scratch.head1.register_forward_hook(lambda m, i, o: taps.__setitem__("image_features", o.detach().clone()))
+    net.scratch.output_conv.register_forward_hook(lambda m, i, o: taps.__setitem__("lowres", i[0].detach().clone()))
     net.scratch.refinenet1.register_forward_hook(lambda m, i, o: taps.__setitem__("path_1", o.detach().clone()))
     enc = net.clip_pretrained.encode_text
     net.clip_pretrained.encode_text = lambda t: taps.setdefault("text_features", enc(t).detach().clone())
@@ -101,9 +117,35 @@ def run_ref_zs_case(spec):
     return cfg, sd, x, tok, out
 
 
+def save_full_case(name, spec, gd):
+    """Full-size case: everything the parity tests need about the reference's decision surface, sub-sampled."""
+    cfg, sd, x, text, out, taps, acts = run_ref_case(spec)
+    low = taps["lowres"]                                # [1,K,240,240] fp32 holding fp16 values (lseg_net.py:194-196)
+    top2, top2_idx = low.topk(2, dim=1)
+    sub = 16 if spec[4] <= 150 else 32
+    torch.save({"spec": spec, "tokens": text.clone(),
+                "top2_idx": top2_idx.to(torch.int16).clone(), "top2_val": top2.to(torch.float16).clone(),
+                "text_features": taps["text_features"].to(torch.float16),
+                "argmax_lowres": low.argmax(1).to(torch.int16).clone(),
+                "margin_lowres": (top2[:, 0] - top2[:, 1]).to(torch.float16).clone(),
+                "lowres_sub8": low[:, :, ::8, ::8].to(torch.float16).clone(),
+                "lowres_absmax": float(low.abs().max()),
+                "logits_sub": out[:, :, ::sub, ::sub].clone(), "logits_sub_step": sub,
+                "path_1_sub8": taps["path_1"][:, :, ::8, ::8].to(torch.float16).clone(),
+                "acts_sub": [a[:, ::8, :].to(torch.float16).clone() for a in acts]},
+               os.path.join(gd, name + ".pt"))
+    print(name, tuple(out.shape), float(out.abs().mean()), "median margin", float((top2[:, 0] - top2[:, 1]).median()))
+
+
 def main():
     gd = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gd, exist_ok=True)
+    if "--full" in sys.argv[1:]:
+        for name, spec in REF_FULL_CASES.items():
+            if "--only" in sys.argv[1:] and name not in sys.argv[1:]:
+                continue
+            save_full_case(name, spec, gd)
+        return
     for name, spec in REF_CASES.items():
         cfg, sd, x, text, out, taps, acts = run_ref_case(spec)
         torch.save({"spec": spec, "tokens": text.clone(), "logits": out.clone(),
