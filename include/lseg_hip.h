@@ -268,6 +268,44 @@ int lseg_op_upsample2x_planes_backward_rows(const float* d_dout, void* d_rows, i
 int lseg_op_l2norm_scale_backward(const void* d_da, int da_dtype, const float* d_x, void* d_dx, int dx_dtype, int M, int C, float scale,
                                   void* stream);
 
+/* ---- training step ------------------------------------------------------------------------------------------------------------
+ * replaces: LSegmentationModule.training_step (modules/lsegmentation_module.py:66-81) -- `out = self(img)` in train() mode,
+ * `loss = criterion(out, target)` (SegmentationLosses = CrossEntropyLoss(ignore_index), [3P] encoding/nn/loss.py), autograd's
+ * backward -- plus what the Trainer does around it: DistributedDataParallel's bucketed gradient all-reduce and SyncBatchNorm
+ * (utils.py:20-22,34) through two callbacks, and SGD with the two learning-rate groups of configure_optimizers (:119-127,165-171).
+ *
+ *   lseg_set_train(h, 1)   net.train(): lseg_forward keeps the activations the backward needs, the refinenets' BatchNorm uses batch
+ *                          statistics and updates running_mean / running_var IN the caller's bound tensors (momentum 0.1).  bf16 only.
+ *   lseg_bind_grad         where the gradient of parameter `key` is written: fp32, same shape/layout as the bound parameter (the
+ *                          caller's .grad tensor, typically a view into a flat bucket).  Unbound parameters get engine-owned buffers
+ *                          (lseg_grad_ptr).  Trainable = pretrained.* and scratch.* tensors the forward touches; the CLIP text tower
+ *                          is frozen (it is in no optimizer group of the reference) and its features are constants of the step.
+ *   lseg_backward          after a train-mode lseg_forward: either dev_dlogits fp32 [B,K,H,W] (autograd hands it over), or
+ *                          dev_target int64 [B,H,W] (then the loss is the mean CE over pixels != ignore_index and dev_loss, if not
+ *                          NULL, receives double[2] = {sum of -log p[target], number of valid pixels}).  accumulate != 0 adds to the
+ *                          gradient buffers (accumulate_grad_batches), 0 overwrites them.
+ *   lseg_grad_bucket       gradients complete in buckets: 0 = DPT head + reassemble, 1+j = ViT block depth-1-j (+ the readout hooked
+ *                          on it), the last one also patch_embed / cls_token / pos_embed.  The bucket callback fires on the host right
+ *                          after the last kernel of a bucket has been ENQUEUED on `stream` (record an event there and launch the
+ *                          all-reduce on a side stream: it overlaps the remaining backward GEMMs).
+ *   lseg_set_bn_sync       SyncBatchNorm: `fn(user, dev_ptr, n, stream)` must sum dev_ptr[0..n) over the ranks in place, ordered on
+ *                          `stream`; called for the 2C batch sums of every BatchNorm (forward) and the 2C gradient sums (backward).
+ *                          world_size = number of ranks (divides the sums).  NULL / 1 = per-GPU statistics.
+ *   lseg_sgd_step          w -= lr * (mu * m + g + wd * w) on the bound fp32 parameters with the engine's momentum buffers, then
+ *                          re-packs the MFMA operand copies. */
+typedef void (*lseg_reduce_cb)(void* user, void* dev_ptr, int64_t n_floats, void* stream);
+typedef void (*lseg_bucket_cb)(void* user, int bucket, void* stream);
+int lseg_set_train(lseg_handle h, int enabled);
+int lseg_bind_grad(lseg_handle h, const char* key, float* dev_grad);
+int lseg_grad_ptr(lseg_handle h, const char* key, float** dev_out, size_t* n_elems);
+int lseg_grad_bucket(lseg_handle h, const char* key);          /* bucket index, or -1 if `key` is not a trainable parameter */
+int lseg_num_grad_buckets(lseg_handle h);
+int lseg_backward(lseg_handle h, const float* dev_dlogits, const int64_t* dev_target, int ignore_index, int accumulate,
+                  double* dev_loss, void* stream);
+int lseg_set_bn_sync(lseg_handle h, lseg_reduce_cb fn, void* user, int world_size);
+int lseg_set_bucket_callback(lseg_handle h, lseg_bucket_cb fn, void* user);
+int lseg_sgd_step(lseg_handle h, float lr_pretrained, float lr_scratch, float momentum, float weight_decay, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,7 @@
 //     accumulator layout of the first (key = 16*s + 4*(lane>>5) + (j&3) + 8*(j>>2)) is turned
 //     into the standard operand order (8 contiguous keys per lane) by one v_permlane32_swap per
 //     packed word -- no LDS round trip of P -- and V^T is read with conflict-free ds_read_b128.
-#include "common.h"
+#include "ops.h"
 #include "../../include/lseg_hip.h"
 
 namespace lseg {
@@ -27,6 +27,7 @@ namespace lseg {
 struct AttnArgs {
     const uint16_t* q; const uint16_t* k; const uint16_t* vt;
     uint16_t* out;
+    float* lse2;           // optional [BH, npad] fp32: log2 of each query row's sum_k exp2(s_k * scale * log2e) (saved for the backward)
     int B, H, ntok, npad, causal;
     float scale_log2e;     // softmax scale * log2(e)
 };
@@ -193,6 +194,7 @@ __global__ __launch_bounds__(256, 3) void lseg_attention_kernel(const AttnArgs a
     // ---- normalise and store: lane holds O[q][d = dblk*32 + 8g + 4hi + 0..3] -------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
+    if (a.lse2 && hi == 0 && qrow < a.ntok) a.lse2[(size_t)bh * a.npad + qrow] = m_run + __builtin_amdgcn_logf(l_tot);   // v_log_f32 = log2
     if (qrow < a.ntok) {
         const int b = bh / a.H, h = bh - b * a.H;
         uint16_t* orow = a.out + ((size_t)b * a.ntok + qrow) * (a.H * 64) + h * 64;
@@ -212,9 +214,15 @@ __global__ __launch_bounds__(256, 3) void lseg_attention_kernel(const AttnArgs a
 
 int launch_attention(const void* q, const void* k, const void* vt, void* out, int B, int H, int ntok,
                      int npad, int dtype, int causal, float scale, hipStream_t stream) {
+    return launch_attention_lse(q, k, vt, out, nullptr, B, H, ntok, npad, dtype, causal, scale, stream);
+}
+
+int launch_attention_lse(const void* q, const void* k, const void* vt, void* out, float* lse2, int B, int H, int ntok,
+                         int npad, int dtype, int causal, float scale, hipStream_t stream) {
     if (npad % 128 != 0 || npad < ntok) return set_error(LSEG_ERR_INVALID, "attention: npad=%d must be a multiple of 128 and >= ntok=%d", npad, ntok);
     AttnArgs a;
     a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.vt = (const uint16_t*)vt; a.out = (uint16_t*)out;
+    a.lse2 = lse2;
     a.B = B; a.H = H; a.ntok = ntok; a.npad = npad; a.causal = causal;
     a.scale_log2e = scale * 1.4426950408889634f;
     dim3 grid((ntok + 127) / 128, B * H);

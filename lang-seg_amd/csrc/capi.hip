@@ -102,6 +102,33 @@ int lseg_get_profile(lseg_handle h, const char* family, double* total_ms, int64_
     return h->e->get_profile(family, total_ms, launches, flops);
 }
 
+// ---- training step -----------------------------------------------------------------------------------------
+int lseg_set_train(lseg_handle h, int enabled) { GUARD(h); return h->e->set_train(enabled != 0); }
+int lseg_bind_grad(lseg_handle h, const char* key, float* dev_grad) { GUARD(h); return h->e->bind_grad(key, dev_grad); }
+int lseg_grad_ptr(lseg_handle h, const char* key, float** dev_out, size_t* n) { GUARD(h); return h->e->grad_ptr(key, dev_out, n); }
+int lseg_grad_bucket(lseg_handle h, const char* key) { if (!h || !h->e || !key) return -1; return h->e->bucket_of(key); }
+int lseg_num_grad_buckets(lseg_handle h) { if (!h || !h->e) return 0; return h->e->n_buckets(); }
+int lseg_backward(lseg_handle h, const float* dev_dlogits, const int64_t* dev_target, int ignore_index, int accumulate,
+                  double* dev_loss, void* stream) {
+    GUARD(h);
+    return h->e->backward(dev_dlogits, dev_target, ignore_index, accumulate, dev_loss, (hipStream_t)stream);
+}
+int lseg_set_bn_sync(lseg_handle h, lseg_reduce_cb fn, void* user, int world_size) {
+    GUARD(h);
+    if (world_size < 1) return set_error(LSEG_ERR_INVALID, "world_size %d", world_size);
+    h->e->bn_sync_fn = fn; h->e->bn_sync_user = user; h->e->bn_world = fn ? world_size : 1;
+    return LSEG_OK;
+}
+int lseg_set_bucket_callback(lseg_handle h, lseg_bucket_cb fn, void* user) {
+    GUARD(h);
+    h->e->bucket_fn = fn; h->e->bucket_user = user;
+    return LSEG_OK;
+}
+int lseg_sgd_step(lseg_handle h, float lr_pretrained, float lr_scratch, float momentum, float weight_decay, void* stream) {
+    GUARD(h);
+    return h->e->sgd_step(lr_pretrained, lr_scratch, momentum, weight_decay, (hipStream_t)stream);
+}
+
 // ---- single operators -----------------------------------------------------------------------------------
 static int op_dt(int lseg_dt, int* out) {
     if (lseg_dt == LSEG_F32) { *out = DT_F32; return 0; }

@@ -526,12 +526,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
 // `shift`: out[c, r] = in[r + shift, c] (zero outside [0, R)) -- the 9 taps of a 3x3 conv's wgrad are row shifts of the
 // padded NHWC activation.
 __global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
-                                                         int R, int C, int ldi, int ldo, int shift) {
+                                                         int R, int C, int ldi, int ldo, int shift, int relu) {
     __shared__ uint16_t t[64][66];
     const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
         const int rr = i >> 6, cc = i & 63, r = r0 + rr + shift, c = c0 + cc;
-        t[rr][cc] = (r >= 0 && r < R && c < C) ? in[(size_t)r * ldi + c] : (uint16_t)0;
+        uint16_t v = (r >= 0 && r < R && c < C) ? in[(size_t)r * ldi + c] : (uint16_t)0;
+        if (relu && (v & 0x8000)) v = 0;          // relu != 0: the operand is ReLU(in) (the RCU convs read their input through a ReLU)
+        t[rr][cc] = v;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
@@ -660,11 +662,12 @@ __global__ void bn_stats_kernel(const uint16_t* __restrict__ x, int dtype, float
     atomicAdd(&stats[C + c], q);
 }
 // y = gamma * (x - mean) * rstd + beta on the interior pixels (the border stays zero); mean/var from bn_stats (biased var)
+// res1 / res2 (same geometry, may be NULL): y += res1 + res2 -- the RCU skip connection and the fusion add (lseg_blocks.py:288,347).
+// inv_n = 1 / (pixels the sums were taken over): B*H*W, times the world size once the sums are all-reduced (SyncBatchNorm).
 __global__ void bn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, const float* __restrict__ stats,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, int B, int H, int W, int C,
-                                float eps, int dtype) {
+                                float eps, int dtype, float inv_n, const uint16_t* __restrict__ res1, const uint16_t* __restrict__ res2) {
     const size_t n = (size_t)B * H * W * C;
-    const float inv_n = 1.0f / (float)((size_t)B * H * W);
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         size_t p = i / C;
@@ -674,7 +677,10 @@ __global__ void bn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __rest
         const size_t off = (((size_t)b * (H + 2) + yy + 1) * (W + 2) + xx + 1) * C + c;
         const float mean = stats[c] * inv_n;
         const float var = fmaxf(stats[C + c] * inv_n - mean * mean, 0.f);
-        store_from_f32(y, off, dtype, gamma[c] * (load_as_f32(x, off, dtype) - mean) * rsqrtf(var + eps) + beta[c]);
+        float v = gamma[c] * (load_as_f32(x, off, dtype) - mean) * rsqrtf(var + eps) + beta[c];
+        if (res1) v += load_as_f32(res1, off, dtype);
+        if (res2) v += load_as_f32(res2, off, dtype);
+        store_from_f32(y, off, dtype, v);
     }
 }
 // backward sums: bstats[0..C) = sum dy, bstats[C..2C) = sum dy * xhat
@@ -697,9 +703,8 @@ __global__ void bn_bwd_stats_kernel(const uint16_t* __restrict__ dy, const uint1
 // dx = gamma * rstd * (dy - mean(dy) - xhat * mean(dy * xhat)) on the interior
 __global__ void bn_bwd_apply_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x, uint16_t* __restrict__ dx,
                                     const float* __restrict__ stats, const float* __restrict__ bstats, const float* __restrict__ gamma,
-                                    int B, int H, int W, int C, float eps, int dtype) {
+                                    int B, int H, int W, int C, float eps, int dtype, float inv_n) {
     const size_t n = (size_t)B * H * W * C;
-    const float inv_n = 1.0f / (float)((size_t)B * H * W);
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         size_t p = i / C;
@@ -718,6 +723,15 @@ __global__ void relu_backward_kernel(const uint16_t* __restrict__ dy, const uint
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const uint16_t v = x[i];
         dx[i] = (v != 0 && !(v & 0x8000)) ? dy[i] : (uint16_t)0;       // positive <=> sign bit clear and not zero (bf16 and fp16)
+    }
+}
+// dx = (x > 0 ? dy : 0) + add : ReLU backward merged with the skip connection's gradient (RCU: out = f(relu(x)) + x)
+__global__ void relu_backward_add_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x, const uint16_t* __restrict__ add,
+                                         uint16_t* __restrict__ dx, size_t n, int dtype) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint16_t v = x[i];
+        const float g = (v != 0 && !(v & 0x8000)) ? load_as_f32(dy, i, dtype) : 0.f;
+        store_from_f32(dx, i, dtype, g + load_as_f32(add, i, dtype));
     }
 }
 // ---- head-side backward bricks (lseg_net.py:185-203 under autograd) ----------------------------------------------------
@@ -876,6 +890,176 @@ __global__ __launch_bounds__(256) void seg_stats_kernel(const float* __restrict_
     }
 }
 
+// ---- glue of the engine-level training step (csrc/train.hip) ------------------------------------------
+// GELU (erf form) forward on a 16-bit tensor: the train-mode forward keeps the pre-activation (fc1 / readout Linear output)
+// for the backward, so the activation is its own pass there.  8 elements per lane.
+__global__ void gelu_forward_kernel(const uint16_t* __restrict__ pre, uint16_t* __restrict__ out, size_t n8, int dtype) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 u = reinterpret_cast<const uint4*>(pre)[i];
+        const uint16_t* e = reinterpret_cast<const uint16_t*>(&u);
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const float z = load_as_f32(e, k, dtype); v[k] = 0.5f * z * (1.0f + erff(z * 0.70710678118654752f)); }
+        reinterpret_cast<uint4*>(out)[i] = make_uint4(pack2_dt(v[0], v[1], dtype), pack2_dt(v[2], v[3], dtype),
+                                                      pack2_dt(v[4], v[5], dtype), pack2_dt(v[6], v[7], dtype));
+    }
+}
+// padded NHWC [B,H+2,W+2,C] -> rows [B*H*W, C] (16-bit, 16 bytes per lane): the GEMM-operand view of a gradient map
+__global__ void unpad_rows_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int B, int H, int W, int C) {
+    const int c8n = C / 8;
+    const size_t total = (size_t)B * H * W * c8n;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(idx % c8n);
+        size_t p = idx / c8n;
+        const int x = (int)(p % W); p /= W;
+        const int y = (int)(p % H);
+        const int b = (int)(p / H);
+        reinterpret_cast<uint4*>(out)[idx] =
+            *reinterpret_cast<const uint4*>(in + (((size_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * C + (size_t)c8 * 8);
+    }
+}
+// stride-2 conv backward helper: dYd (padded [B,H+2,W+2,C], pre-zeroed) gets dY (padded [B,Ho+2,Wo+2,C]) at the even
+// positions: dYd[2oy, 2ox] = dY[oy, ox].  dgrad / wgrad of the stride-2 conv are then the stride-1 ones on dYd.
+__global__ void dilate2_kernel(const uint16_t* __restrict__ dy, uint16_t* __restrict__ dyd, int B, int Ho, int Wo, int H, int W, int C) {
+    const int c8n = C / 8;
+    const size_t total = (size_t)B * Ho * Wo * c8n;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(idx % c8n);
+        size_t p = idx / c8n;
+        const int x = (int)(p % Wo); p /= Wo;
+        const int y = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        *reinterpret_cast<uint4*>(dyd + (((size_t)b * (H + 2) + 2 * y + 1) * (W + 2) + 2 * x + 1) * C + (size_t)c8 * 8) =
+            *reinterpret_cast<const uint4*>(dy + (((size_t)b * (Ho + 2) + y + 1) * (Wo + 2) + x + 1) * C + (size_t)c8 * 8);
+    }
+}
+// inverse of the ConvTranspose pixel-shuffle scatter (MAP_PIXSHUF): dL padded [B, gh*s+2, gw*s+2, C] -> dG rows
+// [B*gh*gw, s*s*C], dG[(b,y,x), (i*s+j)*C + co] = dL[b, y*s+i+1, x*s+j+1, co]
+__global__ void unpixshuf_kernel(const uint16_t* __restrict__ dl, uint16_t* __restrict__ dg, int B, int gh, int gw, int s, int C) {
+    const int c8n = C / 8;
+    const size_t total = (size_t)B * gh * gw * s * s * c8n;
+    const int Wd = gw * s + 2, Hd = gh * s + 2;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(idx % c8n);
+        size_t p = idx / c8n;
+        const int ij = (int)(p % (s * s)); p /= (s * s);
+        const int x = (int)(p % gw); p /= gw;
+        const int y = (int)(p % gh);
+        const int b = (int)(p / gh);
+        const int i = ij / s, j = ij - i * s;
+        reinterpret_cast<uint4*>(dg)[idx] =
+            *reinterpret_cast<const uint4*>(dl + (((size_t)b * Hd + y * s + i + 1) * Wd + x * s + j + 1) * C + (size_t)c8 * 8);
+    }
+}
+// backward of the ProjectReadout concat (lseg_vit.py:87-88): d_cat [B*np, 2D] (16-bit) accumulated into the fp32 gradient of
+// the hooked activation gx [B, ntok, D]:  gx[b, 1+p, :] += d_cat[b*np+p, :D] ;  gx[b, 0, :] += sum_p d_cat[b*np+p, D:]
+__global__ void readout_cat_bwd_kernel(const uint16_t* __restrict__ dcat, float* __restrict__ gx, int B, int ntok, int D, int dtype) {
+    const int np = ntok - 1;
+    const size_t total = (size_t)B * ntok * D;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(idx % D);
+        const size_t bt = idx / D;
+        const int t = (int)(bt % ntok), b = (int)(bt / ntok);
+        float acc = 0.f;
+        if (t > 0) {
+            acc = load_as_f32(dcat, ((size_t)b * np + t - 1) * 2 * D + d, dtype);
+        } else {
+            for (int p = 0; p < np; ++p) acc += load_as_f32(dcat, ((size_t)b * np + p) * 2 * D + D + d, dtype);
+        }
+        gx[idx] += acc;
+    }
+}
+// gradient of the embedding stage (lseg_vit.py:179-193) from gx = d x_0 [B, ntok, D] fp32:
+//   dtok rows [B*np, D] 16-bit (the patch-embed GEMM's dY)  and  dpos_sum [ntok, D] fp32 = sum_b gx[b]  (row 0 = d cls_token)
+__global__ void embed_bwd_kernel(const float* __restrict__ gx, uint16_t* __restrict__ dtok, float* __restrict__ dpos, int B, int ntok,
+                                 int D, int dtype) {
+    const size_t total = (size_t)ntok * D;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(idx % D), t = (int)(idx / D);
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float v = gx[((size_t)b * ntok + t) * D + d];
+            acc += v;
+            if (t > 0) store_from_f32(dtok, ((size_t)b * (ntok - 1) + t - 1) * D + d, dtype, v);
+        }
+        dpos[idx] = acc;
+    }
+}
+// transpose of pos_resize_kernel: dpos [1 + gh*gw, D] -> d pos_embed [1 + g_old^2, D] (+= with atomics; the caller zeroes
+// unless accumulating), plus d cls_token = dpos[0] (cls_token is added to row 0 of every image)
+__global__ void pos_resize_bwd_kernel(const float* __restrict__ dpos, float* __restrict__ dposemb, float* __restrict__ dcls, int g_old,
+                                      int gh, int gw, int D) {
+    const size_t total = (size_t)(1 + gh * gw) * D;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(idx % D);
+        const int t = (int)(idx / D);
+        const float g = dpos[idx];
+        if (t == 0) { atomicAdd(&dposemb[d], g); if (dcls) atomicAdd(&dcls[d], g); continue; }
+        const int y = (t - 1) / gw, x = (t - 1) - y * gw;
+        const float sy = fmaxf(0.f, ((float)y + 0.5f) * ((float)g_old / (float)gh) - 0.5f);
+        const float sx = fmaxf(0.f, ((float)x + 0.5f) * ((float)g_old / (float)gw) - 0.5f);
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < g_old - 1), x1 = x0 + (x0 < g_old - 1);
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        float* o = dposemb + D;
+        atomicAdd(&o[((size_t)y0 * g_old + x0) * D + d], (1.f - ly) * (1.f - lx) * g);
+        atomicAdd(&o[((size_t)y0 * g_old + x1) * D + d], (1.f - ly) * lx * g);
+        atomicAdd(&o[((size_t)y1 * g_old + x0) * D + d], ly * (1.f - lx) * g);
+        atomicAdd(&o[((size_t)y1 * g_old + x1) * D + d], ly * lx * g);
+    }
+}
+// gradient re-layouts into the reference's parameter shapes (dst = or += src):
+//   conv3x3  : dw tap-major [Co_p, 9, Ci_p] -> OIHW [Co, Ci, 3, 3]
+//   convT k=s: dw [(i*s+j)*Cp + co, Cp(ci)] -> [Ci, Co, s, s]          (ConvTranspose2d weight layout, lseg_vit.py:457-466)
+//   fold     : dst[c] (+)= sum_r src[r*ld + c], r < R                    (ConvTranspose bias: the s*s column groups share one bias)
+__global__ void conv_wgrad_unpack_kernel(const float* __restrict__ dw, float* __restrict__ dst, int Co, int Ci, int Cip, int accumulate) {
+    const size_t n = (size_t)Co * Ci * 9;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int t = (int)(i % 9), ci = (int)((i / 9) % Ci), co = (int)(i / ((size_t)9 * Ci));
+        const float v = dw[((size_t)co * 9 + t) * Cip + ci];
+        dst[i] = accumulate ? dst[i] + v : v;
+    }
+}
+__global__ void convT_wgrad_unpack_kernel(const float* __restrict__ dw, float* __restrict__ dst, int C, int Cp, int s, int accumulate) {
+    const size_t n = (size_t)C * C * s * s;
+    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(idx % s), i = (int)((idx / s) % s), co = (int)((idx / ((size_t)s * s)) % C), ci = (int)(idx / ((size_t)s * s * C));
+        const float v = dw[((size_t)(i * s + j) * Cp + co) * Cp + ci];
+        dst[idx] = accumulate ? dst[idx] + v : v;
+    }
+}
+__global__ void fold_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C, int ld, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += src[(size_t)r * ld + c];
+    dst[c] = accumulate ? dst[c] + s : s;
+}
+// running statistics of train-mode BatchNorm (nn.BatchNorm2d / SyncBatchNorm, momentum 0.1): updated in the caller's tensors
+__global__ void bn_running_update_kernel(const float* __restrict__ stats, float* __restrict__ rmean, float* __restrict__ rvar, int C,
+                                         float inv_n, float unbias, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mean = stats[c] * inv_n;
+    const float var = fmaxf(stats[C + c] * inv_n - mean * mean, 0.f);
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * var * unbias;
+}
+// SGD with momentum + weight decay (torch.optim.SGD semantics, lsegmentation_module.py:165-171), fused with the refresh of the
+// engine's packed 16-bit copy when the parameter is used as is (Linear weights):  g += wd*w ; m = mu*m + g ; w -= lr*m
+__global__ void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m, uint16_t* __restrict__ w16,
+                           size_t n, float lr, float mu, float wd, int first, int dtype) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float wi = w[i];
+        const float gi = g[i] + wd * wi;
+        const float mi = first ? gi : mu * m[i] + gi;       // torch: the momentum buffer starts as a copy of the first gradient
+        m[i] = mi;
+        const float wn = wi - lr * mi;
+        w[i] = wn;
+        if (w16) store_from_f32(w16, i, dtype, wn);
+    }
+}
+
 inline int grid_for(size_t total, int block = 256) {
     size_t g = (total + block - 1) / block;
     if (g > 256 * 16) g = 256 * 16;      // cap + grid-stride (cdna guide G11)
@@ -1023,9 +1207,9 @@ int launch_layernorm_backward(const void* dy, int dy_dtype, const float* x, cons
     return 0;
 }
 
-int launch_transpose16(const void* in, void* out, int R, int C, int ldi, int ldo, hipStream_t st, int shift) {
+int launch_transpose16(const void* in, void* out, int R, int C, int ldi, int ldo, hipStream_t st, int shift, int relu) {
     dim3 grid((ldo + 63) / 64, (C + 63) / 64);
-    hipLaunchKernelGGL(transpose16_kernel, grid, dim3(256), 0, st, (const uint16_t*)in, (uint16_t*)out, R, C, ldi, ldo, shift);
+    hipLaunchKernelGGL(transpose16_kernel, grid, dim3(256), 0, st, (const uint16_t*)in, (uint16_t*)out, R, C, ldi, ldo, shift, relu);
     CHECK_LAUNCH();
     return 0;
 }
@@ -1061,34 +1245,59 @@ int launch_qkv_grad_pack(const float* dq, const float* dk, const float* dv, void
     CHECK_LAUNCH();
     return 0;
 }
-int launch_bn_train_forward(const void* x, void* y, float* stats, const float* gamma, const float* beta, int B, int H, int W, int C,
-                            float eps, int dtype, hipStream_t st) {
+// BatchNorm in train mode, split so that a SyncBatchNorm exchange (all-reduce of the [2C] sums) can sit between the two halves.
+// `count` = pixels behind the sums (B*H*W, times the world size after the exchange).
+int launch_bn_stats(const void* x, float* stats, int B, int H, int W, int C, int dtype, hipStream_t st) {
     const int Mp = B * (H + 2) * (W + 2), rpb = 128;
     LSEG_HIP_TRY(hipMemsetAsync(stats, 0, (size_t)2 * C * sizeof(float), st));
     hipLaunchKernelGGL(bn_stats_kernel, dim3((C + 255) / 256, (Mp + rpb - 1) / rpb), dim3(256), 0, st, (const uint16_t*)x, dtype, stats, Mp, C, rpb);
     CHECK_LAUNCH();
-    if (y) {
-        hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for((size_t)B * H * W * C)), dim3(256), 0, st, (const uint16_t*)x, (uint16_t*)y,
-                           stats, gamma, beta, B, H, W, C, eps, dtype);
-        CHECK_LAUNCH();
-    }
     return 0;
+}
+int launch_bn_apply(const void* x, void* y, const float* stats, const float* gamma, const float* beta, const void* res1, const void* res2,
+                    int B, int H, int W, int C, float eps, double count, int dtype, hipStream_t st) {
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for((size_t)B * H * W * C)), dim3(256), 0, st, (const uint16_t*)x, (uint16_t*)y,
+                       stats, gamma, beta, B, H, W, C, eps, dtype, (float)(1.0 / count), (const uint16_t*)res1, (const uint16_t*)res2);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_bn_bwd_stats(const void* dy, const void* x, const float* stats, float* bstats, int B, int H, int W, int C, float eps,
+                        double count, int dtype, hipStream_t st) {
+    const int Mp = B * (H + 2) * (W + 2), rpb = 128;
+    LSEG_HIP_TRY(hipMemsetAsync(bstats, 0, (size_t)2 * C * sizeof(float), st));
+    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((C + 255) / 256, (Mp + rpb - 1) / rpb), dim3(256), 0, st, (const uint16_t*)dy,
+                       (const uint16_t*)x, stats, bstats, Mp, C, (float)(1.0 / count), eps, dtype, rpb);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_bn_bwd_apply(const void* dy, const void* x, const float* stats, const float* bstats, const float* gamma, void* dx,
+                        int B, int H, int W, int C, float eps, double count, int dtype, hipStream_t st) {
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((size_t)B * H * W * C)), dim3(256), 0, st, (const uint16_t*)dy,
+                       (const uint16_t*)x, (uint16_t*)dx, stats, bstats, gamma, B, H, W, C, eps, dtype, (float)(1.0 / count));
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_bn_train_forward(const void* x, void* y, float* stats, const float* gamma, const float* beta, int B, int H, int W, int C,
+                            float eps, int dtype, hipStream_t st) {
+    int r = launch_bn_stats(x, stats, B, H, W, C, dtype, st);
+    if (r || !y) return r;
+    return launch_bn_apply(x, y, stats, gamma, beta, nullptr, nullptr, B, H, W, C, eps, (double)B * H * W, dtype, st);
 }
 int launch_bn_train_backward(const void* dy, const void* x, const float* stats, const float* gamma, void* dx, float* bstats,
                              int B, int H, int W, int C, float eps, int dtype, hipStream_t st) {
-    const int Mp = B * (H + 2) * (W + 2), rpb = 128;
-    const float inv_n = 1.0f / (float)((size_t)B * H * W);
-    LSEG_HIP_TRY(hipMemsetAsync(bstats, 0, (size_t)2 * C * sizeof(float), st));
-    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((C + 255) / 256, (Mp + rpb - 1) / rpb), dim3(256), 0, st, (const uint16_t*)dy,
-                       (const uint16_t*)x, stats, bstats, Mp, C, inv_n, eps, dtype, rpb);
-    CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((size_t)B * H * W * C)), dim3(256), 0, st, (const uint16_t*)dy,
-                       (const uint16_t*)x, (uint16_t*)dx, stats, bstats, gamma, B, H, W, C, eps, dtype);
-    CHECK_LAUNCH();
-    return 0;
+    const double count = (double)B * H * W;
+    int r = launch_bn_bwd_stats(dy, x, stats, bstats, B, H, W, C, eps, count, dtype, st);
+    if (r) return r;
+    return launch_bn_bwd_apply(dy, x, stats, bstats, gamma, dx, B, H, W, C, eps, count, dtype, st);
 }
 int launch_relu_backward(const void* dy, const void* x, void* dx, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(relu_backward_kernel, dim3(grid_for(n)), dim3(256), 0, st, (const uint16_t*)dy, (const uint16_t*)x, (uint16_t*)dx, n);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_relu_backward_add(const void* dy, const void* x, const void* add, void* dx, size_t n, int dtype, hipStream_t st) {
+    hipLaunchKernelGGL(relu_backward_add_kernel, dim3(grid_for(n)), dim3(256), 0, st, (const uint16_t*)dy, (const uint16_t*)x,
+                       (const uint16_t*)add, (uint16_t*)dx, n, dtype);
     CHECK_LAUNCH();
     return 0;
 }
@@ -1108,8 +1317,8 @@ int launch_l2norm_scale_backward(const void* da, int da_dtype, const float* x, v
     CHECK_LAUNCH();
     return 0;
 }
-int launch_colsum16(const void* in, int dtype, float* out, int R, int C, int ld, hipStream_t st) {
-    LSEG_HIP_TRY(hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st));
+int launch_colsum16(const void* in, int dtype, float* out, int R, int C, int ld, hipStream_t st, int accumulate) {
+    if (!accumulate) LSEG_HIP_TRY(hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st));
     const int rpb = 256;
     dim3 grid((C + 255) / 256, (R + rpb - 1) / rpb);
     hipLaunchKernelGGL(colsum16_kernel, grid, dim3(256), 0, st, (const uint16_t*)in, dtype, out, R, C, ld, rpb);
@@ -1126,6 +1335,71 @@ int launch_seg_stats(const float* scores, const int64_t* target, int B, int K, i
     int grid = (int)std::min<size_t>((npix + 255) / 256, 2048);
     hipLaunchKernelGGL(seg_stats_kernel, dim3(grid), dim3(256), (size_t)(3 * K + 2) * sizeof(unsigned int), st,
                        scores, reinterpret_cast<const long long*>(target), K, HW, npix, ignore_index, counts, nll);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+
+int launch_gelu_forward(const void* pre, void* out, size_t n, int dtype, hipStream_t st) {
+    if (n % 8) return set_error(LSEG_ERR_UNSUPPORTED, "gelu forward: n=%zu must be a multiple of 8", n);
+    hipLaunchKernelGGL(gelu_forward_kernel, dim3(grid_for(n / 8)), dim3(256), 0, st, (const uint16_t*)pre, (uint16_t*)out, n / 8, dtype);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_unpad_rows(const void* in, void* out, int B, int H, int W, int C, hipStream_t st) {
+    hipLaunchKernelGGL(unpad_rows_kernel, dim3(grid_for((size_t)B * H * W * (C / 8))), dim3(256), 0, st, (const uint16_t*)in, (uint16_t*)out, B, H, W, C);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_dilate2(const void* dy, void* dyd, int B, int Ho, int Wo, int H, int W, int C, hipStream_t st) {
+    LSEG_HIP_TRY(hipMemsetAsync(dyd, 0, (size_t)B * (H + 2) * (W + 2) * C * 2, st));
+    hipLaunchKernelGGL(dilate2_kernel, dim3(grid_for((size_t)B * Ho * Wo * (C / 8))), dim3(256), 0, st, (const uint16_t*)dy, (uint16_t*)dyd, B, Ho, Wo, H, W, C);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_unpixshuf(const void* dl, void* dg, int B, int gh, int gw, int s, int C, hipStream_t st) {
+    hipLaunchKernelGGL(unpixshuf_kernel, dim3(grid_for((size_t)B * gh * gw * s * s * (C / 8))), dim3(256), 0, st, (const uint16_t*)dl, (uint16_t*)dg, B, gh, gw, s, C);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_readout_cat_bwd(const void* dcat, float* gx, int B, int ntok, int D, int dtype, hipStream_t st) {
+    hipLaunchKernelGGL(readout_cat_bwd_kernel, dim3(grid_for((size_t)B * ntok * D)), dim3(256), 0, st, (const uint16_t*)dcat, gx, B, ntok, D, dtype);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_embed_bwd(const float* gx, void* dtok, float* dpos, int B, int ntok, int D, int dtype, hipStream_t st) {
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for((size_t)ntok * D)), dim3(256), 0, st, gx, (uint16_t*)dtok, dpos, B, ntok, D, dtype);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_pos_resize_bwd(const float* dpos, float* dposemb, float* dcls, int g_old, int gh, int gw, int D, hipStream_t st) {
+    hipLaunchKernelGGL(pos_resize_bwd_kernel, dim3(grid_for((size_t)(1 + gh * gw) * D)), dim3(256), 0, st, dpos, dposemb, dcls, g_old, gh, gw, D);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_conv_wgrad_unpack(const float* dw, float* dst, int Co, int Ci, int Cip, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(conv_wgrad_unpack_kernel, dim3(grid_for((size_t)Co * Ci * 9)), dim3(256), 0, st, dw, dst, Co, Ci, Cip, accumulate);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_convT_wgrad_unpack(const float* dw, float* dst, int C, int Cp, int s, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(convT_wgrad_unpack_kernel, dim3(grid_for((size_t)C * C * s * s)), dim3(256), 0, st, dw, dst, C, Cp, s, accumulate);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_fold_rows(const float* src, float* dst, int R, int C, int ld, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(fold_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, st, src, dst, R, C, ld, accumulate);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_bn_running_update(const float* stats, float* rmean, float* rvar, int C, double count, float momentum, hipStream_t st) {
+    const float unbias = count > 1.0 ? (float)(count / (count - 1.0)) : 1.0f;
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats, rmean, rvar, C, (float)(1.0 / count), unbias, momentum);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_sgd(float* w, const float* g, float* m, void* w16, size_t n, float lr, float mu, float wd, int first, int dtype, hipStream_t st) {
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0, st, w, g, m, (uint16_t*)w16, n, lr, mu, wd, first, dtype);
     CHECK_LAUNCH();
     return 0;
 }

@@ -16,14 +16,34 @@ struct BoundParam {
     size_t numel() const { size_t n = 1; for (auto s : shape) n *= (size_t)s; return n; }
 };
 
-struct Lin { uint16_t* w = nullptr; float* b = nullptr; int n = 0, k = 0; };
+// w: packed [n, k] MFMA operand; b: fp32 bias.  Train mode adds wt = w transposed [k, n] (dgrad GEMM operand) for Linears and
+// wd = the flipped / channel-swapped 3x3 weights (dgrad as a forward conv) for convs.
+struct Lin { uint16_t* w = nullptr; float* b = nullptr; int n = 0, k = 0; uint16_t* wt = nullptr; uint16_t* wd = nullptr; };
 
 struct VitBlock { float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr; Lin qkv, proj, fc1, fc2; };
 struct TextBlock { float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr; Lin qkv, out, fc, proj; };
-struct Rcu { Lin c1, c2; };
+// c1/c2: BN-folded convs (eval).  Train mode: r1/r2 = the raw convs, BN affine parameters in fp32, per-unit saved maps.
+struct Rcu {
+    Lin c1, c2;
+    Lin r1, r2;
+    float *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;
+    std::string key;                                                       // "scratch.refinenetR.resConfUnitU."
+    uint16_t *cv1 = nullptr, *n1 = nullptr, *cv2 = nullptr;                // conv1 out, bn1 out, conv2 out (padded NHWC)
+    float *st1 = nullptr, *st2 = nullptr;                                  // [2C] batch sums of bn1 / bn2
+};
 struct Refine { Rcu u1, u2; Lin out_conv; bool has_u1 = false; };
 
 struct ProfileSlot { double total_ms = 0; int64_t launches = 0; double flops = 0; };
+
+// saved tensors of one ViT block for the backward (train mode): everything 16-bit is an MFMA operand of a wgrad / dgrad GEMM
+struct BlockSave {
+    float *xin = nullptr, *xmid = nullptr, *lse = nullptr;
+    uint16_t *ln1 = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *att = nullptr, *ln2 = nullptr, *pre = nullptr, *mlp = nullptr;
+};
+struct LevelSave { uint16_t *cat = nullptr, *ropre = nullptr, *ro = nullptr, *r1 = nullptr, *tmp = nullptr, *dro = nullptr; };
+
+typedef void (*lseg_reduce_fn)(void* user, void* dev_ptr, int64_t n_floats, void* stream);   // in-place sum over ranks
+typedef void (*lseg_bucket_fn)(void* user, int bucket, void* stream);                        // the bucket's gradients are enqueued
 
 class Engine {
 public:
@@ -38,6 +58,17 @@ public:
     int get_text_features(void* out_f16, hipStream_t st);
     int get_intermediate(const char* name, float* out, size_t cap, size_t* n, hipStream_t st);
     int get_profile(const char* family, double* ms, int64_t* launches, double* flops);
+    // ---- training step (train.hip; modules/lsegmentation_module.py:66-81) ----
+    int set_train(bool on);
+    int bind_grad(const char* key, float* dev_ptr);
+    int grad_ptr(const char* key, float** out, size_t* n);
+    int backward(const float* dlogits, const int64_t* target, int ignore_index, int accumulate, double* dev_loss2, hipStream_t st);
+    int sgd_step(float lr_pretrained, float lr_scratch, float momentum, float weight_decay, hipStream_t st);
+    int n_buckets() const { return cfg.depth + 1; }
+    int bucket_of(const std::string& key) const;
+    lseg_reduce_fn bn_sync_fn = nullptr; void* bn_sync_user = nullptr; int bn_world = 1;
+    lseg_bucket_fn bucket_fn = nullptr; void* bucket_user = nullptr;
+    bool train_mode = false;
 
     lseg_config cfg;
     int device;
@@ -56,6 +87,23 @@ private:
                 int stride, int relu_in, int relu_out, hipStream_t st);
     int refine(int r, int B, hipStream_t st);
     int flush_events();
+    // train.hip
+    int train_alloc();
+    int finalize_train(hipStream_t st);
+    int forward_train(const float* x, int B, float* logits, hipStream_t st);
+    int rcu_train(const uint16_t* in, Rcu& U, const uint16_t* res2, uint16_t* out, int B, int H, int W, hipStream_t st);
+    int rcu_backward(const uint16_t* dout, const uint16_t* in, Rcu& U, uint16_t* din, int lev, int B, int H, int W, int acc, hipStream_t st);
+    int lin_bwd(const uint16_t* dy, int M, int N, int K, const uint16_t* x, const uint16_t* wt, uint16_t* dx, float* dw, float* db,
+                int acc, hipStream_t st, int dw_rows = -1);
+    int conv_bwd(const uint16_t* dy_pad, const uint16_t* x_pad, int relu_x, const Lin& w, uint16_t* dx_pad, float* dw_dst, int B, int H,
+                 int W, int Cin, int Cout, int Ci_real, int Co_real, int acc, hipStream_t st);
+    int block_backward(int i, int B, int acc, hipStream_t st);
+    int readout_backward(int l, int B, int acc, hipStream_t st);
+    int reassemble_backward(int l, int B, int acc, hipStream_t st);
+    int refine_backward(int r, int B, int acc, hipStream_t st);
+    float* grad(const std::string& key, size_t n);
+    void bucket_done(int b, hipStream_t st) { if (bucket_fn) bucket_fn(bucket_user, b, (void*)st); }
+    int bn_sync(float* p, int n, hipStream_t st) { if (bn_sync_fn && bn_world > 1) bn_sync_fn(bn_sync_user, p, n, (void*)st); return 0; }
 
     std::map<std::string, BoundParam> bound_;
     std::vector<void*> allocs_;
@@ -100,6 +148,33 @@ private:
     int* d_eot_ = nullptr;
     uint16_t *tx_ = nullptr, *tln_ = nullptr, *tq_ = nullptr, *tk_ = nullptr, *tvt_ = nullptr, *tatt_ = nullptr,
              *tmlp_ = nullptr, *tpool_ = nullptr, *tfeat_ = nullptr, *tnorm_ = nullptr;
+
+    // ---- train mode (allocated by set_train(true)) ------------------------------------------------------------------------
+    bool train_alloc_ = false, train_fwd_valid_ = false;
+    int train_B_ = 0;
+    std::vector<BlockSave> sv_;
+    float* xlast_ = nullptr;               // output of the last block (= xin of a virtual block `depth`)
+    LevelSave lv_[4];
+    uint16_t *dmapA_[4] = {}, *dmapB_[4] = {}, *dmapC_[4] = {}, *dmapD_[4] = {};   // gradient maps per pyramid level (padded NHWC, zero border)
+    uint16_t *dpath_[4] = {};              // d path_{l+1}: aliases the level-(l-1) map it is produced in
+    uint16_t *dpath0_ = nullptr;           // d path_1 rows [B*4*h*w, F]
+    uint16_t *drn_[4] = {}, *dL_[4] = {};
+    uint16_t *rowsA_ = nullptr, *rowsB_ = nullptr;  // row-major 16-bit temporaries (GEMM operand views of gradient maps)
+    uint16_t *ddil_ = nullptr, *dtmp_ = nullptr;    // stride-2 reassemble conv: dilated dY, d(1x1 output)
+    uint16_t *tn16_ = nullptr;
+    float* last_logits_ = nullptr;
+    uint16_t *ws_a_ = nullptr, *ws_b_ = nullptr;    // transposed operands of the wgrad GEMMs
+    size_t ws_a_n_ = 0, ws_b_n_ = 0;
+    float* ws_dw_ = nullptr; size_t ws_dw_n_ = 0;   // wgrad output in the engine's packed layout before the re-layout into the parameter's
+    float *ws_stats_ = nullptr, *zeros_ = nullptr;
+    float *gx_ = nullptr, *dq_ = nullptr, *dk_ = nullptr, *dv_ = nullptr, *dpos_ = nullptr, *logits_ = nullptr, *dlogits_ = nullptr;
+    uint16_t *g16_ = nullptr, *dmlp_ = nullptr, *dln_ = nullptr, *datt_ = nullptr, *dqkv_ = nullptr, *dtok_ = nullptr;
+    uint16_t *drows_ = nullptr, *da_ = nullptr, *df_ = nullptr, *tnT_ = nullptr;
+    unsigned long long* counts_ = nullptr; double* nll_ = nullptr;
+    struct GradSlot { float* ptr = nullptr; size_t n = 0; bool bound = false; };
+    std::map<std::string, GradSlot> grads_;
+    std::map<std::string, float*> moms_;   // SGD momentum buffers (fused optimizer)
+    bool sgd_first_ = true;
 
     // ---- side stream: the (small, latency-bound) text tower overlaps the image tower ----------------
     hipStream_t text_stream_ = nullptr;

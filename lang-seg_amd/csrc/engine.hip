@@ -326,6 +326,7 @@ int Engine::finalize(hipStream_t st) {
     LSEG_HIP_TRY(hipStreamSynchronize(st));      // the caller may now free/modify its tensors
     finalized_ = true;
     text_valid = false;
+    if (train_alloc_) TRY(finalize_train(st));   // transposed / flipped / un-folded packs of the training step
     return 0;
 }
 
@@ -486,6 +487,10 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
     if (B < 1 || B > cfg.max_batch) return set_error(LSEG_ERR_INVALID, "B=%d outside [1, max_batch=%d]", B, cfg.max_batch);
     if (!x_in) return set_error(LSEG_ERR_INVALID, "x is NULL");
     LSEG_HIP_TRY(hipSetDevice(device));
+    if (train_mode) {                    // net.train(): activations saved for lseg_backward, BatchNorm on batch statistics
+        if (argmax_out) return set_error(LSEG_ERR_UNSUPPORTED, "argmax output is an inference feature (train mode is on)");
+        return forward_train(x_in, B, logits, st);
+    }
     const lseg_config& c = cfg;
     const int D = c.dim, H = c.heads, F = c.features, M = B * ntok_;
     last_B_ = B;

@@ -34,7 +34,7 @@ int launch_head_block(const float* in, float* out, const float* w9, const float*
 int launch_argmax_planes(const float* in, uint8_t* out, int B, int K, int HW, hipStream_t st);
 int launch_layernorm_backward(const void* dy, int dy_dtype, const float* x, const float* gamma, float* dx, float* dgamma,
                               float* dbeta, int M, int D, float eps, int accumulate, hipStream_t st);
-int launch_transpose16(const void* in, void* out, int R, int C, int ldi, int ldo, hipStream_t st, int shift = 0);
+int launch_transpose16(const void* in, void* out, int R, int C, int ldi, int ldo, hipStream_t st, int shift = 0, int relu = 0);
 int launch_attention_backward(const void* q, const void* k, const void* vt, const void* o, const void* d_o, const float* lse2,
                               float* dq, float* dk, float* dv, int B, int H, int ntok, int npad, int dtype, int causal, float scale,
                               hipStream_t stream);
@@ -52,8 +52,32 @@ int launch_upsample2x_nhwc_backward(const void* dout, void* din, int B, int H, i
 int launch_softmax_ce_backward(const float* scores, const int64_t* target, float* dz, int B, int K, int HW, int ignore_index,
                                const double* nll, hipStream_t st);
 int launch_conv_dgrad_pack(const void* wp, void* wd, int Co, int Ci, hipStream_t st);
-int launch_colsum16(const void* in, int dtype, float* out, int R, int C, int ld, hipStream_t st);
+int launch_colsum16(const void* in, int dtype, float* out, int R, int C, int ld, hipStream_t st, int accumulate = 0);
+int launch_relu_backward_add(const void* dy, const void* x, const void* add, void* dx, size_t n, int dtype, hipStream_t st);
 int launch_seg_stats(const float* scores, const int64_t* target, int B, int K, int HW, int ignore_index,
                      unsigned long long* counts, double* nll, hipStream_t st);
+
+// ---- engine-level training step (train.hip) --------------------------------------------------------------------------------
+int launch_attention_lse(const void* q, const void* k, const void* vt, void* out, float* lse2, int B, int H, int ntok, int npad, int dtype,
+                         int causal, float scale, hipStream_t stream);
+int launch_bn_stats(const void* x, float* stats, int B, int H, int W, int C, int dtype, hipStream_t st);
+int launch_bn_apply(const void* x, void* y, const float* stats, const float* gamma, const float* beta, const void* res1, const void* res2,
+                    int B, int H, int W, int C, float eps, double count, int dtype, hipStream_t st);
+int launch_bn_bwd_stats(const void* dy, const void* x, const float* stats, float* bstats, int B, int H, int W, int C, float eps,
+                        double count, int dtype, hipStream_t st);
+int launch_bn_bwd_apply(const void* dy, const void* x, const float* stats, const float* bstats, const float* gamma, void* dx,
+                        int B, int H, int W, int C, float eps, double count, int dtype, hipStream_t st);
+int launch_bn_running_update(const float* stats, float* rmean, float* rvar, int C, double count, float momentum, hipStream_t st);
+int launch_gelu_forward(const void* pre, void* out, size_t n, int dtype, hipStream_t st);
+int launch_unpad_rows(const void* in, void* out, int B, int H, int W, int C, hipStream_t st);
+int launch_dilate2(const void* dy, void* dyd, int B, int Ho, int Wo, int H, int W, int C, hipStream_t st);
+int launch_unpixshuf(const void* dl, void* dg, int B, int gh, int gw, int s, int C, hipStream_t st);
+int launch_readout_cat_bwd(const void* dcat, float* gx, int B, int ntok, int D, int dtype, hipStream_t st);
+int launch_embed_bwd(const float* gx, void* dtok, float* dpos, int B, int ntok, int D, int dtype, hipStream_t st);
+int launch_pos_resize_bwd(const float* dpos, float* dposemb, float* dcls, int g_old, int gh, int gw, int D, hipStream_t st);
+int launch_conv_wgrad_unpack(const float* dw, float* dst, int Co, int Ci, int Cip, int accumulate, hipStream_t st);
+int launch_convT_wgrad_unpack(const float* dw, float* dst, int C, int Cp, int s, int accumulate, hipStream_t st);
+int launch_fold_rows(const float* src, float* dst, int R, int C, int ld, int accumulate, hipStream_t st);
+int launch_sgd(float* w, const float* g, float* m, void* w16, size_t n, float lr, float mu, float wd, int first, int dtype, hipStream_t st);
 
 }  // namespace lseg

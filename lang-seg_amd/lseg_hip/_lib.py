@@ -61,6 +61,15 @@ SIGNATURES = {
     "lseg_set_debug": (_i, [_vp, _i]),
     "lseg_set_profiling": (_i, [_vp, _i]),
     "lseg_get_profile": (_i, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "lseg_set_train": (_i, [_vp, _i]),
+    "lseg_bind_grad": (_i, [_vp, C.c_char_p, _vp]),
+    "lseg_grad_ptr": (_i, [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_sz)]),
+    "lseg_grad_bucket": (_i, [_vp, C.c_char_p]),
+    "lseg_num_grad_buckets": (_i, [_vp]),
+    "lseg_backward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "lseg_set_bn_sync": (_i, [_vp, _vp, _vp, _i]),
+    "lseg_set_bucket_callback": (_i, [_vp, _vp, _vp]),
+    "lseg_sgd_step": (_i, [_vp, _f, _f, _f, _f, _vp]),
     "lseg_op_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "lseg_op_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "lseg_op_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
@@ -85,6 +94,10 @@ SIGNATURES = {
     "lseg_op_conv3x3_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "lseg_op_layernorm_backward": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
 }
+
+# callback types of the training step (include/lseg_hip.h: lseg_reduce_cb, lseg_bucket_cb)
+REDUCE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+BUCKET_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_void_p)
 
 _lib: Optional[C.CDLL] = None
 

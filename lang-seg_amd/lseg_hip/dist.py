@@ -77,89 +77,48 @@ def barrier():
 
 # ---- training exchange step (BASELINE config 4): ONE collective family ---------------------------------
 class GradBucketer:
-    """Bucketed gradient all-reduce for data-parallel training: the single collective of the path
-    (the reference gets it from Lightning's DDP, `train_lseg.py` -> accelerator="ddp").
+    """Bucketed gradient all-reduce over module parameters (the reference gets it from Lightning's DDP, `train_lseg.py` ->
+    accelerator="ddp") -- the torch.autograd-facing front of `lseg_hip.train.BucketExchange`.
 
-    Parameters are grouped into buckets in REVERSE forward order (head -> refinenets -> ViT block 23..0 -> patch embed),
-    one bucket per ViT block (12.6 M parameters = 50 MB fp32: large enough that a ring over the 7 x ~153 GB/s xGMI
-    links is bandwidth- not latency-bound, small enough to start while earlier blocks are still in backward).
-    `ready(i)` is called by the backward as soon as bucket i's gradients are complete: the bucket is flattened and its
-    all-reduce is launched asynchronously (on a side stream for CUDA/RCCL, so it overlaps the remaining dgrad/wgrad
-    GEMMs); `finish()` waits for every handle, divides by the world size (DDP's mean) and scatters the result back into
-    `.grad`.  Buckets never change after construction, so the flat buffers are allocated once.
-    """
+    Parameters are grouped with `lseg_hip.train.grad_bucket_index` -- the same rule the HIP engine uses (lseg_grad_bucket): bucket
+    0 = DPT head + reassemble (complete first in the backward), 1 + j = ViT block depth-1-j with the readout hooked on it, the
+    last one also carries patch_embed / cls_token / pos_embed.  Every bucket is ONE flat buffer and each parameter's `.grad` is
+    made a view into it, so `ready(i)` launches the all-reduce in place (no flatten / scatter copies) and `finish()` only waits
+    and divides.  Parameters without a gradient (find_unused_parameters=True in the reference) contribute zeros.  `finish()`
+    raises if a bucket was not readied this step (ranks that disagree would hang on mismatched collectives)."""
 
-    def __init__(self, named_params, bucket_key=None, dtype: Optional[torch.dtype] = None):
-        self.world = dist.get_world_size() if dist.is_initialized() else 1
-        key = bucket_key or default_bucket_key
-        groups, order = {}, []
-        for name, p in named_params:
-            if not p.requires_grad:
-                continue
-            k = key(name)
-            if k not in groups:
-                groups[k] = []
-                order.append(k)
-            groups[k].append((name, p))
-        self.keys = order[::-1]                                   # reverse forward order = backward completion order
-        self.buckets = [groups[k] for k in self.keys]
+    def __init__(self, named_params, depth: int, hooks, dtype: Optional[torch.dtype] = None, group=None):
+        from .train import BucketExchange, grad_bucket_index
+        named = [(n, p) for n, p in named_params if p.requires_grad]
+        nb = depth + 1
+        groups = [[] for _ in range(nb)]
+        for n, p in named:
+            b = grad_bucket_index(n[4:] if n.startswith("net.") else n, depth, hooks)
+            if b >= 0:
+                groups[b].append((n, p))
+        self.buckets = groups
+        self.keys = [[n for n, _ in g] for g in groups]
         self.flat = []
-        for b in self.buckets:
-            n = sum(p.numel() for _, p in b)
-            dev = b[0][1].device
-            self.flat.append(torch.zeros(n, dtype=dtype or b[0][1].dtype, device=dev))
-        self._work = [None] * len(self.buckets)
-        self._stream = torch.cuda.Stream() if (torch.cuda.is_available() and self.flat and self.flat[0].is_cuda) else None
+        for g in groups:
+            n = sum(p.numel() for _, p in g)
+            dev = g[0][1].device if g else torch.device("cpu")
+            flat = torch.zeros(max(n, 1), dtype=dtype or torch.float32, device=dev)
+            off = 0
+            for _, p in g:
+                view = flat[off:off + p.numel()].view_as(p)
+                if p.grad is not None:
+                    view.copy_(p.grad)
+                p.grad = view                                  # autograd accumulates into the bucket from now on
+                off += p.numel()
+            self.flat.append(flat)
+        self.exchange = BucketExchange(self.flat, group)
+        self.world = self.exchange.world
 
     def __len__(self):
         return len(self.buckets)
 
     def ready(self, i: int):
-        """Gradients of bucket i are final: flatten and launch its all-reduce (asynchronous)."""
-        flat, off = self.flat[i], 0
-        for _, p in self.buckets[i]:
-            n = p.numel()
-            g = p.grad if p.grad is not None else torch.zeros_like(p)     # unused parameters (find_unused_parameters=True)
-            flat[off:off + n].copy_(g.reshape(-1))
-            off += n
-        if self.world == 1:
-            return
-        if self._stream is not None:
-            self._stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(self._stream):
-                self._work[i] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
-        else:
-            self._work[i] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        self.exchange.ready(i)
 
     def finish(self):
-        """Wait for all buckets, average, write back into .grad (call once per step, before the optimiser)."""
-        for i, b in enumerate(self.buckets):
-            if self._work[i] is not None:
-                self._work[i].wait()
-                self._work[i] = None
-            flat, off = self.flat[i], 0
-            if self.world > 1:
-                flat.div_(self.world)
-            for _, p in b:
-                n = p.numel()
-                if p.grad is None:
-                    p.grad = torch.empty_like(p)
-                p.grad.copy_(flat[off:off + n].view_as(p))
-                off += n
-        if self._stream is not None:
-            torch.cuda.current_stream().wait_stream(self._stream)
-
-
-def default_bucket_key(name: str) -> str:
-    """One bucket per ViT block / per refinenet / per remaining top-level group (state-dict names of SURVEY App. B)."""
-    parts = name.split(".")
-    if name.startswith("pretrained.model.blocks.") or name.startswith("net.pretrained.model.blocks."):
-        i = parts.index("blocks")
-        return ".".join(parts[: i + 2])
-    if "refinenet" in name:
-        i = [k for k, s in enumerate(parts) if s.startswith("refinenet")][0]
-        return ".".join(parts[: i + 1])
-    if "clip_pretrained" in parts:
-        return "clip_pretrained"
-    i = 2 if parts[0] == "net" else 1
-    return ".".join(parts[: i + 1]) if len(parts) > i else name
+        self.exchange.finish()

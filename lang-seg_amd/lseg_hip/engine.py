@@ -72,6 +72,7 @@ class HipEngine:
         self._K = 0
         self._group = 0
         self._keep: List[torch.Tensor] = []
+        self.training = False
 
     def close(self):
         if getattr(self, "_h", None):
@@ -86,9 +87,11 @@ class HipEngine:
 
     # ---- parameters -------------------------------------------------------------------------------
     def load_state_dict(self, sd: Dict[str, torch.Tensor], prefix: str = ""):
-        """Bind every tensor of a (reference-layout) state dict and repack on the device."""
+        """Bind every tensor of a (reference-layout) state dict and repack on the device.  Tensors already on the engine's device
+        are bound IN PLACE (no copy): they are the fp32 masters the fused SGD step updates and the BatchNorm running statistics
+        train mode writes (include/lseg_hip.h); `self.bound[key]` is the device tensor behind each key."""
         st = _stream_ptr(self.device)
-        keep = []
+        self.bound: Dict[str, torch.Tensor] = {}
         for k, v in sd.items():
             if prefix:
                 if not k.startswith(prefix):
@@ -99,12 +102,11 @@ class HipEngine:
             if v.dtype not in _DT:
                 continue
             t = v.detach().to(self.device).contiguous()
-            keep.append(t)
+            self.bound[k] = t
             shape = (C.c_int64 * max(1, t.dim()))(*t.shape)
             _lib.check(self.lib.lseg_bind_param(self._h, k.encode(), C.c_void_p(t.data_ptr()), _DT[t.dtype],
                                                 shape, t.dim()))
         _lib.check(self.lib.lseg_finalize_params(self._h, C.c_void_p(st)))
-        del keep      # finalize synchronises: the engine now owns packed copies
 
     # ---- text -------------------------------------------------------------------------------------------
     def set_tokens(self, tokens: torch.Tensor, labels_per_image: int = 0):
@@ -149,6 +151,78 @@ class HipEngine:
         if want_logits and want_argmax:
             return logits, amax
         return logits if want_logits else amax
+
+    # ---- training step (include/lseg_hip.h "training step"; modules/lsegmentation_module.py:66-81) ---------------------
+    def trainable_keys(self, sd: Dict[str, torch.Tensor]) -> List[str]:
+        """State-dict keys (relative to `net.`) the backward produces gradients for, in bucket order."""
+        keys = []
+        for k, v in sd.items():
+            if not v.is_floating_point() or v.dtype != torch.float32 or k.endswith(("running_mean", "running_var")):
+                continue
+            if k.startswith(_SKIP_PREFIX) or ".refinenet4.resConfUnit1." in k or k.startswith("clip_pretrained."):
+                continue
+            b = self.lib.lseg_grad_bucket(self._h, k.encode())
+            if b >= 0:
+                keys.append((b, k))
+        return [k for _, k in sorted(keys, key=lambda t: t[0])]
+
+    def enable_training(self, sd: Dict[str, torch.Tensor]):
+        """net.train(): allocate the saved-activation workspace, and one FLAT fp32 gradient buffer per bucket (what the RCCL
+        all-reduce runs on, in place); every parameter's gradient is a view into its bucket, bound to the engine."""
+        _lib.check(self.lib.lseg_set_train(self._h, 1))
+        nb = self.lib.lseg_num_grad_buckets(self._h)
+        groups: List[List[str]] = [[] for _ in range(nb)]
+        for k in self.trainable_keys(sd):
+            groups[self.lib.lseg_grad_bucket(self._h, k.encode())].append(k)
+        self.grad_buckets: List[torch.Tensor] = []
+        self.grads: Dict[str, torch.Tensor] = {}
+        for ks in groups:
+            n = sum(sd[k].numel() for k in ks)
+            flat = torch.zeros(max(n, 1), dtype=torch.float32, device=self.device)
+            off = 0
+            for k in ks:
+                m = sd[k].numel()
+                view = flat[off:off + m].view(sd[k].shape)
+                _lib.check(self.lib.lseg_bind_grad(self._h, k.encode(), C.c_void_p(view.data_ptr())))
+                self.grads[k] = view
+                off += m
+            self.grad_buckets.append(flat)
+        self._loss = torch.zeros(2, dtype=torch.float64, device=self.device)
+        self.training = True
+
+    def set_train(self, enabled: bool):
+        _lib.check(self.lib.lseg_set_train(self._h, int(enabled)))
+        self.training = bool(enabled)
+
+    def backward(self, target: Optional[torch.Tensor] = None, dlogits: Optional[torch.Tensor] = None,
+                 ignore_index: int = -1, accumulate: bool = False) -> Optional[torch.Tensor]:
+        """After a train-mode forward.  target int64 [B,H,W] -> returns the mean cross-entropy (0-dim tensor on the device,
+        no host sync); or dlogits fp32 [B,K,H,W] (autograd hand-over) -> None.  Gradients land in self.grads / grad_buckets."""
+        st = C.c_void_p(_stream_ptr(self.device))
+        if dlogits is not None:
+            dl = dlogits.contiguous()
+            assert dl.dtype == torch.float32 and dl.device == self.device
+            _lib.check(self.lib.lseg_backward(self._h, C.c_void_p(dl.data_ptr()), None, ignore_index, int(accumulate), None, st))
+            return None
+        t = target.contiguous()
+        assert t.dtype == torch.int64 and t.device == self.device
+        _lib.check(self.lib.lseg_backward(self._h, None, C.c_void_p(t.data_ptr()), ignore_index, int(accumulate),
+                                          C.c_void_p(self._loss.data_ptr()), st))
+        return (self._loss[0] / self._loss[1]).float()
+
+    def sgd_step(self, lr_pretrained: float, lr_scratch: float, momentum: float = 0.9, weight_decay: float = 1e-4):
+        _lib.check(self.lib.lseg_sgd_step(self._h, lr_pretrained, lr_scratch, momentum, weight_decay,
+                                          C.c_void_p(_stream_ptr(self.device))))
+
+    def set_bucket_callback(self, fn):
+        """fn(bucket_index) is called on the host as soon as the bucket's last gradient kernel is enqueued."""
+        self._bucket_cb = _lib.BUCKET_CB(lambda user, b, stream: fn(int(b))) if fn is not None else None
+        _lib.check(self.lib.lseg_set_bucket_callback(self._h, C.cast(self._bucket_cb, C.c_void_p) if fn else None, None))
+
+    def set_bn_sync(self, fn, world_size: int):
+        """fn(dev_ptr, n_floats) must sum the n floats at dev_ptr over the ranks, ordered on the current stream."""
+        self._bn_cb = _lib.REDUCE_CB(lambda user, p, n, stream: fn(int(p), int(n))) if fn is not None else None
+        _lib.check(self.lib.lseg_set_bn_sync(self._h, C.cast(self._bn_cb, C.c_void_p) if fn else None, None, int(world_size)))
 
     # ---- taps / measurement ----------------------------------------------------------------------------
     def set_debug(self, enabled: bool):

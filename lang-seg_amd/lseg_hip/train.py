@@ -1,0 +1,145 @@
+"""The data-parallel training step of the path (BASELINE config 4).
+
+What the reference gets from Lightning (`train_lseg.py` -> utils.do_training: accelerator="ddp", sync_batchnorm=True,
+utils.py:20-22,34) around `LSegmentationModule.training_step` (modules/lsegmentation_module.py:66-81):
+
+  * DistributedDataParallel's bucketed gradient all-reduce  ->  `BucketExchange`: the HIP engine writes every gradient straight
+    into one flat fp32 buffer per bucket (lseg_bind_grad); as soon as the last kernel of a bucket is enqueued the engine calls
+    back, the bucket's RCCL all-reduce is launched IN PLACE on a side stream (ordered behind the compute stream by an event) and
+    runs under the remaining backward GEMMs.  Buckets = DPT head | ViT block 23 | ... | ViT block 0 + embeddings (12.6 M
+    parameters = 50 MB fp32 per block: bandwidth-bound on the 7 x ~153 GB/s xGMI links).  No flatten / scatter copies.
+  * SyncBatchNorm  ->  `bn_sync`: the 2C per-layer sums are all-reduced between the statistics and the normalisation kernels
+    (forward) and between the gradient sums and the dx kernel (backward): 56 x 2 KB latency-bound collectives per step, exactly
+    the reference's semantics.  `sync_bn=False` keeps per-GPU statistics (a declared deviation: no collective besides the
+    gradient all-reduce, as BASELINE.json's north_star words it).
+  * SGD(momentum 0.9, weight decay 1e-4) with the two learning-rate groups of configure_optimizers (:119-127,165-171)
+    ->  the engine's fused `lseg_sgd_step` on the fp32 masters (torch.optim works too: the gradients are ordinary tensors).
+
+One process per GPU; `torch.distributed` backend "nccl" is RCCL on ROCm, "gloo" in the CPU tests of `BucketExchange`.
+"""
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def grad_bucket_index(key: str, depth: int, hooks) -> int:
+    """Bucket of a state-dict key (relative to `net.`): the Python mirror of the engine's lseg_grad_bucket (csrc/train.hip
+    Engine::bucket_of; tests/test_gpu_train.py holds the two together).  -1 = not a trainable parameter of the path."""
+    bp = "pretrained.model.blocks."
+    if key.startswith(bp):
+        return 1 + (depth - 1 - int(key[len(bp):].split(".")[0]))
+    ap = "pretrained.act_postprocess"
+    if key.startswith(ap):
+        l = int(key[len(ap)]) - 1
+        if key[len(ap) + 1:].startswith(".0."):
+            return 1 + (depth - 1 - hooks[l])
+        return 0
+    if key.startswith("scratch."):
+        return 0
+    if key.startswith("pretrained.model."):
+        return depth
+    return -1
+
+
+class BucketExchange:
+    """In-place, asynchronous mean all-reduce of flat gradient buckets in backward-completion order."""
+
+    def __init__(self, buckets: List[torch.Tensor], group=None):
+        self.buckets = buckets
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._work = [None] * len(buckets)
+        self._ready = [False] * len(buckets)
+        cuda = bool(buckets) and buckets[0].is_cuda
+        self._stream = torch.cuda.Stream(device=buckets[0].device) if cuda else None
+        self._event = torch.cuda.Event() if cuda else None
+
+    def __len__(self):
+        return len(self.buckets)
+
+    def ready(self, i: int):
+        """Bucket i's gradients are complete on the current stream: launch its all-reduce behind them."""
+        if self._ready[i]:
+            raise RuntimeError(f"gradient bucket {i} was readied twice in one step")
+        self._ready[i] = True
+        if self.world == 1:
+            return
+        flat = self.buckets[i]
+        if self._stream is not None:
+            self._event.record(torch.cuda.current_stream(flat.device))
+            self._stream.wait_event(self._event)
+            with torch.cuda.stream(self._stream):
+                self._work[i] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self._work[i] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish(self):
+        """Every bucket must have been readied this step (ranks that disagree would hang on mismatched collectives): wait,
+        turn the sums into DDP's mean, hand the buffers back to the compute stream."""
+        missing = [i for i, r in enumerate(self._ready) if not r]
+        if missing:
+            raise RuntimeError(f"gradient buckets {missing} were never readied this step")
+        for i, flat in enumerate(self.buckets):
+            w = self._work[i]
+            if w is not None:
+                if self._stream is not None:
+                    with torch.cuda.stream(self._stream):
+                        w.wait()
+                        flat.div_(self.world)
+                else:
+                    w.wait()
+                    flat.div_(self.world)
+                self._work[i] = None
+        if self._stream is not None and self.world > 1:
+            torch.cuda.current_stream(self.buckets[0].device).wait_stream(self._stream)
+        self._ready = [False] * len(self.buckets)
+
+
+class _HipCopy:
+    """device-to-device hipMemcpyAsync by raw pointer (the BatchNorm sums live in engine-owned memory)."""
+
+    def __init__(self):
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        self.hip.hipMemcpyAsync.restype = C.c_int
+
+    def __call__(self, dst: int, src: int, nbytes: int, stream: int):
+        rc = self.hip.hipMemcpyAsync(C.c_void_p(dst), C.c_void_p(src), nbytes, 3, C.c_void_p(stream))
+        if rc != 0:
+            raise RuntimeError(f"hipMemcpyAsync failed with {rc}")
+
+
+class DataParallelTrainer:
+    """forward (train mode) -> loss + backward with overlapped bucket all-reduce -> fused SGD, on one engine."""
+
+    def __init__(self, engine, state_dict: Dict[str, torch.Tensor], sync_bn: bool = True, group=None):
+        self.eng = engine
+        engine.enable_training(state_dict)
+        self.exchange = BucketExchange(engine.grad_buckets, group)
+        self.world = self.exchange.world
+        engine.set_bucket_callback(self.exchange.ready)
+        self.sync_bn = bool(sync_bn) and self.world > 1
+        if self.sync_bn:
+            self._copy = _HipCopy()
+            self._bn_buf = torch.zeros(1 << 16, dtype=torch.float32, device=engine.device)
+            self._group = group
+            engine.set_bn_sync(self._bn_allreduce, self.world)
+
+    def _bn_allreduce(self, ptr: int, n: int):
+        st = torch.cuda.current_stream(self.eng.device).cuda_stream
+        buf = self._bn_buf[:n]
+        self._copy(buf.data_ptr(), ptr, 4 * n, st)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self._group)
+        self._copy(ptr, buf.data_ptr(), 4 * n, st)
+
+    def step(self, x: torch.Tensor, target: torch.Tensor, lr_pretrained: float, lr_scratch: float, momentum: float = 0.9,
+             weight_decay: float = 1e-4, ignore_index: int = -1, optimize: bool = True) -> torch.Tensor:
+        """One training step; returns the (local) mean cross-entropy as a 0-dim device tensor, no host synchronisation."""
+        self.eng.forward(x, want_logits=False)
+        loss = self.eng.backward(target=target, ignore_index=ignore_index)
+        self.exchange.finish()
+        if optimize:
+            self.eng.sgd_step(lr_pretrained, lr_scratch, momentum, weight_decay)
+        return loss

@@ -65,9 +65,34 @@ class LSegmentationModule(_Base):
         inter, union = batch_intersection_union(pred.data, target.data, self.nclass)
         return correct, labeled, inter, union
 
-    def training_step(self, batch, batch_nb):                 # :66-81
-        raise NotImplementedError("training step (backward kernels + RCCL gradient all-reduce) is the next "
-                                  "row of the hot-path scope (SURVEY.md §8a17/§8e); this round ships inference")
+    def training_step(self, batch, batch_nb):                 # :66-81 (autocast/GradScaler are disabled there: self.enabled = False)
+        img, target = batch
+        out = self(img)                                       # train-mode engine forward; autograd node = lseg_backward
+        multi_loss = isinstance(out, tuple)
+        if not hasattr(self, "criterion"):
+            self.criterion = self.get_criterion(**self.other_kwargs)
+        loss = self.criterion(*out, target) if multi_loss else self.criterion(out, target)
+        final_output = out[0] if multi_loss else out
+        train_pred, train_gt = self._filter_invalid(final_output, target)
+        if train_gt.nelement() != 0 and hasattr(self, "train_accuracy"):
+            self.train_accuracy(train_pred, train_gt)
+        self.log("train_loss", loss)
+        return loss
+
+    def native_training_step(self, img, target, lr_scale=1.0):
+        """The same step without autograd in the loop (the fast path bench.py --train measures): engine forward + fused
+        upsample/CE/backward + bucketed RCCL all-reduce + fused SGD, through lseg_hip.train.DataParallelTrainer."""
+        from lseg_hip.train import DataParallelTrainer
+        net = self.net
+        B, _, H, W = img.shape
+        eng = net._engine(B, H, W, net.text.shape[0], img.device)
+        if getattr(self, "_trainer", None) is None or self._trainer.eng is not eng:
+            eng.set_tokens(net.text)
+            self._trainer = DataParallelTrainer(eng, dict(net.state_dict()), sync_bn=True)
+        wd = self.other_kwargs.get("weight_decay", 1e-4)
+        loss = self._trainer.step(img.float(), target, self.base_lr * lr_scale, self.base_lr * 10 * lr_scale, 0.9, wd,
+                                  self.other_kwargs.get("ignore_index", -1))
+        return loss                                           # the fused SGD updated the parameters' storage in place
 
     def _filter_invalid(self, pred, target):                  # :114-117
         valid = target != self.other_kwargs["ignore_index"]

@@ -54,6 +54,23 @@ def _make_fusion_block(features, use_bn):
                                      expand=False, align_corners=True)
 
 
+class _EngineTrainFn(torch.autograd.Function):
+    """Autograd node of the train-mode forward: `loss.backward()` (Lightning's, or anyone's) lands in lseg_backward with the
+    gradient of the logits; the parameter gradients come back as views of the engine's flat buckets (lseg_bind_grad).
+    The parameters are inputs only so that autograd routes their gradients; the arithmetic is all in the HIP engine."""
+
+    @staticmethod
+    def forward(ctx, x, net, eng, keys, *params):
+        ctx.eng, ctx.keys = eng, keys
+        return eng.forward(x)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        ctx.eng.backward(dlogits=dlogits)
+        grads = tuple(ctx.eng.grads[k] if k in ctx.eng.grads else None for k in ctx.keys)
+        return (None, None, None, None) + grads
+
+
 class LSeg(BaseModel):
     def __init__(self, head, features=256, backbone="clip_vitl16_384", readout="project",
                  channels_last=False, use_bn=False, **kwargs):
@@ -118,16 +135,21 @@ class LSeg(BaseModel):
             raise RuntimeError("LSegNet.forward needs a CUDA/HIP tensor: like the reference (clip.load(device="
                                "'cuda'), lseg_vit.py:224) this network has no CPU path, and the HIP engine has no "
                                "PyTorch fallback")
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("the HIP engine implements the inference forward; the training step "
-                                      "(backward + RCCL all-reduce) is the next row of SURVEY.md §8 -- call .eval()")
         B, _, H, W = x.shape
         eng = self._engine(B, H, W, text.shape[0], x.device)
+        train = self.training and torch.is_grad_enabled()          # net.train() under autograd: training_step (:66-81)
+        if train and not getattr(eng, "grads", None):
+            eng.enable_training({k: v for k, v in self.state_dict().items()})
+        if eng.training != train:
+            eng.set_train(train)
         tkey = (tuple(text.shape), text.data_ptr() if labelset == "" else hash(text.numpy().tobytes()))
         if eng._tok != tkey:
             eng.set_tokens(text)
             eng._tok = tkey
         eng.set_text_cache(bool(self.cache_text))
+        if train:
+            named = [(k, p) for k, p in self.named_parameters() if k in eng.grads]
+            return _EngineTrainFn.apply(x.float(), self, eng, tuple(k for k, _ in named), *[p for _, p in named])
         return eng.forward(x.float())
 
 

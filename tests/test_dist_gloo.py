@@ -75,25 +75,30 @@ def _bucket_worker(rank, world, port, q):
         p.requires_grad_(True)
         p.grad = None if i % 17 == 3 else torch.randn(p.shape, generator=g)     # a few "unused" parameters
     mine = [None if p.grad is None else p.grad.clone() for _, p in params]
-    b = D.GradBucketer(params)
-    order = list(range(len(b)))
-    if rank == 1:
-        pass                                    # same launch order on every rank (collectives are matched by order)
-    for i in order:
+    cfg = net.cfg
+    b = D.GradBucketer(params, cfg.depth, cfg.hooks)
+    try:                                        # a bucket that was never readied is an error, not stale gradients
+        b.finish()
+        unreadied_raises = False
+    except RuntimeError:
+        unreadied_raises = True
+    for i in range(len(b)):                     # same launch order on every rank (collectives are matched by order)
         b.ready(i)
     b.finish()
-    out = {n: p.grad.clone() for n, p in params}
-    keys = list(b.keys)
+    out = {n: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for n, p in params}
+    keys = [ks for ks in b.keys]
     gathered = [None] * world
     dist.all_gather_object(gathered, mine)
     if rank == 0:                               # verify here: only small python objects cross the process boundary
         bad = []
         for i, (n, _) in enumerate(params):
+            if n.startswith("clip_pretrained."):      # frozen tower: in no optimizer group, in no bucket
+                continue
             g0 = gathered[0][i] if gathered[0][i] is not None else torch.zeros_like(out[n])
             g1 = gathered[1][i] if gathered[1][i] is not None else torch.zeros_like(out[n])
             if not torch.allclose(out[n], (g0 + g1) / 2, atol=1e-6):
                 bad.append(n)
-        q.put((bad, keys, len(params)))
+        q.put((bad, keys, len(params), unreadied_raises))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -107,12 +112,17 @@ def test_bucketed_gradient_allreduce_two_ranks():
     procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    bad, keys, nparams = q.get(timeout=150)
+    bad, keys, nparams, unreadied_raises = q.get(timeout=150)
     for p in procs:
         p.join(timeout=30)
         assert p.exitcode == 0
     assert not bad and nparams > 50, bad[:5]
-    # buckets: reverse forward order, one per ViT block / refinenet
-    blk = [k for k in keys if ".blocks." in k]
-    assert len(blk) >= 2 and blk == sorted(blk, key=lambda s: -int(s.split(".")[-1]))
-    assert any("refinenet" in k for k in keys) and keys.index([k for k in keys if "refinenet1" in k][0]) < keys.index(blk[0])
+    assert unreadied_raises
+    # buckets in backward-completion order: DPT head + reassemble first, then ViT blocks depth-1 .. 0 (tiny16: depth 4),
+    # each with the ProjectReadout hooked on it, the last one with the embeddings
+    assert len(keys) == 5
+    assert any("refinenet1" in k for k in keys[0]) and any("act_postprocess1.3" in k for k in keys[0])
+    for j in range(4):
+        assert all(f".blocks.{3 - j}." in k or "0.project.0" in k or j == 3 for k in keys[1 + j]), keys[1 + j][:4]
+        assert any(f".blocks.{3 - j}." in k for k in keys[1 + j])
+    assert any("patch_embed" in k for k in keys[4]) and any("pos_embed" in k for k in keys[4])

@@ -332,8 +332,13 @@ def test_engine_matches_fixtures_made_by_the_reference_code(name, dtype, golden_
     out = eng.forward(x.cuda()).cpu()
     ref = g["logits"]
     assert out.shape == ref.shape
-    # head blocks (arch_option 1/2) amplify the cosine logits: their gain on this random net = output range / input range (14.3)
-    gain = 1.0 if arch == 0 else max(1.0, ref.abs().max().item() / 14.2857)
+    # head blocks (arch_option 1/2, lseg_net.py:43-79): each applies ONE shared 3x3 filter per label plane (+ the channel max
+    # for the bottleneck) and a 1-Lipschitz activation, so a block amplifies an input error by at most sum|w| (+1): the
+    # tolerance follows that bound, computed from the actual filter
+    gain = 1.0
+    if arch != 0:
+        per_block = sd["scratch.head_block.depthwise.depthwise.weight"].abs().sum().item() + (1.0 if arch == 1 else 0.0)
+        gain = max(1.0, per_block) ** depth
     err = (out - ref).abs().max().item()
     print(f"{name}[{dtype}]: max|dlogit| {err:.4f} (logit range {ref.abs().max().item():.2f}, head-block gain {gain:.2f})")
     assert err <= REF_TOL[dtype] * gain, (name, dtype, err)
