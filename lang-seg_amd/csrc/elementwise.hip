@@ -1194,10 +1194,12 @@ int launch_argmax_planes(const float* in, uint8_t* out, int B, int K, int HW, hi
 }
 
 int launch_layernorm_backward(const void* dy, int dy_dtype, const float* x, const float* gamma, float* dx, float* dgamma,
-                              float* dbeta, int M, int D, float eps, int accumulate, hipStream_t st) {
+                              float* dbeta, int M, int D, float eps, int accumulate, hipStream_t st, int accumulate_params) {
     if (D % 4 != 0 || D > 64 * 4 * 4) return set_error(LSEG_ERR_UNSUPPORTED, "layernorm backward: D=%d", D);
-    LSEG_HIP_TRY(hipMemsetAsync(dgamma, 0, (size_t)D * sizeof(float), st));
-    LSEG_HIP_TRY(hipMemsetAsync(dbeta, 0, (size_t)D * sizeof(float), st));
+    if (!accumulate_params) {
+        LSEG_HIP_TRY(hipMemsetAsync(dgamma, 0, (size_t)D * sizeof(float), st));
+        LSEG_HIP_TRY(hipMemsetAsync(dbeta, 0, (size_t)D * sizeof(float), st));
+    }
     int blocks = (M + 3) / 4;
     if (blocks > 1024) blocks = 1024;
 #define LN_BWD(V) hipLaunchKernelGGL(layernorm_bwd_kernel<V>, dim3(blocks), dim3(256), 0, st, dy, dy_dtype, x, gamma, dx, dgamma, dbeta, M, D, eps, accumulate)

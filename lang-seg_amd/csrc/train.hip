@@ -511,16 +511,12 @@ int Engine::block_backward(int i, int B, int acc, hipStream_t st) {
     auto G = [&](const char* k, size_t n) { return grad(p + k, n); };
     float *dg1 = G("norm1.weight", D), *db1 = G("norm1.bias", D), *dg2 = G("norm2.weight", D), *db2 = G("norm2.bias", D);
     if (!dg1 || !db1 || !dg2 || !db2) return LSEG_ERR_INVALID;
-    if (!acc) {
-        LSEG_HIP_TRY(hipMemsetAsync(dg1, 0, D * sizeof(float), st)); LSEG_HIP_TRY(hipMemsetAsync(db1, 0, D * sizeof(float), st));
-        LSEG_HIP_TRY(hipMemsetAsync(dg2, 0, D * sizeof(float), st)); LSEG_HIP_TRY(hipMemsetAsync(db2, 0, D * sizeof(float), st));
-    }
     // x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
     TRY(launch_convert(gx_, DT_F32, g16_, img_dt_, (size_t)M * D, st));
     TRY(lin_bwd(g16_, M, D, 4 * D, s.mlp, b.fc2.wt, dmlp_, G("mlp.fc2.weight", (size_t)D * 4 * D), G("mlp.fc2.bias", D), acc, st));
     TRY(launch_gelu_backward(dmlp_, s.pre, dmlp_, (size_t)M * 4 * D, img_dt_, st));
     TRY(lin_bwd(dmlp_, M, 4 * D, D, s.ln2, b.fc1.wt, dln_, G("mlp.fc1.weight", (size_t)4 * D * D), G("mlp.fc1.bias", 4 * D), acc, st));
-    TRY(launch_layernorm_backward(dln_, img_dt_, s.xmid, b.g2, gx_, dg2, db2, M, D, 1e-6f, 1, st));
+    TRY(launch_layernorm_backward(dln_, img_dt_, s.xmid, b.g2, gx_, dg2, db2, M, D, 1e-6f, 1, st, acc));
     // x_mid = x_in + proj(attention(qkv(LN1(x_in))))
     TRY(launch_convert(gx_, DT_F32, g16_, img_dt_, (size_t)M * D, st));
     TRY(lin_bwd(g16_, M, D, D, s.att, b.proj.wt, datt_, G("attn.proj.weight", (size_t)D * D), G("attn.proj.bias", D), acc, st));
@@ -528,7 +524,7 @@ int Engine::block_backward(int i, int B, int acc, hipStream_t st) {
     TRY(launch_attention_backward(s.q, s.k, s.vt, s.att, datt_, s.lse, dq_, dk_, dv_, B, H, ntok_, npad_, img_dt_, 0, 0.125f, st));
     TRY(launch_qkv_grad_pack(dq_, dk_, dv_, dqkv_, B, H, ntok_, npad_, img_dt_, st));
     TRY(lin_bwd(dqkv_, M, 3 * D, D, s.ln1, b.qkv.wt, dln_, G("attn.qkv.weight", (size_t)3 * D * D), G("attn.qkv.bias", 3 * D), acc, st));
-    TRY(launch_layernorm_backward(dln_, img_dt_, s.xin, b.g1, gx_, dg1, db1, M, D, 1e-6f, 1, st));
+    TRY(launch_layernorm_backward(dln_, img_dt_, s.xin, b.g1, gx_, dg1, db1, M, D, 1e-6f, 1, st, acc));
     return 0;
 }
 
