@@ -28,8 +28,14 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 GF_IMAGE = lambda K: 799.4 + 0.05898 * K        # image tower GF / image
-GF_TEXT = lambda K: 5.959 * K                   # CLIP text tower GF / forward call
+GF_TEXT = lambda K: 5.959 * K                   # CLIP text tower GF / forward call, the reference's 77-position schedule
 PEAK_BF16_TFLOPS = 2500.0                       # MI355X_MICROARCH.md dense bf16 MFMA peak
+
+
+def gf_text_executed(K, L, W=512, layers=12, out_c=512):
+    """FLOPs the engine actually spends in the text tower: the exact causal truncation computes L = max(EOT)+1 positions per
+    label instead of 77; per layer 24*L*W^2 (qkv, out, mlp) + 4*L^2*W (QK^T, PV), plus the projection."""
+    return K * (layers * (24.0 * L * W * W + 4.0 * L * L * W) + 2.0 * W * out_c) / 1e9
 
 
 def parse():
@@ -45,16 +51,19 @@ def parse():
     ap.add_argument("--size", type=int, default=480)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-samples", type=int, default=3, help="timed CPU-baseline forwards (each ~5 s)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the batch sweep and the training-step leg")
+    ap.add_argument("--train-batch", type=int, default=8, help="per-GPU batch of the training-step leg (BASELINE configs[3])")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = min(32, cores))")
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, sd, tok, size, threads):
+def cpu_baseline(cfg, sd, tok, size, threads, samples=3):
     """The CPU oracle (a port of the reference forward, oracle/lseg_oracle.py) timed on this
-    box's host cores.  BOUNDED sample: ONE B=1 forward of the same workload (fp32 image tower +
+    box's host cores.  BOUNDED sample: `samples` B=1 forwards of the same workload (fp32 image tower +
     fp16-emulated text tower recomputed, reference semantics), after a warm-up on the reduced
-    twin so library start-up is not timed.  torch CPU GEMMs stop scaling (and thrash) far below
-    the core count of a many-socket host, so the thread count is capped and reported as `cores`."""
+    twin so library start-up is not timed; the median is reported.  torch CPU GEMMs stop scaling (and
+    thrash) far below the core count of a many-socket host, so the thread count is capped and reported as `cores`."""
     from oracle.lseg_oracle import lseg_forward
     from lseg_hip.config import get_config
     from lseg_hip.synth import synthetic_images, synthetic_state_dict, synthetic_tokens
@@ -64,12 +73,59 @@ def cpu_baseline(cfg, sd, tok, size, threads):
         lseg_forward(synthetic_state_dict(tiny), synthetic_images(1, 64, 64),
                      synthetic_tokens(["a", "b"], tiny.text.vocab, tiny.text.ctx), tiny)
         x = synthetic_images(1, size, size, seed=0)
-        t0 = time.time()
-        lseg_forward(sd, x, tok, cfg)
-        dt = time.time() - t0
+        times = []
+        for _ in range(max(1, samples)):
+            t0 = time.time()
+            lseg_forward(sd, x, tok, cfg)
+            times.append(time.time() - t0)
+    dt = sorted(times)[len(times) // 2]
     return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"1 timed B=1 forward of the same workload (torch-CPU oracle, {threads} threads of "
-                      f"{os.cpu_count()} host cores, text tower recomputed), {dt:.2f} s"}
+            "sample": f"median of {len(times)} timed B=1 forwards of the same workload (torch-CPU oracle, {threads} threads of "
+                      f"{os.cpu_count()} host cores, text tower recomputed): " + ", ".join(f"{t:.2f}" for t in times) + " s"}
+
+
+def time_forward(eng, x, steps, warmup, sync):
+    for _ in range(warmup):
+        eng.forward(x)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.forward(x)
+    sync()
+    return (time.perf_counter() - t0) / steps
+
+
+def train_leg(cfg, sd, tok, size, B, rank, sync, D):
+    """BASELINE configs[3]: one data-parallel training step per GPU batch B -- train-mode forward, fused CE, backward with the
+    bucketed RCCL all-reduce overlapped, fused SGD (lseg_hip/train.py).  1 warm-up + 3 timed steps."""
+    from lseg_hip.engine import HipEngine
+    from lseg_hip.synth import synthetic_images
+    from lseg_hip.train import DataParallelTrainer
+    sd_dev = {k: v.cuda() for k, v in sd.items()}
+    eng = HipEngine(cfg, size, size, max_batch=B, max_labels=tok.shape[0])
+    eng.load_state_dict(sd_dev)
+    eng.set_tokens(tok)
+    tr = DataParallelTrainer(eng, sd_dev, sync_bn=True)
+    x = synthetic_images(B, size, size, seed=100 + rank).cuda()
+    g = torch.Generator().manual_seed(7 + rank)
+    t = torch.randint(0, tok.shape[0], (B, size, size), generator=g)
+    t[torch.rand(t.shape, generator=g) < 0.2] = -1
+    t = t.cuda()
+    base_lr = 0.004 / 16 * B                                    # lsegmentation_module.py:32, train.sh
+    loss = tr.step(x, t, base_lr, 10 * base_lr)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        loss = tr.step(x, t, base_lr, 10 * base_lr)
+    sync()
+    dt = D.max_over_ranks((time.perf_counter() - t0) / 3, device="cuda")
+    out = {"images_per_sec": round(tr.world * B / dt, 2), "ms_per_step": round(dt * 1e3, 2), "per_gpu_batch": B,
+           "loss": round(float(loss.item()), 4), "sync_bn": tr.sync_bn,
+           "what": "train-mode forward + CE + backward + bucketed gradient all-reduce (RCCL, overlapped) + fused SGD; bf16 MFMA "
+                   "operands, fp32 masters/gradients; synthetic images and masks",
+           "tflops_3x_forward_convention": round(tr.world * 3 * B * GF_IMAGE(tok.shape[0]) / dt / 1e3, 1)}
+    eng.close()
+    return out
 
 
 def main():
@@ -112,7 +168,7 @@ def main():
 
     for _ in range(args.warmup):
         out = eng.forward(x)
-    eng.set_profiling(True)
+    eng.set_profiling(True)                 # timing events are created here, outside the timed region
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -133,6 +189,19 @@ def main():
     if not selfcheck <= 1e-2:
         raise SystemExit(f"bench self-check failed: batch-of-{B} logits differ from the single-image run by {selfcheck}")
 
+    # extra legs, outside the headline's timed region: per-GPU batch sweep (config 3 runs 4 images per GPU) and the training step
+    sweep, train = None, None
+    if not args.no_sweep:
+        sweep = {}
+        for b in (1, 4, 8, 16):
+            if b >= B:
+                continue
+            tb = D.max_over_ranks(time_forward(eng, x[:b], 10 if b > 1 else 30, 3, sync), device="cuda")
+            sweep[str(b)] = round(world * b / tb, 1)
+        sweep[str(B)] = round(world * B * args.steps / dt, 1)
+        if args.backbone == "clip_vitl16_384" and args.dtype == "bf16":
+            train = train_leg(cfg, sd, tok, args.size, args.train_batch, rank, sync, D)
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         ips = world * B * args.steps / dt
@@ -140,7 +209,7 @@ def main():
         fwd = eng.profile("forward")
         roof = None
         traffic = None      # HBM-side bytes per launch from the PMC passes (tools/collect_profiles.sh), if recorded
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")      # written this round by tools/collect_profiles.sh
         if os.path.exists(tpath):
             t = json.load(open(tpath)).get("mlp_fc1_gemm", {})
             if t.get("batch") == B and args.backbone == "clip_vitl16_384":
@@ -156,8 +225,12 @@ def main():
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                     "avg_launch_ms": round(avg_ms, 5), "launches": fc1["launches"],
                     "flops_per_launch": fc1["flops_per_launch"]}
-        # whole-path figures (reference-algorithm FLOP convention)
-        gf_step = B * GF_IMAGE(K) + GF_TEXT(K)
+        # whole-path figures.  Two conventions, both labelled: EXECUTED = the FLOPs the engine spends (text tower
+        # truncated to max(EOT)+1 positions: exact); REFERENCE-ALGORITHM = what the reference's schedule would spend
+        # on the same inputs (77 text positions).  Roofline fractions use the executed count only.
+        L_exec = int(tok.argmax(dim=-1).max().item()) + 1
+        gf_step = B * GF_IMAGE(K) + gf_text_executed(K, L_exec)
+        gf_step_ref = B * GF_IMAGE(K) + GF_TEXT(K)
         line = {
             "metric": "images/sec at 480x480, ViT-L/16 + 150 ADE20K labels",
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
@@ -169,13 +242,18 @@ def main():
                        "parallelism": f"dp{world} (batch sharded, no collectives)"},
             "path_tflops": round(world * gf_step / (ms * 1e-3) / 1e3, 2),
             "path_frac_of_mfma_peak": round(gf_step / (ms * 1e-3) / 1e3 / PEAK_BF16_TFLOPS, 4),
+            "path_flops_convention": f"executed FLOPs: image tower {GF_IMAGE(K):.1f} GF/image + text tower at {L_exec} of 77 positions "
+                                     f"({gf_text_executed(K, L_exec):.1f} GF/call)",
+            "path_tflops_reference_algorithm": round(world * gf_step_ref / (ms * 1e-3) / 1e3, 2),
+            "batch_sweep_images_per_sec": sweep,
+            "train_step": train,
             "engine_forward_ms_hip_events": round(fwd["total_ms"] / max(1, fwd["launches"]), 4),
             "roofline": roof,
             "selfcheck_batch_vs_single_max_abs": round(selfcheck, 6),
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or min(32, os.cpu_count() or 1)
-            line["cpu_baseline"] = cpu_baseline(cfg, sd, tok, args.size, threads)
+            line["cpu_baseline"] = cpu_baseline(cfg, sd, tok, args.size, threads, args.cpu_samples)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -192,13 +192,11 @@ int launch_attention_backward(const void* q, const void* k, const void* vt, cons
     a.B = B; a.H = H; a.ntok = ntok; a.npad = npad; a.causal = causal; a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
     const size_t lds = 10 * sizeof(Tile) + 2 * 64 * sizeof(float);
     dim3 grid((ntok + 63) / 64, B * H);
-    if (dtype == DT_BF16) {
-        static bool done = false;
-        if (!done) { LSEG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lseg_attention_bwd_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+    if (dtype == DT_BF16) {          // the dynamic-LDS opt-in is per device: set it on every launch (microseconds; correctness-first kernel)
+        LSEG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lseg_attention_bwd_kernel<BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(lseg_attention_bwd_kernel<BF16>, grid, dim3(256), lds, stream, a);
     } else if (dtype == DT_F16) {
-        static bool done = false;
-        if (!done) { LSEG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lseg_attention_bwd_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); done = true; }
+        LSEG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lseg_attention_bwd_kernel<F16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(lseg_attention_bwd_kernel<F16>, grid, dim3(256), lds, stream, a);
     } else {
         return set_error(LSEG_ERR_INVALID, "attention backward: dtype %d", dtype);

@@ -95,7 +95,12 @@ int lseg_get_intermediate(lseg_handle h, const char* name, float* dev_out, size_
     return h->e->get_intermediate(name, dev_out, cap, n, (hipStream_t)stream);
 }
 
-int lseg_set_profiling(lseg_handle h, int enabled) { GUARD(h); h->e->profiling = enabled != 0; return LSEG_OK; }
+int lseg_set_profiling(lseg_handle h, int enabled) {
+    GUARD(h);
+    h->e->profiling = enabled != 0;
+    if (enabled) return h->e->reserve_events(2 * (h->e->cfg.depth + 1) * 64);     // events for 64 forwards, created outside any timed loop
+    return LSEG_OK;
+}
 int lseg_get_profile(lseg_handle h, const char* family, double* total_ms, int64_t* launches, double* flops) {
     GUARD(h);
     if (!family) return set_error(LSEG_ERR_INVALID, "family NULL");

@@ -439,7 +439,7 @@ template <int MAXV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ dy, int dy_dtype, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, float* __restrict__ dx,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int M, int D, float eps, int accumulate) {
+                                                            int M, int D, float eps, int accumulate, float* __restrict__ partial) {
     const int lane = threadIdx.x & 63;
     const int nv = D >> 2;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
@@ -507,6 +507,27 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
                 *o = r;
             }
         }
+    }
+    // parameter gradients: with a workspace, the four waves of the block are summed through LDS and every block writes ONE
+    // partial row [2D] (reduced by colreduce_kernel: deterministic, no atomics); without, fp32 atomics (a few thousand waves
+    // hammering 2D addresses: 0.5 ms at M = 7208, D = 1024 -- 25x the streaming time)
+    if (partial) {
+        __shared__ float red[4][2][64 * 4 * MAXV > 1024 ? 1024 : 64 * 4 * MAXV];
+        const int w = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int g = lane + 64 * i;
+            if (g < nv) {
+                reinterpret_cast<float4*>(red[w][0])[g] = dg[i];
+                reinterpret_cast<float4*>(red[w][1])[g] = db[i];
+            }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < D; c += 256) {
+            partial[(size_t)blockIdx.x * 2 * D + c] = (red[0][0][c] + red[1][0][c]) + (red[2][0][c] + red[3][0][c]);
+            partial[(size_t)blockIdx.x * 2 * D + D + c] = (red[0][1][c] + red[1][1][c]) + (red[2][1][c] + red[3][1][c]);
+        }
+        return;
     }
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
@@ -807,16 +828,46 @@ __global__ __launch_bounds__(256) void l2norm_scale_bwd_kernel(const uint16_t* _
         }
     }
 }
-// out[c] += sum_r in[r, c] (bias gradient); out must be zeroed; fp32 atomics across row chunks
-__global__ void colsum16_kernel(const uint16_t* __restrict__ in, int dtype, float* __restrict__ out, int R, int C, int ld,
-                                int rows_per_block) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// out[c] += sum_r in[r, c] (bias gradient); out must be zeroed; fp32 atomics across row chunks.
+// A block = 32 column groups of 8 columns (16-byte loads) x 8 row lanes; the row lanes are summed through LDS.
+__global__ __launch_bounds__(256) void colsum16_kernel(const uint16_t* __restrict__ in, int dtype, float* __restrict__ out, int R, int C,
+                                                       int ld, int rows_per_block) {
+    __shared__ float red[8][32][8];
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c0 = (blockIdx.x * 32 + cg) * 8;
     const int r0 = blockIdx.y * rows_per_block;
     const int r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c0 + 8 <= C) {
+        for (int r = r0 + rl; r < r1; r += 8) {
+            const uint4 u = *reinterpret_cast<const uint4*>(in + (size_t)r * ld + c0);
+            const uint16_t* e = reinterpret_cast<const uint16_t*>(&u);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += load_as_f32(e, k, dtype);
+        }
+    } else if (c0 < C) {
+        for (int r = r0 + rl; r < r1; r += 8)
+            for (int k = 0; k < 8 && c0 + k < C; ++k) s[k] += load_as_f32(in, (size_t)r * ld + c0 + k, dtype);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[rl][cg][k] = s[k];
+    __syncthreads();
+    const int k = threadIdx.x & 7, g = threadIdx.x >> 3;        // 256 threads = 32 groups x 8 columns
+    const int c = (blockIdx.x * 32 + g) * 8 + k;
+    if (c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t += red[q][g][k];
+        atomicAdd(&out[c], t);
+    }
+}
+// dst[c] (+)= sum over the nb partial rows of src [nb, ld] (fixed order: deterministic)
+__global__ void colreduce_kernel(const float* __restrict__ src, float* __restrict__ dst, int nb, int C, int ld, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
     float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += load_as_f32(in, (size_t)r * ld + c, dtype);
-    atomicAdd(&out[c], s);
+    for (int r = 0; r < nb; ++r) s += src[(size_t)r * ld + c];
+    dst[c] = accumulate ? dst[c] + s : s;
 }
 
 // ---- segmentation statistics on device -------------------------------------------------------------------------------
@@ -1194,18 +1245,28 @@ int launch_argmax_planes(const float* in, uint8_t* out, int B, int K, int HW, hi
 }
 
 int launch_layernorm_backward(const void* dy, int dy_dtype, const float* x, const float* gamma, float* dx, float* dgamma,
-                              float* dbeta, int M, int D, float eps, int accumulate, hipStream_t st, int accumulate_params) {
+                              float* dbeta, int M, int D, float eps, int accumulate, hipStream_t st, int accumulate_params,
+                              float* partial_ws) {
     if (D % 4 != 0 || D > 64 * 4 * 4) return set_error(LSEG_ERR_UNSUPPORTED, "layernorm backward: D=%d", D);
-    if (!accumulate_params) {
-        LSEG_HIP_TRY(hipMemsetAsync(dgamma, 0, (size_t)D * sizeof(float), st));
-        LSEG_HIP_TRY(hipMemsetAsync(dbeta, 0, (size_t)D * sizeof(float), st));
-    }
     int blocks = (M + 3) / 4;
-    if (blocks > 1024) blocks = 1024;
-#define LN_BWD(V) hipLaunchKernelGGL(layernorm_bwd_kernel<V>, dim3(blocks), dim3(256), 0, st, dy, dy_dtype, x, gamma, dx, dgamma, dbeta, M, D, eps, accumulate)
+    if (partial_ws) {
+        if (blocks > LN_BWD_PARTIAL_BLOCKS) blocks = LN_BWD_PARTIAL_BLOCKS;
+    } else {
+        if (blocks > 1024) blocks = 1024;
+        if (!accumulate_params) {
+            LSEG_HIP_TRY(hipMemsetAsync(dgamma, 0, (size_t)D * sizeof(float), st));
+            LSEG_HIP_TRY(hipMemsetAsync(dbeta, 0, (size_t)D * sizeof(float), st));
+        }
+    }
+#define LN_BWD(V) hipLaunchKernelGGL(layernorm_bwd_kernel<V>, dim3(blocks), dim3(256), 0, st, dy, dy_dtype, x, gamma, dx, dgamma, dbeta, M, D, eps, accumulate, partial_ws)
     if (D <= 256) LN_BWD(1); else if (D <= 512) LN_BWD(2); else LN_BWD(4);
 #undef LN_BWD
     CHECK_LAUNCH();
+    if (partial_ws) {
+        hipLaunchKernelGGL(colreduce_kernel, dim3((D + 255) / 256), dim3(256), 0, st, partial_ws, dgamma, blocks, D, 2 * D, accumulate_params);
+        hipLaunchKernelGGL(colreduce_kernel, dim3((D + 255) / 256), dim3(256), 0, st, partial_ws + D, dbeta, blocks, D, 2 * D, accumulate_params);
+        CHECK_LAUNCH();
+    }
     return 0;
 }
 
@@ -1321,7 +1382,7 @@ int launch_l2norm_scale_backward(const void* da, int da_dtype, const float* x, v
 }
 int launch_colsum16(const void* in, int dtype, float* out, int R, int C, int ld, hipStream_t st, int accumulate) {
     if (!accumulate) LSEG_HIP_TRY(hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st));
-    const int rpb = 256;
+    const int rpb = R >= 65536 ? 2048 : 256;
     dim3 grid((C + 255) / 256, (R + rpb - 1) / rpb);
     hipLaunchKernelGGL(colsum16_kernel, grid, dim3(256), 0, st, (const uint16_t*)in, dtype, out, R, C, ld, rpb);
     CHECK_LAUNCH();

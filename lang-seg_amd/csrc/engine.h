@@ -166,7 +166,7 @@ private:
     uint16_t *ws_a_ = nullptr, *ws_b_ = nullptr;    // transposed operands of the wgrad GEMMs
     size_t ws_a_n_ = 0, ws_b_n_ = 0;
     float* ws_dw_ = nullptr; size_t ws_dw_n_ = 0;   // wgrad output in the engine's packed layout before the re-layout into the parameter's
-    float *ws_stats_ = nullptr, *zeros_ = nullptr;
+    float *ws_stats_ = nullptr, *zeros_ = nullptr, *ws_ln_ = nullptr;
     float *gx_ = nullptr, *dq_ = nullptr, *dk_ = nullptr, *dv_ = nullptr, *dpos_ = nullptr, *logits_ = nullptr, *dlogits_ = nullptr;
     uint16_t *g16_ = nullptr, *dmlp_ = nullptr, *dln_ = nullptr, *datt_ = nullptr, *dqkv_ = nullptr, *dtok_ = nullptr;
     uint16_t *drows_ = nullptr, *da_ = nullptr, *df_ = nullptr, *tnT_ = nullptr;
@@ -178,13 +178,17 @@ private:
 
     // ---- side stream: the (small, latency-bound) text tower overlaps the image tower ----------------
     hipStream_t text_stream_ = nullptr;
-    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr, ev_text_done_ = nullptr;
+    bool text_pending_ = false;
 
     // ---- profiling ---------------------------------------------------------------------------------
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_fc1_, ev_fwd_;
-    std::vector<hipEvent_t> ev_pool_;
+    std::vector<hipEvent_t> ev_pool_, ev_free_;
     ProfileSlot prof_fc1_, prof_fwd_;
     hipEvent_t get_event();
+public:
+    int reserve_events(int n);
+private:
 };
 
 }  // namespace lseg

@@ -45,6 +45,8 @@ Engine::~Engine() {
     if (text_stream_) (void)hipStreamDestroy(text_stream_);
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
+    if (ev_text_done_) (void)hipEventDestroy(ev_text_done_);
+    for (auto e : ev_free_) (void)hipEventDestroy(e);
     for (void* p : allocs_) (void)hipFree(p);
     for (auto e : ev_pool_) (void)hipEventDestroy(e);
 }
@@ -148,6 +150,7 @@ int Engine::init() {
     LSEG_HIP_TRY(hipStreamCreateWithFlags(&text_stream_, hipStreamNonBlocking));
     LSEG_HIP_TRY(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
     LSEG_HIP_TRY(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+    LSEG_HIP_TRY(hipEventCreateWithFlags(&ev_text_done_, hipEventDisableTiming));
     LSEG_HIP_TRY(hipDeviceSynchronize());
     inited_ = true;
     return 0;
@@ -346,6 +349,9 @@ int Engine::set_tokens(const int64_t* tok, int K, int ctx) {
         }
         eot[k] = best;
     }
+    // The text-tower kernels that read d_tok_ / d_eot_ run asynchronously (engine side stream, or the caller's stream): wait for
+    // the last encode_text to finish before overwriting them, otherwise forward N could embed / pool with forward N+1's tokens.
+    if (text_pending_) { LSEG_HIP_TRY(hipEventSynchronize(ev_text_done_)); text_pending_ = false; }
     LSEG_HIP_TRY(hipMemcpy(d_tok_, tok, (size_t)K * ctx * sizeof(int64_t), hipMemcpyHostToDevice));
     LSEG_HIP_TRY(hipMemcpy(d_eot_, eot.data(), (size_t)K * sizeof(int), hipMemcpyHostToDevice));
     K_ = K;
@@ -401,6 +407,8 @@ int Engine::encode_text(hipStream_t st) {
     g.C = tfeat_; g.out_dtype = DT_F16; g.ldc = c.out_c; g.map_mode = MAP_LINEAR;
     TRY(launch_gemm(g, DT_F16, st));
     TRY(launch_text_l2norm(tfeat_, tnorm_, K_, c.out_c, st));
+    LSEG_HIP_TRY(hipEventRecord(ev_text_done_, st));
+    text_pending_ = true;
     text_valid = true;
     return 0;
 }
@@ -444,11 +452,22 @@ int Engine::refine(int r, int B, hipStream_t st) {
     return launch_gemm(g, img_dt_, st);
 }
 
+// timing events come from a free list filled outside the timed region (lseg_set_profiling / flush): no hipEventCreate per forward
 hipEvent_t Engine::get_event() {
     hipEvent_t e;
-    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    if (!ev_free_.empty()) { e = ev_free_.back(); ev_free_.pop_back(); }
+    else if (hipEventCreate(&e) != hipSuccess) return nullptr;
     ev_pool_.push_back(e);
     return e;
+}
+
+int Engine::reserve_events(int n) {
+    while ((int)ev_free_.size() < n) {
+        hipEvent_t e;
+        LSEG_HIP_TRY(hipEventCreate(&e));
+        ev_free_.push_back(e);
+    }
+    return 0;
 }
 
 int Engine::flush_events() {
@@ -464,7 +483,7 @@ int Engine::flush_events() {
     };
     TRY(drain(ev_fc1_, prof_fc1_));
     TRY(drain(ev_fwd_, prof_fwd_));
-    for (auto e : ev_pool_) (void)hipEventDestroy(e);
+    for (auto e : ev_pool_) ev_free_.push_back(e);       // recycled, not destroyed
     ev_pool_.clear();
     return 0;
 }

@@ -53,6 +53,7 @@ struct GemmArgs {
 };
 
 void gemm_args_init(GemmArgs& g);
+int device_cu_count(int dev);
 // ab_dtype: DT_BF16 | DT_F16.  Returns 0 or a negative lseg_status.
 int launch_gemm(const GemmArgs& g, int ab_dtype, hipStream_t stream);
 

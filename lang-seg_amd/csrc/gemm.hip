@@ -16,6 +16,7 @@
 // The MFMA is issued "swapped" (weights as the row operand) so each lane ends up with 4 consecutive output
 // channels of one row -> 8/16-byte epilogue stores and float4 bias/residual loads.  DESIGN.md §3.1 has the
 // measurements behind each of these choices.
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -23,6 +24,18 @@
 #include "../../include/lseg_hip.h"
 
 namespace lseg {
+
+// compute units of a device (cached per device id; 256 on MI355X): sizes the persistent grids
+int device_cu_count(int dev) {
+    static std::atomic<int> cache[64];
+    const int slot = dev & 63;
+    int v = cache[slot].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    hipDeviceProp_t prop;
+    v = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    cache[slot].store(v, std::memory_order_relaxed);
+    return v;
+}
 
 void gemm_args_init(GemmArgs& g) {
     g = GemmArgs{};
@@ -929,15 +942,20 @@ int launch_one(const GemmArgs& g, hipStream_t stream) {
     // persistent grid: a multiple of 8 (one slice per XCD), at most `slots` resident workgroups
     constexpr int by_lds = 163840 / CFG::LDS, by_waves = 8 / (CFG::NW / 4);
     constexpr int per_cu = by_lds < by_waves ? (by_lds < 1 ? 1 : by_lds) : by_waves;
-    const int slots = 256 * per_cu;
+    int dev = 0;
+    LSEG_HIP_TRY(hipGetDevice(&dev));
+    const int slots = device_cu_count(dev) * per_cu;
     int grid = ((tiles + 7) / 8) * 8;
     if (grid > slots) grid = slots;
     auto kern = lseg_gemm_kernel<T, CFG, CONV, RELU_IN, EPI, TAG>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    // the dynamic-LDS opt-in is a per-DEVICE function attribute: one bit per device (a process may drive several GPUs, one
+    // engine and one host thread each: additional_utils/models.py:229-238), set with an atomic so concurrent threads are safe
+    static std::atomic<unsigned long long> attr_done{0};
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_done.load(std::memory_order_acquire) & bit)) {
         LSEG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_done = true;
+        attr_done.fetch_or(bit, std::memory_order_release);
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(CFG::THREADS), lds, stream, g);
     LSEG_HIP_TRY(hipGetLastError());

@@ -33,7 +33,9 @@ int launch_head_block(const float* in, float* out, const float* w9, const float*
                       int bottleneck, int act, int apply_act, hipStream_t st);
 int launch_argmax_planes(const float* in, uint8_t* out, int B, int K, int HW, hipStream_t st);
 int launch_layernorm_backward(const void* dy, int dy_dtype, const float* x, const float* gamma, float* dx, float* dgamma,
-                              float* dbeta, int M, int D, float eps, int accumulate, hipStream_t st, int accumulate_params = 0);
+                              float* dbeta, int M, int D, float eps, int accumulate, hipStream_t st, int accumulate_params = 0,
+                              float* partial_ws = nullptr);      // partial_ws: [LN_BWD_PARTIAL_BLOCKS, 2D] floats -> no atomics
+constexpr int LN_BWD_PARTIAL_BLOCKS = 256;
 int launch_transpose16(const void* in, void* out, int R, int C, int ldi, int ldo, hipStream_t st, int shift = 0, int relu = 0);
 int launch_attention_backward(const void* q, const void* k, const void* vt, const void* o, const void* d_o, const float* lse2,
                               float* dq, float* dk, float* dv, int B, int H, int ntok, int npad, int dtype, int causal, float scale,

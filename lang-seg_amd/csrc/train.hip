@@ -151,6 +151,7 @@ int Engine::train_alloc() {
     TALLOC(ws_a_, uint16_t, wsa); TALLOC(ws_b_, uint16_t, wsb); TALLOC(ws_dw_, float, wdw);
     TALLOC(ws_stats_, float, 2 * std::max<size_t>(F, 16 * 1024));
     TALLOC(zeros_, float, 16 * 1024);
+    TALLOC(ws_ln_, float, (size_t)LN_BWD_PARTIAL_BLOCKS * 2 * D);
     TALLOC(gx_, float, M * D); TALLOC(dpos_, float, (size_t)ntok_ * D);
     TALLOC(dq_, float, B * H * npad_ * 64); TALLOC(dk_, float, B * H * npad_ * 64); TALLOC(dv_, float, B * H * npad_ * 64);
     TALLOC(g16_, uint16_t, M * D); TALLOC(dmlp_, uint16_t, M * 4 * D); TALLOC(dln_, uint16_t, M * D); TALLOC(datt_, uint16_t, M * D);
@@ -516,7 +517,7 @@ int Engine::block_backward(int i, int B, int acc, hipStream_t st) {
     TRY(lin_bwd(g16_, M, D, 4 * D, s.mlp, b.fc2.wt, dmlp_, G("mlp.fc2.weight", (size_t)D * 4 * D), G("mlp.fc2.bias", D), acc, st));
     TRY(launch_gelu_backward(dmlp_, s.pre, dmlp_, (size_t)M * 4 * D, img_dt_, st));
     TRY(lin_bwd(dmlp_, M, 4 * D, D, s.ln2, b.fc1.wt, dln_, G("mlp.fc1.weight", (size_t)4 * D * D), G("mlp.fc1.bias", 4 * D), acc, st));
-    TRY(launch_layernorm_backward(dln_, img_dt_, s.xmid, b.g2, gx_, dg2, db2, M, D, 1e-6f, 1, st, acc));
+    TRY(launch_layernorm_backward(dln_, img_dt_, s.xmid, b.g2, gx_, dg2, db2, M, D, 1e-6f, 1, st, acc, ws_ln_));
     // x_mid = x_in + proj(attention(qkv(LN1(x_in))))
     TRY(launch_convert(gx_, DT_F32, g16_, img_dt_, (size_t)M * D, st));
     TRY(lin_bwd(g16_, M, D, D, s.att, b.proj.wt, datt_, G("attn.proj.weight", (size_t)D * D), G("attn.proj.bias", D), acc, st));
@@ -524,7 +525,7 @@ int Engine::block_backward(int i, int B, int acc, hipStream_t st) {
     TRY(launch_attention_backward(s.q, s.k, s.vt, s.att, datt_, s.lse, dq_, dk_, dv_, B, H, ntok_, npad_, img_dt_, 0, 0.125f, st));
     TRY(launch_qkv_grad_pack(dq_, dk_, dv_, dqkv_, B, H, ntok_, npad_, img_dt_, st));
     TRY(lin_bwd(dqkv_, M, 3 * D, D, s.ln1, b.qkv.wt, dln_, G("attn.qkv.weight", (size_t)3 * D * D), G("attn.qkv.bias", 3 * D), acc, st));
-    TRY(launch_layernorm_backward(dln_, img_dt_, s.xin, b.g1, gx_, dg1, db1, M, D, 1e-6f, 1, st, acc));
+    TRY(launch_layernorm_backward(dln_, img_dt_, s.xin, b.g1, gx_, dg1, db1, M, D, 1e-6f, 1, st, acc, ws_ln_));
     return 0;
 }
 

@@ -8,6 +8,7 @@ a GPU the forward raises.
 """
 import math
 import warnings
+from collections import OrderedDict
 
 import numpy as np
 import torch
@@ -96,8 +97,8 @@ class LSeg(BaseModel):
             self.scratch.head_block = depthwise_block(activation=act)
         self.scratch.output_conv = head
         self.text = tokenize(self.labels, self.cfg.text.ctx, self.cfg.text.vocab)     # lseg_net.py:158
-        self._engines = {}
-        self._param_stamp = None
+        self._engines = OrderedDict()            # (H, W, device index) -> HipEngine, least recently used first
+        self.max_engines = kwargs.get("max_engines", 4)
         self.image_dtype = kwargs.get("image_dtype", "bf16")
         self.cache_text = kwargs.get("cache_text", False)
 
@@ -107,9 +108,19 @@ class LSeg(BaseModel):
                      if isinstance(p, torch.Tensor))
 
     def _engine(self, B, H, W, K, device):
+        """One engine per (image size, device): each holds its own packed weights + activation plan (~1 GB for ViT-L/16).  The
+        cache is bounded (callers with varying image sizes: lseg_app, `evaluate` on uncropped images): the least recently used
+        engine of THIS device is closed when more than `max_engines` exist.  Replicas made by DataParallel.replicate
+        (additional_utils/encoding_models.py:43) share this dict object; the device index in the key keeps their engines apart."""
         from lseg_hip.engine import HipEngine
         key = (H, W, device.index)
         eng = self._engines.get(key)
+        if eng is not None:
+            self._engines.move_to_end(key)
+        else:
+            mine = [k for k in self._engines if k[2] == device.index]
+            while len(mine) >= max(1, self.max_engines):
+                self._engines.pop(mine.pop(0)).close()
         if eng is None or eng.max_batch < B or eng.max_labels < K:
             if eng is not None:
                 eng.close()

@@ -171,3 +171,42 @@ def test_zero_shot_module_surface(repo_root):
         m(torch.zeros(1, 3, 64, 64), [0])
     with pytest.raises(NotImplementedError):
         LSegRNNetZS()
+
+
+def test_engine_cache_is_bounded_and_keeps_replicas_on_their_own_device(monkeypatch):
+    """LSegNet keeps one engine per (image size, device).  (i) callers with varying image sizes (lseg_app, plain `evaluate`) must
+    not grow device memory without bound: least-recently-used engines of a device are closed; (ii) the reference's evaluator fans
+    out with DataParallel.replicate + one thread per GPU (additional_utils/encoding_models.py:43, models.py:229-238): replicas are
+    shallow copies sharing this cache, so the device index is part of the key and every device gets its own engine."""
+    import copy
+    import lseg_hip.engine as E
+    from modules.models.lseg_net import LSegNet
+    made, closed = [], []
+
+    class FakeEngine:
+        def __init__(self, cfg, H, W, max_batch, max_labels, device=None, image_dtype="bf16"):
+            self.key = (H, W, device.index)
+            self.max_batch, self.max_labels, self.training = max_batch, max_labels, False
+            made.append(self.key)
+
+        def load_state_dict(self, sd):
+            pass
+
+        def close(self):
+            closed.append(self.key)
+
+    monkeypatch.setattr(E, "HipEngine", FakeEngine)
+    warnings.simplefilter("ignore")
+    net = LSegNet(labels=["a", "b"], backbone="tiny16", features=64, arch_option=0, block_depth=0, activation="lrelu", max_engines=2)
+    d0, d1 = torch.device("cuda", 0), torch.device("cuda", 1)
+    e_a = net._engine(1, 64, 64, 2, d0)
+    assert net._engine(1, 64, 64, 2, d0) is e_a and made == [(64, 64, 0)]
+    net._engine(1, 96, 64, 2, d0)
+    net._engine(1, 64, 64, 2, d0)                       # touch: (96, 64) is now the least recently used
+    net._engine(1, 128, 128, 2, d0)                     # third size on device 0 -> evicts (96, 64)
+    assert closed == [(96, 64, 0)] and len([k for k in net._engines if k[2] == 0]) == 2
+    replica = copy.copy(net)                            # what replicate() does to the module object
+    e_b = replica._engine(1, 64, 64, 2, d1)
+    assert e_b is not e_a and e_b.key == (64, 64, 1)
+    assert net._engine(1, 64, 64, 2, d0) is e_a         # device 1's engines never evict device 0's
+    assert closed == [(96, 64, 0)]
