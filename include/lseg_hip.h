@@ -43,7 +43,9 @@ typedef enum {
     LSEG_ERR_MISSING_PARAM = -6
 } lseg_status;
 
-typedef enum { LSEG_F32 = 0, LSEG_F16 = 1, LSEG_BF16 = 2, LSEG_I64 = 3 } lseg_dtype;
+typedef enum { LSEG_F32 = 0, LSEG_F16 = 1, LSEG_BF16 = 2, LSEG_I64 = 3,
+               LSEG_F16_SPLIT = 4   /* lseg_config.image_dtype only: split-precision validation mode, see below */
+} lseg_dtype;
 
 /* Resample op that follows the 1x1 conv of act_postprocessK
  * (modules/models/lseg_vit.py:446-523 / 315-396). */
@@ -76,7 +78,10 @@ typedef struct {
     int32_t img_h, img_w;     /* input size, multiples of patch (and such that the reassemble pyramid is a x2 ladder) */
     int32_t max_batch;        /* workspace is sized for this many images per call */
     int32_t max_labels;       /* workspace is sized for this many labels (K) */
-    int32_t image_dtype;      /* LSEG_BF16 (default) or LSEG_F16: MFMA operand type of the image tower */
+    int32_t image_dtype;      /* MFMA operand type of the image tower: LSEG_BF16 (default), LSEG_F16, or LSEG_F16_SPLIT = every
+                               * 16-bit operand as a (hi, lo) fp16 pair, three MFMA products per K-step (~21 mantissa bits: the
+                               * reference's tower is fp32).  ~1/4 of the bf16 rate; a validation mode: its masks equal the
+                               * reference's except at fp16-ulp ties of the reference's own fp16 logits.  Inference only. */
     int32_t flags;            /* bit 0: run the text tower on all text_ctx positions (reference schedule)
                                * instead of the exact causal truncation to max(EOT)+1 positions */
 } lseg_config;

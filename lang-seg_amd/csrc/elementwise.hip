@@ -330,7 +330,7 @@ __global__ void transpose_convert_kernel(const void* in, int in_dtype, void* out
 // conv3x3 weight [Co,Ci,3,3] (+ eval BatchNorm fold) -> [Co, 9*Ci] tap-major; bias_out = beta - mean*s
 // (ResidualConvUnit_custom conv+bn pairs, lseg_blocks.py:276-283)
 __global__ void pack_conv3x3_kernel(const float* w, const float* bn_w, const float* bn_b, const float* bn_m,
-                                    const float* bn_v, float bn_eps, const float* conv_bias, uint16_t* wp,
+                                    const float* bn_v, float bn_eps, const float* conv_bias, void* wp,
                                     float* bias_out, int Co, int Ci, int Cip, int dtype) {
     const size_t n = (size_t)Co * 9 * Ci;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -339,7 +339,7 @@ __global__ void pack_conv3x3_kernel(const float* w, const float* bn_w, const flo
         const int co = (int)(i / ((size_t)9 * Ci));
         const float s = bn_w ? bn_w[co] * rsqrtf(bn_v[co] + bn_eps) : 1.f;
         const float v = w[((size_t)co * Ci + ci) * 9 + tap] * s;
-        wp[((size_t)co * 9 + tap) * Cip + ci] = dtype == DT_F16 ? f32_to_f16(v) : f32_to_bf16(v);   // Cip >= Ci: zero-padded K
+        store_from_f32(wp, ((size_t)co * 9 + tap) * Cip + ci, dtype, v);   // Cip >= Ci: zero-padded K
         if (ci == 0 && tap == 0 && bias_out) {
             float b = conv_bias ? conv_bias[co] * s : 0.f;
             if (bn_w) b += bn_b[co] - bn_m[co] * s;
@@ -348,7 +348,7 @@ __global__ void pack_conv3x3_kernel(const float* w, const float* bn_w, const flo
     }
 }
 // ConvTranspose2d(k = s) weight [Ci, Co, s, s] -> GEMM weight [(i*s + j)*Co + co, Ci]
-__global__ void pack_convT_kernel(const float* w, uint16_t* wp, int Ci, int Co, int Cp, int s, int dtype) {
+__global__ void pack_convT_kernel(const float* w, void* wp, int Ci, int Co, int Cp, int s, int dtype) {
     const size_t n = (size_t)s * s * Co * Ci;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < n; idx += (size_t)gridDim.x * blockDim.x) {
         const int ci = (int)(idx % Ci);
@@ -357,12 +357,12 @@ __global__ void pack_convT_kernel(const float* w, uint16_t* wp, int Ci, int Co, 
         const int ij = (int)(row / Co);
         const int i = ij / s, j = ij - i * s;
         const float v = w[(((size_t)ci * Co + co) * s + i) * s + j];
-        wp[((size_t)ij * Cp + co) * Cp + ci] = dtype == DT_F16 ? f32_to_f16(v) : f32_to_bf16(v);   // [(ij*Cp+co), Cp], zero-padded
+        store_from_f32(wp, ((size_t)ij * Cp + co) * Cp + ci, dtype, v);   // [(ij*Cp+co), Cp], zero-padded
     }
 }
 
 // ---- test taps: NHWC 16-bit (optionally padded) -> NCHW fp32 -------------------------------------------------
-__global__ void nhwc_to_nchw_f32_kernel(const uint16_t* in, float* out, int B, int H, int W, int C, int Cs, int pad, int dtype) {
+__global__ void nhwc_to_nchw_f32_kernel(const uint16_t* in, float* out, int B, int H, int W, int C, int Cs, int pad, int dtype, size_t lo_plane) {
     const size_t n = (size_t)B * C * H * W;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(i % W);
@@ -370,7 +370,7 @@ __global__ void nhwc_to_nchw_f32_kernel(const uint16_t* in, float* out, int B, i
         const int c = (int)((i / ((size_t)W * H)) % C);
         const int b = (int)(i / ((size_t)W * H * C));
         const size_t src = (((size_t)b * (H + 2 * pad) + y + pad) * (W + 2 * pad) + x + pad) * Cs + c;   // Cs = channel stride
-        out[i] = load_as_f32(in, src, dtype);
+        out[i] = load_as_f32(in, src, dtype) + (lo_plane ? load_as_f32(in, src + lo_plane, dtype) : 0.f);
     }
 }
 // fp32 [M, C] rows (pixel-major) -> NCHW fp32
@@ -1213,17 +1213,17 @@ int launch_pack_conv3x3(const float* w, const float* bn_w, const float* bn_b, co
                         float bn_eps, const float* conv_bias, void* wp, float* bias_out, int Co, int Ci, int Cip, int dtype,
                         hipStream_t st) {
     hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(grid_for((size_t)Co * 9 * Ci)), dim3(256), 0, st, w, bn_w, bn_b, bn_m, bn_v,
-                       bn_eps, conv_bias, (uint16_t*)wp, bias_out, Co, Ci, Cip, dtype);
+                       bn_eps, conv_bias, wp, bias_out, Co, Ci, Cip, dtype);
     CHECK_LAUNCH();
     return 0;
 }
 int launch_pack_convT(const float* w, void* wp, int Ci, int Co, int Cp, int s, int dtype, hipStream_t st) {
-    hipLaunchKernelGGL(pack_convT_kernel, dim3(grid_for((size_t)s * s * Co * Ci)), dim3(256), 0, st, w, (uint16_t*)wp, Ci, Co, Cp, s, dtype);
+    hipLaunchKernelGGL(pack_convT_kernel, dim3(grid_for((size_t)s * s * Co * Ci)), dim3(256), 0, st, w, wp, Ci, Co, Cp, s, dtype);
     CHECK_LAUNCH();
     return 0;
 }
-int launch_nhwc_to_nchw_f32(const void* in, float* out, int B, int H, int W, int C, int Cs, int pad, int dtype, hipStream_t st) {
-    hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3(grid_for((size_t)B * C * H * W)), dim3(256), 0, st, (const uint16_t*)in, out, B, H, W, C, Cs, pad, dtype);
+int launch_nhwc_to_nchw_f32(const void* in, float* out, int B, int H, int W, int C, int Cs, int pad, int dtype, hipStream_t st, size_t lo_plane) {
+    hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3(grid_for((size_t)B * C * H * W)), dim3(256), 0, st, (const uint16_t*)in, out, B, H, W, C, Cs, pad, dtype, lo_plane);
     CHECK_LAUNCH();
     return 0;
 }

@@ -79,7 +79,7 @@ public:
 private:
     void* dalloc(size_t bytes, bool zero = true);
     int need(const std::string& key, BoundParam& out, std::initializer_list<int64_t> shape);
-    int pack_linear(const std::string& wkey, const std::string& bkey, int n, int k, int dt, Lin& out, hipStream_t st);
+    int pack_linear(const std::string& wkey, const std::string& bkey, int n, int k, int dt, Lin& out, hipStream_t st, bool image = false);
     int pack_f32(const std::string& key, size_t n, float*& out, hipStream_t st);
     int pack_conv3(const std::string& wkey, const std::string& bn_prefix, const std::string& bias_key, int co, int ci,
                    int cop, int cip, Lin& out, hipStream_t st);
@@ -112,6 +112,13 @@ private:
 
     // derived geometry
     int gh_, gw_, np_, ntok_, npad_, img_dt_;
+    bool strict_ = false;                       // split-precision mode (lseg_config.image_dtype == LSEG_F16_SPLIT)
+    std::map<const void*, size_t> plane_;       // 16-bit buffer -> element offset of its lo plane
+    size_t pl(const void* p) const { auto it = plane_.find(p); return it == plane_.end() ? 0 : it->second; }
+    int igemm(GemmArgs& g, hipStream_t st);     // image-tower GEMM: fills the split-precision planes when strict_
+    float* pack_tmp_ = nullptr; size_t pack_tmp_n_ = 0;
+    uint16_t* relu_tmp_ = nullptr;
+    int pack_tmp(size_t n, hipStream_t st);
     int lh_[4], lw_[4];          // spatial size of reassembled level l (0..3)
     int cp_[4];                  // reassemble channels rounded up to 64 (ViT-B/32: 96 -> 128), extra channels are 0
     int tnpad_;

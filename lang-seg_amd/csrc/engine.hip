@@ -66,6 +66,12 @@ void* Engine::dalloc(size_t bytes, bool zero) {
         if (!ptr) return set_error(LSEG_ERR_HIP, "hipMalloc of %zu bytes failed (" #ptr ")",     \
                                    (size_t)(count) * sizeof(type));                              \
     } while (0)
+// 16-bit image-tower tensor: in split-precision mode a (hi, lo) pair of planes, `count` elements apart (recorded in plane_)
+#define ALLOC16(ptr, count)                                                                      \
+    do {                                                                                         \
+        ALLOC(ptr, uint16_t, (size_t)(count) * (strict_ ? 2 : 1));                                \
+        if (strict_) plane_[ptr] = (size_t)(count);                                              \
+    } while (0)
 
 int Engine::init() {
     const lseg_config& c = cfg;
@@ -82,7 +88,8 @@ int Engine::init() {
     if (c.max_batch < 1 || c.max_labels < 1) return set_error(LSEG_ERR_INVALID, "max_batch/max_labels");
     LSEG_HIP_TRY(hipSetDevice(device));
 
-    img_dt_ = T_code(c.image_dtype);
+    strict_ = c.image_dtype == LSEG_F16_SPLIT;
+    img_dt_ = strict_ ? DT_F16 : T_code(c.image_dtype);
     gh_ = c.img_h / c.patch; gw_ = c.img_w / c.patch; np_ = gh_ * gw_; ntok_ = np_ + 1;
     npad_ = ((ntok_ + 127) / 128) * 128;
     tnpad_ = ((c.text_ctx + 127) / 128) * 128;
@@ -101,30 +108,31 @@ int Engine::init() {
     const size_t B = c.max_batch, D = c.dim, F = c.features;
     const size_t M = B * ntok_;
     ALLOC(x_, float, M * D);
-    ALLOC(ln_, uint16_t, M * D);
-    ALLOC(q_, uint16_t, B * c.heads * npad_ * 64);
-    ALLOC(k_, uint16_t, B * c.heads * npad_ * 64);
-    ALLOC(vt_, uint16_t, B * c.heads * 64 * npad_);
-    ALLOC(att_, uint16_t, M * D);
-    ALLOC(mlp_, uint16_t, M * 4 * D);
-    ALLOC(patchA_, uint16_t, B * np_ * 3 * c.patch * c.patch);
-    ALLOC(catA_, uint16_t, B * np_ * 2 * D);
-    ALLOC(ro_, uint16_t, B * np_ * D);
+    ALLOC16(ln_, M * D);
+    ALLOC16(q_, B * c.heads * npad_ * 64);
+    ALLOC16(k_, B * c.heads * npad_ * 64);
+    ALLOC16(vt_, B * c.heads * 64 * npad_);
+    ALLOC16(att_, M * D);
+    ALLOC16(mlp_, M * 4 * D);
+    ALLOC16(patchA_, B * np_ * 3 * c.patch * c.patch);
+    ALLOC16(catA_, B * np_ * 2 * D);
+    ALLOC16(ro_, B * np_ * D);
     size_t r1max = 0;
     for (int l = 0; l < 4; ++l) r1max = std::max(r1max, (size_t)cp_[l]);
-    ALLOC(r1_, uint16_t, B * np_ * r1max);
-    ALLOC(tmp_pad_, uint16_t, B * (gh_ + 2) * (gw_ + 2) * r1max);
+    ALLOC16(r1_, B * np_ * r1max);
+    ALLOC16(tmp_pad_, B * (gh_ + 2) * (gw_ + 2) * r1max);
     for (int l = 0; l < 4; ++l) {
         const size_t pp = B * (lh_[l] + 2) * (lw_[l] + 2);
-        ALLOC(L_[l], uint16_t, pp * cp_[l]);
-        ALLOC(rn_[l], uint16_t, pp * F);
-        ALLOC(t1_[l], uint16_t, pp * F);
-        ALLOC(sum_[l], uint16_t, pp * F);
-        ALLOC(t2_[l], uint16_t, pp * F);
-        ALLOC(up_[l], uint16_t, B * 4 * lh_[l] * lw_[l] * F);
-        if (l > 0) ALLOC(path_[l], uint16_t, B * (2 * lh_[l] + 2) * (2 * lw_[l] + 2) * F);   // padded, feeds level l-1
-        else ALLOC(path_[l], uint16_t, B * 4 * lh_[0] * lw_[0] * F);                         // path_1: plain rows
+        ALLOC16(L_[l], pp * cp_[l]);
+        ALLOC16(rn_[l], pp * F);
+        ALLOC16(t1_[l], pp * F);
+        ALLOC16(sum_[l], pp * F);
+        ALLOC16(t2_[l], pp * F);
+        ALLOC16(up_[l], B * 4 * lh_[l] * lw_[l] * F);
+        if (l > 0) ALLOC16(path_[l], B * (2 * lh_[l] + 2) * (2 * lw_[l] + 2) * F);   // padded, feeds level l-1
+        else ALLOC16(path_[l], B * 4 * lh_[0] * lw_[0] * F);                         // path_1: plain rows
     }
+    if (strict_) ALLOC16(relu_tmp_, B * (lh_[0] + 2) * (lw_[0] + 2) * F);
     const size_t hw1 = (size_t)4 * lh_[0] * lw_[0];
     ALLOC(feat_, float, B * hw1 * c.out_c);
     ALLOC(a16_, uint16_t, B * hw1 * c.out_c);
@@ -185,12 +193,31 @@ int Engine::pack_f32(const std::string& key, size_t n, float*& out, hipStream_t 
     return launch_convert(p.ptr, p.dtype, out, DT_F32, n, st);
 }
 
-int Engine::pack_linear(const std::string& wkey, const std::string& bkey, int n, int k, int dt, Lin& out, hipStream_t st) {
+int Engine::pack_tmp(size_t n, hipStream_t st) {
+    if (n > pack_tmp_n_) { ALLOC(pack_tmp_, float, n); pack_tmp_n_ = n; }
+    LSEG_HIP_TRY(hipMemsetAsync(pack_tmp_, 0, n * sizeof(float), st));
+    return 0;
+}
+
+int Engine::igemm(GemmArgs& g, hipStream_t st) {
+    if (strict_) {
+        g.split = 1;
+        g.a_plane = pl(g.A); g.w_plane = pl(g.W);
+        if (!g.a_plane || !g.w_plane) return set_error(LSEG_ERR_STATE, "split-precision GEMM on a tensor without a lo plane");
+        if (g.out_dtype != DT_F32) { g.c_plane = pl(g.C); g.ck_plane = pl(g.Ck); g.cv_plane = pl(g.Cv); }
+        if (g.res && g.res_dtype != DT_F32) g.res_plane = pl(g.res);
+    }
+    return launch_gemm(g, img_dt_, st);
+}
+
+int Engine::pack_linear(const std::string& wkey, const std::string& bkey, int n, int k, int dt, Lin& out, hipStream_t st, bool image) {
     BoundParam w;
     TRY(need(wkey, w, {n, k}));
-    if (!out.w) ALLOC(out.w, uint16_t, (size_t)n * k);
+    const bool split = image && strict_;
+    if (!out.w) { ALLOC(out.w, uint16_t, (size_t)n * k * (split ? 2 : 1)); if (split) plane_[out.w] = (size_t)n * k; }
     out.n = n; out.k = k;
-    TRY(launch_convert(w.ptr, w.dtype, out.w, dt, (size_t)n * k, st));
+    if (split) TRY(launch_convert_split(w.ptr, w.dtype, out.w, (size_t)n * k, (size_t)n * k, st));
+    else TRY(launch_convert(w.ptr, w.dtype, out.w, dt, (size_t)n * k, st));
     if (!bkey.empty()) TRY(pack_f32(bkey, n, out.b, st));
     return 0;
 }
@@ -215,10 +242,16 @@ int Engine::pack_conv3(const std::string& wkey, const std::string& bnp, const st
         if (b.dtype != LSEG_F32) return set_error(LSEG_ERR_UNSUPPORTED, "'%s' must be fp32", bias_key.c_str());
         cb = (const float*)b.ptr;
     }
-    if (!out.w) ALLOC(out.w, uint16_t, (size_t)cop * 9 * cip);          // zero-initialised: padding stays 0
+    const size_t nw = (size_t)cop * 9 * cip;
+    if (!out.w) { ALLOC(out.w, uint16_t, nw * (strict_ ? 2 : 1)); if (strict_) plane_[out.w] = nw; }   // zero-initialised: padding stays 0
     const bool has_bias = bw || cb;
     if (!out.b) ALLOC(out.b, float, cop);          // bias-less convs (layerN_rn) get zeros: keeps them on the specialised epilogue
     out.n = cop; out.k = 9 * cip;
+    if (strict_) {                                 // fold + re-layout in fp32, then split into the (hi, lo) planes
+        TRY(pack_tmp(nw, st));
+        TRY(launch_pack_conv3x3((const float*)w.ptr, bw, bb, bm, bv, 1e-5f, cb, pack_tmp_, has_bias ? out.b : nullptr, co, ci, cip, DT_F32, st));
+        return launch_convert_split(pack_tmp_, DT_F32, out.w, nw, nw, st);
+    }
     return launch_pack_conv3x3((const float*)w.ptr, bw, bb, bm, bv, 1e-5f, cb, out.w, has_bias ? out.b : nullptr, co, ci, cip, img_dt_, st);
 }
 
@@ -230,7 +263,7 @@ int Engine::finalize(hipStream_t st) {
     char buf[256];
     const std::string vm = "pretrained.model.";
     // ---- ViT --------------------------------------------------------------------------------------------
-    TRY(pack_linear(vm + "patch_embed.proj.weight", vm + "patch_embed.proj.bias", D, 3 * P * P, img_dt_, patch_, st));
+    TRY(pack_linear(vm + "patch_embed.proj.weight", vm + "patch_embed.proj.bias", D, 3 * P * P, img_dt_, patch_, st, true));
     TRY(pack_f32(vm + "cls_token", D, cls_, st));
     TRY(pack_f32(vm + "pos_embed", (size_t)(1 + c.pos_grid * c.pos_grid) * D, pos_raw_, st));
     if (!pos_) ALLOC(pos_, float, (size_t)ntok_ * D);
@@ -242,25 +275,26 @@ int Engine::finalize(hipStream_t st) {
         VitBlock& k = blocks_[i];
         TRY(pack_f32(b + "norm1.weight", D, k.g1, st)); TRY(pack_f32(b + "norm1.bias", D, k.b1, st));
         TRY(pack_f32(b + "norm2.weight", D, k.g2, st)); TRY(pack_f32(b + "norm2.bias", D, k.b2, st));
-        TRY(pack_linear(b + "attn.qkv.weight", b + "attn.qkv.bias", 3 * D, D, img_dt_, k.qkv, st));
-        TRY(pack_linear(b + "attn.proj.weight", b + "attn.proj.bias", D, D, img_dt_, k.proj, st));
-        TRY(pack_linear(b + "mlp.fc1.weight", b + "mlp.fc1.bias", 4 * D, D, img_dt_, k.fc1, st));
-        TRY(pack_linear(b + "mlp.fc2.weight", b + "mlp.fc2.bias", D, 4 * D, img_dt_, k.fc2, st));
+        TRY(pack_linear(b + "attn.qkv.weight", b + "attn.qkv.bias", 3 * D, D, img_dt_, k.qkv, st, true));
+        TRY(pack_linear(b + "attn.proj.weight", b + "attn.proj.bias", D, D, img_dt_, k.proj, st, true));
+        TRY(pack_linear(b + "mlp.fc1.weight", b + "mlp.fc1.bias", 4 * D, D, img_dt_, k.fc1, st, true));
+        TRY(pack_linear(b + "mlp.fc2.weight", b + "mlp.fc2.bias", D, 4 * D, img_dt_, k.fc2, st, true));
     }
     // ---- readout / reassemble / layer_rn -------------------------------------------------------------
     for (int l = 0; l < 4; ++l) {
         snprintf(buf, sizeof(buf), "pretrained.act_postprocess%d.", l + 1);
         const std::string a = buf;
         const int C = c.reassemble_ch[l], Cp = cp_[l];
-        TRY(pack_linear(a + "0.project.0.weight", a + "0.project.0.bias", D, 2 * D, img_dt_, readout_[l], st));
+        TRY(pack_linear(a + "0.project.0.weight", a + "0.project.0.bias", D, 2 * D, img_dt_, readout_[l], st, true));
         {   // 1x1 conv [C, D] -> [Cp, D] (rows >= C are zero: the padded channels stay exactly 0)
             BoundParam w, b;
             TRY(need(a + "3.weight", w, {C, D}));
             TRY(need(a + "3.bias", b, {C}));
-            if (!r1x1_[l].w) ALLOC(r1x1_[l].w, uint16_t, (size_t)Cp * D);
+            if (!r1x1_[l].w) { ALLOC(r1x1_[l].w, uint16_t, (size_t)Cp * D * (strict_ ? 2 : 1)); if (strict_) plane_[r1x1_[l].w] = (size_t)Cp * D; }
             if (!r1x1_[l].b) ALLOC(r1x1_[l].b, float, Cp);
             r1x1_[l].n = Cp; r1x1_[l].k = D;
-            TRY(launch_convert(w.ptr, w.dtype, r1x1_[l].w, img_dt_, (size_t)C * D, st));
+            if (strict_) TRY(launch_convert_split(w.ptr, w.dtype, r1x1_[l].w, (size_t)C * D, (size_t)Cp * D, st));
+            else TRY(launch_convert(w.ptr, w.dtype, r1x1_[l].w, img_dt_, (size_t)C * D, st));
             TRY(launch_convert(b.ptr, b.dtype, r1x1_[l].b, DT_F32, C, st));
         }
         if (c.resample_kind[l] == LSEG_RS_CONVT) {
@@ -269,10 +303,17 @@ int Engine::finalize(hipStream_t st) {
             TRY(need(a + "4.weight", w, {C, C, s, s}));
             TRY(need(a + "4.bias", b, {C}));
             if (w.dtype != LSEG_F32) return set_error(LSEG_ERR_UNSUPPORTED, "'%s4.weight' must be fp32", a.c_str());
-            if (!rsmp_[l].w) ALLOC(rsmp_[l].w, uint16_t, (size_t)s * s * Cp * Cp);
+            const size_t nwt = (size_t)s * s * Cp * Cp;
+            if (!rsmp_[l].w) { ALLOC(rsmp_[l].w, uint16_t, nwt * (strict_ ? 2 : 1)); if (strict_) plane_[rsmp_[l].w] = nwt; }
             if (!rsmp_[l].b) ALLOC(rsmp_[l].b, float, Cp);
             rsmp_[l].n = s * s * Cp; rsmp_[l].k = Cp;
-            TRY(launch_pack_convT((const float*)w.ptr, rsmp_[l].w, C, C, Cp, s, img_dt_, st));
+            if (strict_) {
+                TRY(pack_tmp(nwt, st));
+                TRY(launch_pack_convT((const float*)w.ptr, pack_tmp_, C, C, Cp, s, DT_F32, st));
+                TRY(launch_convert_split(pack_tmp_, DT_F32, rsmp_[l].w, nwt, nwt, st));
+            } else {
+                TRY(launch_pack_convT((const float*)w.ptr, rsmp_[l].w, C, C, Cp, s, img_dt_, st));
+            }
             TRY(launch_convert(b.ptr, b.dtype, rsmp_[l].b, DT_F32, C, st));
         } else if (c.resample_kind[l] == LSEG_RS_CONV_S2) {
             TRY(pack_conv3(a + "4.weight", "", a + "4.bias", C, C, Cp, Cp, rsmp_[l], st));
@@ -285,7 +326,7 @@ int Engine::finalize(hipStream_t st) {
         snprintf(buf, sizeof(buf), "scratch.refinenet%d.", r);
         const std::string p = buf;
         Refine& R = refine_[r - 1];
-        TRY(pack_linear(p + "out_conv.weight", p + "out_conv.bias", F, F, img_dt_, R.out_conv, st));
+        TRY(pack_linear(p + "out_conv.weight", p + "out_conv.bias", F, F, img_dt_, R.out_conv, st, true));
         for (int u = 1; u <= 2; ++u) {
             if (u == 1 && r == 4) continue;      // refinenet4.resConfUnit1 never runs (lseg_net.py:176)
             const std::string q = p + "resConfUnit" + std::to_string(u) + ".";
@@ -295,7 +336,7 @@ int Engine::finalize(hipStream_t st) {
         }
         R.has_u1 = r != 4;
     }
-    TRY(pack_linear("scratch.head1.weight", "scratch.head1.bias", c.out_c, F, img_dt_, head1_, st));
+    TRY(pack_linear("scratch.head1.weight", "scratch.head1.bias", c.out_c, F, img_dt_, head1_, st, true));
     if (c.arch_option == 1 || c.arch_option == 2) {
         TRY(pack_f32("scratch.head_block.depthwise.depthwise.weight", 9, hb_w_, st));
         TRY(pack_f32("scratch.head_block.depthwise.depthwise.bias", 1, hb_b_, st));
@@ -419,12 +460,16 @@ int Engine::conv3x3(const void* in, const Lin& w, const void* res, const void* r
     GemmArgs g;
     gemm_args_init(g);
     const int Cin = w.k / 9, Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    if (strict_ && relu_in) {        // the ReLU-ed input is materialised: a sign test on the hi fragments alone cannot zero the lo plane
+        TRY(launch_relu_split(in, pl(in), relu_tmp_, pl(relu_tmp_), (size_t)B * (H + 2) * (W + 2) * Cin, st));
+        in = relu_tmp_; relu_in = 0;
+    }
     g.A = (const uint16_t*)in; g.W = w.w; g.M = B * Ho * Wo; g.N = w.n; g.K = w.k; g.lda = Cin; g.ldw = w.k;
     g.conv = 1; g.cin = Cin; g.hp = H + 2; g.wp = W + 2; g.ho = Ho; g.wo = Wo; g.stride = stride; g.relu_in = relu_in;
     g.bias = w.b; g.act = relu_out ? ACT_RELU : ACT_NONE;
     if (res) { g.res_mode = RES_DEST; g.res = res; g.res_dtype = img_dt_; g.res2 = res2; }
     g.C = out; g.out_dtype = img_dt_; g.ldc = w.n; g.map_mode = MAP_PADDED;
-    return launch_gemm(g, img_dt_, st);
+    return igemm(g, st);
 }
 
 // FeatureFusionBlock_custom.forward (lseg_blocks.py:337-358) for refinenet r (4..1)
@@ -442,14 +487,15 @@ int Engine::refine(int r, int B, hipStream_t st) {
     }
     TRY(conv3x3(rcu2_in, R.u2.c1, nullptr, nullptr, t1_[l], B, H, W, 1, 1, 1, st));
     TRY(conv3x3(t1_[l], R.u2.c2, rcu2_in, nullptr, t2_[l], B, H, W, 1, 0, 0, st));
-    TRY(launch_upsample2x_nhwc(t2_[l], up_[l], B, H, W, F, img_dt_, st));               // :352-354
+    if (strict_) TRY(launch_upsample2x_nhwc_split(t2_[l], pl(t2_[l]), up_[l], pl(up_[l]), B, H, W, F, st));
+    else TRY(launch_upsample2x_nhwc(t2_[l], up_[l], B, H, W, F, img_dt_, st));          // :352-354
     GemmArgs g;
     gemm_args_init(g);                                                                 // out_conv :356
     g.A = up_[l]; g.W = R.out_conv.w; g.M = B * 4 * H * W; g.N = F; g.K = F; g.lda = F; g.ldw = F;
     g.bias = R.out_conv.b; g.C = path_[l]; g.out_dtype = img_dt_; g.ldc = F;
     if (l > 0) { g.map_mode = MAP_PADDED; g.ho = 2 * H; g.wo = 2 * W; }
     else g.map_mode = MAP_LINEAR;
-    return launch_gemm(g, img_dt_, st);
+    return igemm(g, st);
 }
 
 // timing events come from a free list filled outside the timed region (lseg_set_profiling / flush): no hipEventCreate per forward
@@ -528,44 +574,48 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
     }
 
     // ---- forward_flex (lseg_vit.py:166-201): patch embed + cls + pos -------------------------------------
-    TRY(launch_im2col_patch(x_in, patchA_, B, c.img_h, c.img_w, c.patch, img_dt_, st));
+    if (strict_) TRY(launch_im2col_split(x_in, patchA_, pl(patchA_), B, c.img_h, c.img_w, c.patch, st));
+    else TRY(launch_im2col_patch(x_in, patchA_, B, c.img_h, c.img_w, c.patch, img_dt_, st));
     GemmArgs g;
     gemm_args_init(g);
     g.A = patchA_; g.W = patch_.w; g.M = B * np_; g.N = D; g.K = patch_.k; g.lda = patch_.k; g.ldw = patch_.k;
     g.bias = patch_.b; g.res_mode = RES_PERIODIC; g.res = pos_; g.res_dtype = DT_F32; g.ldr = D;
     g.C = x_; g.out_dtype = DT_F32; g.ldc = D; g.map_mode = MAP_PERIODIC; g.p_div = np_; g.p_mul = ntok_; g.p_off = 1;
-    TRY(launch_gemm(g, img_dt_, st));
+    TRY(igemm(g, st));
     TRY(launch_cls_rows(cls_, pos_, x_, B, ntok_, D, st));
 
     // ---- 24 x timm Block; hooks feed readout/reassemble/layer_rn immediately ------------------------------
     for (int i = 0; i < c.depth; ++i) {
         VitBlock& b = blocks_[i];
-        TRY(launch_layernorm(x_, DT_F32, b.g1, b.b1, ln_, img_dt_, M, D, 1e-6f, st));
+        if (strict_) TRY(launch_ln_split(x_, b.g1, b.b1, ln_, pl(ln_), M, D, 1e-6f, st));
+        else TRY(launch_layernorm(x_, DT_F32, b.g1, b.b1, ln_, img_dt_, M, D, 1e-6f, st));
         gemm_args_init(g);
         g.A = ln_; g.W = b.qkv.w; g.M = M; g.N = 3 * D; g.K = D; g.lda = D; g.ldw = D;
         g.bias = b.qkv.b; g.out_dtype = img_dt_; g.map_mode = MAP_QKV;
         g.C = q_; g.Ck = k_; g.Cv = vt_; g.qkv_dim = D; g.qkv_ntok = ntok_; g.qkv_npad = npad_; g.qkv_heads = H;
-        TRY(launch_gemm(g, img_dt_, st));
-        TRY(launch_attention(q_, k_, vt_, att_, B, H, ntok_, npad_, img_dt_, 0, 0.125f, st));
+        TRY(igemm(g, st));
+        if (strict_) TRY(launch_attention_strict(q_, k_, vt_, att_, pl(q_), pl(vt_), pl(att_), B, H, ntok_, npad_, 0.125f, st));
+        else TRY(launch_attention(q_, k_, vt_, att_, B, H, ntok_, npad_, img_dt_, 0, 0.125f, st));
         gemm_args_init(g);
         g.A = att_; g.W = b.proj.w; g.M = M; g.N = D; g.K = D; g.lda = D; g.ldw = D;
         g.bias = b.proj.b; g.res_mode = RES_DEST; g.res = x_; g.res_dtype = DT_F32;
         g.C = x_; g.out_dtype = DT_F32; g.ldc = D; g.map_mode = MAP_LINEAR;
-        TRY(launch_gemm(g, img_dt_, st));
-        TRY(launch_layernorm(x_, DT_F32, b.g2, b.b2, ln_, img_dt_, M, D, 1e-6f, st));
+        TRY(igemm(g, st));
+        if (strict_) TRY(launch_ln_split(x_, b.g2, b.b2, ln_, pl(ln_), M, D, 1e-6f, st));
+        else TRY(launch_layernorm(x_, DT_F32, b.g2, b.b2, ln_, img_dt_, M, D, 1e-6f, st));
         gemm_args_init(g);
         g.A = ln_; g.W = b.fc1.w; g.M = M; g.N = 4 * D; g.K = D; g.lda = D; g.ldw = D;
         g.bias = b.fc1.b; g.act = ACT_GELU; g.C = mlp_; g.out_dtype = img_dt_; g.ldc = 4 * D; g.map_mode = MAP_LINEAR;
         g.tag = 1;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (profiling) { e0 = get_event(); e1 = get_event(); if (e0) (void)hipEventRecord(e0, st); }
-        TRY(launch_gemm(g, img_dt_, st));
+        TRY(igemm(g, st));
         if (profiling && e0 && e1) { (void)hipEventRecord(e1, st); ev_fc1_.push_back({e0, e1}); prof_fc1_.flops = 2.0 * M * 4.0 * D * D; }
         gemm_args_init(g);
         g.A = mlp_; g.W = b.fc2.w; g.M = M; g.N = D; g.K = 4 * D; g.lda = 4 * D; g.ldw = 4 * D;
         g.bias = b.fc2.b; g.res_mode = RES_DEST; g.res = x_; g.res_dtype = DT_F32;
         g.C = x_; g.out_dtype = DT_F32; g.ldc = D; g.map_mode = MAP_LINEAR;
-        TRY(launch_gemm(g, img_dt_, st));
+        TRY(igemm(g, st));
 
         for (int l = 0; l < 4; ++l) {
             if (c.hooks[l] != i) continue;
@@ -575,11 +625,12 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
             }
             const int C = cp_[l];                 // padded channel count (== reassemble_ch unless ViT-B/32 level 1)
             // ProjectReadout (lseg_vit.py:86-90)
-            TRY(launch_readout_cat(x_, catA_, B, ntok_, D, img_dt_, st));
+            if (strict_) TRY(launch_readout_cat_split(x_, catA_, pl(catA_), B, ntok_, D, st));
+            else TRY(launch_readout_cat(x_, catA_, B, ntok_, D, img_dt_, st));
             gemm_args_init(g);
             g.A = catA_; g.W = readout_[l].w; g.M = B * np_; g.N = D; g.K = 2 * D; g.lda = 2 * D; g.ldw = 2 * D;
             g.bias = readout_[l].b; g.act = ACT_GELU; g.C = ro_; g.out_dtype = img_dt_; g.ldc = D; g.map_mode = MAP_LINEAR;
-            TRY(launch_gemm(g, img_dt_, st));
+            TRY(igemm(g, st));
             // act_postprocess[3]: 1x1 conv (token-major rows == NHWC pixels, the Transpose/Unflatten are free)
             gemm_args_init(g);
             g.A = ro_; g.W = r1x1_[l].w; g.M = B * np_; g.N = C; g.K = D; g.lda = D; g.ldw = D;
@@ -587,7 +638,7 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
             if (c.resample_kind[l] == LSEG_RS_CONVT) { g.C = r1_; g.map_mode = MAP_LINEAR; }
             else if (c.resample_kind[l] == LSEG_RS_IDENTITY) { g.C = L_[l]; g.map_mode = MAP_PADDED; g.ho = gh_; g.wo = gw_; }
             else { g.C = tmp_pad_; g.map_mode = MAP_PADDED; g.ho = gh_; g.wo = gw_; }
-            TRY(launch_gemm(g, img_dt_, st));
+            TRY(igemm(g, st));
             if (c.resample_kind[l] == LSEG_RS_CONVT) {
                 // ConvTranspose2d(k = s = stride) as a GEMM with a pixel-shuffle scatter epilogue
                 const int s = c.resample_k[l];
@@ -595,7 +646,7 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
                 g.A = r1_; g.W = rsmp_[l].w; g.M = B * np_; g.N = s * s * C; g.K = C; g.lda = C; g.ldw = C;
                 g.bias = rsmp_[l].b; g.bias_mod = C; g.C = L_[l]; g.out_dtype = img_dt_; g.ldc = C;
                 g.map_mode = MAP_PIXSHUF; g.ho = gh_; g.wo = gw_; g.ps_s = s; g.ps_C = C;
-                TRY(launch_gemm(g, img_dt_, st));
+                TRY(igemm(g, st));
             } else if (c.resample_kind[l] == LSEG_RS_CONV_S2) {
                 TRY(conv3x3(tmp_pad_, rsmp_[l], nullptr, nullptr, L_[l], B, gh_, gw_, 2, 0, 0, st));
             }
@@ -615,14 +666,14 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
     gemm_args_init(g);
     g.A = path_[0]; g.W = head1_.w; g.M = Mp; g.N = c.out_c; g.K = F; g.lda = F; g.ldw = F;
     g.bias = head1_.b;
-    if (c.out_c == 512 && !debug) {
+    if (c.out_c == 512 && !debug && !strict_) {
         // fused: head1 + fp32 L2-norm + the two fp16 roundings in one epilogue (rows are complete inside
         // a workgroup); the 118 MB/image fp32 feature map is never written
         g.C = a16_; g.out_dtype = DT_F16; g.ldc = c.out_c; g.map_mode = MAP_ROWNORM; g.rn_scale = logit_scale;
-        TRY(launch_gemm(g, img_dt_, st));
+        TRY(igemm(g, st));
     } else {
         g.C = feat_; g.out_dtype = DT_F32; g.ldc = c.out_c; g.map_mode = MAP_LINEAR;
-        TRY(launch_gemm(g, img_dt_, st));
+        TRY(igemm(g, st));
         TRY(launch_l2norm_scale_f16(feat_, a16_, Mp, c.out_c, logit_scale, st));
     }
     const int Kout = group_k > 0 ? group_k : K_;            // label planes per image
@@ -684,17 +735,17 @@ int Engine::get_intermediate(const char* name, float* out, size_t cap, size_t* n
         const int H = 2 * lh_[l], W = 2 * lw_[l];
         need_n = (size_t)B * F * H * W;
         if (cap < need_n) return set_error(LSEG_ERR_INVALID, "buffer too small: %zu < %zu", cap, need_n);
-        TRY(launch_nhwc_to_nchw_f32(path_[l], out, B, H, W, F, F, l > 0 ? 1 : 0, img_dt_, st));
+        TRY(launch_nhwc_to_nchw_f32(path_[l], out, B, H, W, F, F, l > 0 ? 1 : 0, img_dt_, st, pl(path_[l])));
     } else if (!strncmp(name, "rn", 2) && name[2] >= '1' && name[2] <= '4' && !name[3]) {
         const int l = name[2] - '1';
         need_n = (size_t)B * F * lh_[l] * lw_[l];
         if (cap < need_n) return set_error(LSEG_ERR_INVALID, "buffer too small: %zu < %zu", cap, need_n);
-        TRY(launch_nhwc_to_nchw_f32(rn_[l], out, B, lh_[l], lw_[l], F, F, 1, img_dt_, st));
+        TRY(launch_nhwc_to_nchw_f32(rn_[l], out, B, lh_[l], lw_[l], F, F, 1, img_dt_, st, pl(rn_[l])));
     } else if (!strncmp(name, "layer", 5) && name[5] >= '1' && name[5] <= '4' && !name[6]) {
         const int l = name[5] - '1';
         need_n = (size_t)B * cfg.reassemble_ch[l] * lh_[l] * lw_[l];
         if (cap < need_n) return set_error(LSEG_ERR_INVALID, "buffer too small: %zu < %zu", cap, need_n);
-        TRY(launch_nhwc_to_nchw_f32(L_[l], out, B, lh_[l], lw_[l], cfg.reassemble_ch[l], cp_[l], 1, img_dt_, st));
+        TRY(launch_nhwc_to_nchw_f32(L_[l], out, B, lh_[l], lw_[l], cfg.reassemble_ch[l], cp_[l], 1, img_dt_, st, pl(L_[l])));
     } else if (!strcmp(name, "image_features")) {
         const int hw1 = 4 * lh_[0] * lw_[0];
         need_n = (size_t)B * cfg.out_c * hw1;

@@ -50,6 +50,13 @@ struct GemmArgs {
     int tag;                    // 0 generic, 1 = the profiled dominant instance (distinct symbol)
     int dbg;                    // tools only: bits 0-1 ablation (1 = skip epilogue stores, 2 = skip the epilogue), 4 = phase timing, 8 = no stagger
     int group_m;                // row-blocks per rasterisation group (0 -> 8)
+    // ---- split-precision ("strict") mode: every 16-bit operand is a (hi, lo) fp16 pair, x = hi + lo with lo = fp16(x - hi),
+    // kept as two planes `plane` elements apart.  The K-loop runs three segments into the same fp32 accumulators:
+    //   A_hi.W_hi + A_lo.W_hi + A_hi.W_lo   (the lo.lo term is below fp32 round-off) -- ~21 mantissa bits instead of 11.
+    // 16-bit outputs are written as (hi, lo) planes as well; 16-bit residuals are read as hi + lo.
+    int split;                  // 0 off, 1 on
+    size_t a_plane, w_plane;    // element offset of the lo plane of A / W
+    size_t c_plane, ck_plane, cv_plane, res_plane;   // lo planes of C / Ck / Cv / res (and res2)
 };
 
 void gemm_args_init(GemmArgs& g);

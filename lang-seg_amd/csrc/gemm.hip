@@ -194,6 +194,13 @@ __device__ __forceinline__ void apply_act(const GemmArgs& g, float (&v)[4]) {
     }
 }
 
+// (hi, lo) fp16 pair of a value: hi = fp16(v), lo = fp16(v - hi)
+__device__ __forceinline__ void store_split(void* dst, size_t off, size_t plane, float v) {
+    const float hi = round_f16(v);
+    ((uint16_t*)dst)[off] = f32_to_f16(hi);
+    ((uint16_t*)dst)[off + plane] = f32_to_f16(v - hi);
+}
+
 __device__ __forceinline__ void store4(void* dst, size_t off, int dtype, const float (&v)[4]) {
     if (dtype == DT_F32) {
         *reinterpret_cast<float4*>((float*)dst + off) = make_float4(v[0], v[1], v[2], v[3]);
@@ -211,7 +218,7 @@ __device__ __forceinline__ void store4(void* dst, size_t off, int dtype, const f
 template <int NI>
 __device__ __forceinline__ bool epilogue_cols(const GemmArgs& g, int n_first, int lane, int (&ncol)[NI], ColPart (&cp)[NI],
                                               ColPart (&cpw)[NI / 2], float4 (&bias)[NI]) {
-    const bool wide = g.out_dtype != DT_F32 && (g.N & 31) == 0 && g.map_mode != MAP_NCHW && (g.dbg & 3) == 0 &&
+    const bool wide = g.out_dtype != DT_F32 && (g.N & 31) == 0 && g.map_mode != MAP_NCHW && (g.dbg & 3) == 0 && !g.split &&
                       (g.map_mode != MAP_PIXSHUF || (g.ps_C & 31) == 0);
     {
         const int r16 = lane >> 4;
@@ -274,6 +281,14 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& g, int m, const int
             if (fast && !strided) {
                 rv[i] = load4_as_f32(g.res, roff, g.res_dtype);
                 if (g.res2) rv2[i] = load4_as_f32(g.res2, roff, g.res_dtype);
+                if (g.split && g.res_dtype != DT_F32) {          // 16-bit residual maps are (hi, lo) planes
+                    const float4 l1 = load4_as_f32(g.res, roff + g.res_plane, g.res_dtype);
+                    rv[i].x += l1.x; rv[i].y += l1.y; rv[i].z += l1.z; rv[i].w += l1.w;
+                    if (g.res2) {
+                        const float4 l2 = load4_as_f32(g.res2, roff + g.res_plane, g.res_dtype);
+                        rv2[i].x += l2.x; rv2[i].y += l2.y; rv2[i].z += l2.z; rv2[i].w += l2.w;
+                    }
+                }
             } else {
                 float t[4] = {0.f, 0.f, 0.f, 0.f};
                 for (int r = 0; r < 4; ++r)
@@ -329,7 +344,12 @@ __device__ __forceinline__ void epilogue_row(const GemmArgs& g, int m, const int
         } else if (g.map_mode == MAP_NCHW) {
             estride = g.p_div;
         }
-        if (estride == 1 && fast) {
+        if (g.split && g.out_dtype != DT_F32) {
+            const size_t plane = dst == g.Cv && g.map_mode == MAP_QKV ? g.cv_plane : (dst == g.Ck && g.map_mode == MAP_QKV ? g.ck_plane : g.c_plane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (ncol[i] + r < g.N) store_split(dst, off + r * estride, plane, v[i][r]);
+        } else if (estride == 1 && fast) {
             store4(dst, off, g.out_dtype, v[i]);
         } else {
 #pragma unroll
@@ -641,12 +661,13 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
     };
 
     const int nk = g.K >> 6;
+    const int nseg = g.split ? 3 : 1;           // split precision: K-loop segments A_hi.W_hi, A_lo.W_hi, A_hi.W_lo
     const int cpt = CONV ? (g.cin >> 6) : 1;    // 64-wide K chunks per conv tap
     constexpr int W_RING_OFF = CFG::A_RING * A_BYTES;
     // After the last tile a cursor keeps re-issuing that tile (never consumed): every step issues exactly
     // SPW loads per wave, so the counted vmcnt stays exact.
-    int atile = tile, akt = 0, aslot = 0;
-    int wtile = tile, wkt = 0, wslot = 0;
+    int atile = tile, akt = 0, aslot = 0, aseg = 0;
+    int wtile = tile, wkt = 0, wslot = 0, wseg = 0;
     setup_a(atile);
     setup_w(wtile);
     const char *abase = nullptr, *wbase = nullptr;        // source bases of the K-steps the cursors point at
@@ -659,22 +680,28 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
         } else {
             koff_a = akt << 6;
         }
-        return reinterpret_cast<const char*>(g.A + koff_a);
+        return reinterpret_cast<const char*>(g.A + (aseg == 1 ? g.a_plane : 0) + koff_a);
     };
     auto advance_a = [&]() {
         aslot = aslot + 1 == CFG::A_RING ? 0 : aslot + 1;
         if (++akt == nk) {
             akt = 0;
-            if (atile + wpx < tile_end) atile += wpx;
-            setup_a(atile);
+            if (++aseg == nseg) {
+                aseg = 0;
+                if (atile + wpx < tile_end) atile += wpx;
+                setup_a(atile);
+            }
         }
     };
     auto advance_w = [&]() {
         wslot ^= 1;
         if (++wkt == nk) {
             wkt = 0;
-            if (wtile + wpx < tile_end) wtile += wpx;
-            setup_w(wtile);
+            if (++wseg == nseg) {
+                wseg = 0;
+                if (wtile + wpx < tile_end) wtile += wpx;
+                setup_w(wtile);
+            }
         }
     };
     // One issue GROUP = the W panel at the W cursor, then the A panel at the A cursor (one K-step further on);
@@ -683,7 +710,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
     auto issue_q = [&](auto qc) {
         constexpr int q = decltype(qc)::value;
         if constexpr (q < W_SPW) {
-            if constexpr (q == 0) wbase = reinterpret_cast<const char*>(g.W + (wkt << 6));
+            if constexpr (q == 0) wbase = reinterpret_cast<const char*>(g.W + (wseg == 2 ? g.w_plane : 0) + (wkt << 6));
             glds_slab_off(wbase, w_off[q], smem + W_RING_OFF + wslot * CFG::W_BYTES + (q * NW + w) * 1024);
             if constexpr (q == W_SPW - 1) advance_w();
         } else {
@@ -837,7 +864,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
         for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < MI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < nk; ++kt) step();
+        for (int kt = 0; kt < nk * nseg; ++kt) step();
         // ---- epilogue: the next tile's first K-step is already in flight / in registers
         unsigned long long te0 = 0;
         if ((g.dbg & 4)) te0 = __builtin_readcyclecounter();
@@ -991,7 +1018,7 @@ template <typename T>
 int select_epi(const GemmArgs& g) {
     constexpr int dt = std::is_same<T, BF16>::value ? DT_BF16 : DT_F16;
     static const bool off = getenv("LSEG_GEMM_GENERIC_EPI") != nullptr;       // A/B switch (tools)
-    if (off || (g.dbg & 3) || !g.bias || g.bias_mod || g.round_mid || (g.N % 128) != 0) return EPI_GENERIC;
+    if (off || g.split || (g.dbg & 3) || !g.bias || g.bias_mod || g.round_mid || (g.N % 128) != 0) return EPI_GENERIC;
     if (g.res2 && !(g.dbg & 4) && g.map_mode != MAP_PADDED) return EPI_GENERIC;
     if ((reinterpret_cast<uintptr_t>(g.C) & 15) || (reinterpret_cast<uintptr_t>(g.bias) & 15)) return EPI_GENERIC;
     if (g.map_mode == MAP_PADDED && g.out_dtype == dt && (g.ldc % 8) == 0 && (g.act == ACT_NONE || g.act == ACT_RELU) &&
@@ -1017,6 +1044,7 @@ int select_epi(const GemmArgs& g) {
 template <typename T>
 int dispatch(const GemmArgs& g, hipStream_t stream) {
     if (g.map_mode == MAP_ROWNORM) {
+        if (g.split) return set_error(LSEG_ERR_UNSUPPORTED, "the fused head has no split-precision form (use the two-kernel path)");
         if (g.conv || g.relu_in || g.N != 512 || !g.bias)
             return set_error(LSEG_ERR_UNSUPPORTED, "fused head needs a plain GEMM with N == 512 and a bias");
         return launch_one<T, CfgRow, false, false, EPI_GENERIC, 0>(g, stream);
@@ -1031,6 +1059,7 @@ int dispatch(const GemmArgs& g, hipStream_t stream) {
         return pick_tile<T, true, false, EPI_GENERIC, 0>(g, stream);
     }
     if (g.relu_in) return set_error(LSEG_ERR_UNSUPPORTED, "gemm: relu_in is only implemented for the conv path");
+    if (g.split && !std::is_same<T, F16>::value) return set_error(LSEG_ERR_UNSUPPORTED, "split precision runs on fp16 (hi, lo) pairs");
     switch (epi) {
         case EPI_PAD16: return pick_tile<T, false, false, EPI_PAD16, 0>(g, stream);
         case EPI_LIN16: return pick_tile<T, false, false, EPI_LIN16, 0>(g, stream);
@@ -1054,6 +1083,7 @@ int launch_gemm(const GemmArgs& g_in, int ab_dtype, hipStream_t stream) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return set_error(LSEG_ERR_INVALID, "gemm: empty problem %dx%dx%d", g.M, g.N, g.K);
     if (g.K % 64 != 0) return set_error(LSEG_ERR_UNSUPPORTED, "gemm: K=%d must be a multiple of 64", g.K);
     if (g.conv && (g.cin % 64 != 0)) return set_error(LSEG_ERR_UNSUPPORTED, "conv: Cin=%d must be a multiple of 64", g.cin);
+    if (g.split && g.relu_in) return set_error(LSEG_ERR_UNSUPPORTED, "split precision: ReLU on the A fragments is not representable (materialise relu(A))");
     if ((g.lda % 8) || (g.ldw % 8)) return set_error(LSEG_ERR_UNSUPPORTED, "gemm: lda/ldw must be multiples of 8 elements");
     {   // per-lane source offsets are 32-bit byte offsets
         const double a_bytes = g.conv ? (double)g.M * g.stride * g.stride * 1.2 * g.cin * 2 + 4.0 * g.wp * g.cin * 2

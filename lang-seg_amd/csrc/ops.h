@@ -25,9 +25,9 @@ int launch_convert2d(const void* in, int in_dtype, void* out, int out_dtype, int
 int launch_transpose_convert(const void* in, int in_dtype, void* out, int out_dtype, int R, int C, hipStream_t st);
 int launch_pack_conv3x3(const float* w, const float* bn_w, const float* bn_b, const float* bn_m, const float* bn_v,
                         float bn_eps, const float* conv_bias, void* wp, float* bias_out, int Co, int Ci, int Cip, int dtype,
-                        hipStream_t st);
+                        hipStream_t st);      // dtype DT_F32: wp is a float buffer (split-precision packs go through fp32)
 int launch_pack_convT(const float* w, void* wp, int Ci, int Co, int Cp, int s, int dtype, hipStream_t st);
-int launch_nhwc_to_nchw_f32(const void* in, float* out, int B, int H, int W, int C, int Cs, int pad, int dtype, hipStream_t st);
+int launch_nhwc_to_nchw_f32(const void* in, float* out, int B, int H, int W, int C, int Cs, int pad, int dtype, hipStream_t st, size_t lo_plane = 0);
 int launch_rows_to_nchw_f32(const float* in, float* out, int B, int HW, int C, hipStream_t st);
 int launch_head_block(const float* in, float* out, const float* w9, const float* bias, int B, int K, int H, int W,
                       int bottleneck, int act, int apply_act, hipStream_t st);
@@ -58,6 +58,16 @@ int launch_colsum16(const void* in, int dtype, float* out, int R, int C, int ld,
 int launch_relu_backward_add(const void* dy, const void* x, const void* add, void* dx, size_t n, int dtype, hipStream_t st);
 int launch_seg_stats(const float* scores, const int64_t* target, int B, int K, int HW, int ignore_index,
                      unsigned long long* counts, double* nll, hipStream_t st);
+
+// ---- split-precision ("strict") mode (strict.hip): 16-bit tensors as (hi, lo) fp16 planes `plane` elements apart --------------
+int launch_convert_split(const void* in, int in_dtype, void* out, size_t n, size_t plane, hipStream_t st);
+int launch_ln_split(const float* x, const float* gamma, const float* beta, void* out, size_t plane, int M, int D, float eps, hipStream_t st);
+int launch_im2col_split(const float* x, void* A, size_t plane, int B, int H, int W, int P, hipStream_t st);
+int launch_readout_cat_split(const float* x, void* A, size_t plane, int B, int ntok, int D, hipStream_t st);
+int launch_upsample2x_nhwc_split(const void* in, size_t in_plane, void* out, size_t out_plane, int B, int H, int W, int C, hipStream_t st);
+int launch_relu_split(const void* in, size_t in_plane, void* out, size_t out_plane, size_t n, hipStream_t st);
+int launch_attention_strict(const void* q, const void* k, const void* vt, void* out, size_t qk_plane, size_t vt_plane, size_t out_plane,
+                            int B, int H, int ntok, int npad, float scale, hipStream_t st);
 
 // ---- engine-level training step (train.hip) --------------------------------------------------------------------------------
 int launch_attention_lse(const void* q, const void* k, const void* vt, void* out, float* lse2, int B, int H, int ntok, int npad, int dtype,

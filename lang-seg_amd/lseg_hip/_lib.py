@@ -11,7 +11,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LSEG_HIP_LIB", os.path.join(_HERE, "liblseg_hip.so"))   # override: A/B-testing builds
 
-LSEG_F32, LSEG_F16, LSEG_BF16, LSEG_I64 = 0, 1, 2, 3
+LSEG_F32, LSEG_F16, LSEG_BF16, LSEG_I64, LSEG_F16_SPLIT = 0, 1, 2, 3, 4
 RS_IDENTITY, RS_CONVT, RS_CONV_S2 = 0, 1, 2
 ABI_VERSION = 1
 

@@ -47,7 +47,8 @@ def to_c_config(cfg: LSegConfig, img_h: int, img_w: int, max_batch: int, max_lab
     c.text_vocab, c.text_ctx, c.text_width, c.text_heads, c.text_layers = t.vocab, t.ctx, t.width, t.heads, t.layers
     c.img_h, c.img_w = img_h, img_w
     c.max_batch, c.max_labels = max_batch, max_labels
-    c.image_dtype = {"bf16": _lib.LSEG_BF16, "fp16": _lib.LSEG_F16}[image_dtype]
+    # "strict": split-precision validation mode ((hi, lo) fp16 operand pairs, ~21 mantissa bits; include/lseg_hip.h)
+    c.image_dtype = {"bf16": _lib.LSEG_BF16, "fp16": _lib.LSEG_F16, "strict": _lib.LSEG_F16_SPLIT}[image_dtype]
     c.flags = 1 if full_text_context else 0
     return c
 

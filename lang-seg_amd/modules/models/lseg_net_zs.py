@@ -10,6 +10,8 @@ Only the ViT backbones are implemented (clip_vitl16_384, clip_vitb32_384); the r
 variants (LSegRNNetZS, lseg_net_zs.py:243-363) raise.
 """
 import numpy as np
+from collections import OrderedDict
+
 import torch
 import torch.nn as nn
 
@@ -43,8 +45,8 @@ class LSeg(_LSegShared):
         self.scratch.output_conv = head
         # one token pair per class: ['others', <class name>]  (:169-176)
         self.texts = [tokenize(["others", name], self.cfg.text.ctx, self.cfg.text.vocab) for name in self.label_list]
-        self._engines = {}
-        self._param_stamp = None
+        self._engines = OrderedDict()
+        self.max_engines = kwargs.get("max_engines", 4)
         self.image_dtype = kwargs.get("image_dtype", "bf16")
         self.cache_text = kwargs.get("cache_text", False)
 

@@ -294,7 +294,11 @@ _REF = sorted(f[:-3] for f in os.listdir(_GOLD) if f.startswith("ref_vit"))
 _REF_FULL = sorted(f[:-3] for f in os.listdir(_GOLD) if f.startswith("ref_full_"))
 
 # measured |dlogit| of the bf16 engine vs these fixtures is 0.08-0.16 (fp16 operands: 0.01-0.03); stated tolerance ~2x that
-REF_TOL = {"bf16": 0.30, "fp16": 0.06}
+# "strict" = the split-precision validation mode ((hi, lo) fp16 operand pairs): what is left is fp32 summation order and the
+# reference's own fp16 rounding of the logits (ulp 0.002-0.004 at |logit| 2-8); two fp32 CPU implementations of the path (oracle vs
+# reference) already differ by 0.002-0.004 (tests/test_oracle_ref_golden.py)
+REF_TOL = {"bf16": 0.30, "fp16": 0.06, "strict": 0.012}
+STAGE_TOL = {"bf16": 0.10, "fp16": 0.015, "strict": 2e-3}
 
 
 def assert_argmax_mismatches_are_ties(out_low_or_logits, ref_argmax, ref_margin, err, what):
@@ -308,7 +312,7 @@ def assert_argmax_mismatches_are_ties(out_low_or_logits, ref_argmax, ref_margin,
     return frac
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "strict"])
 @pytest.mark.parametrize("name", _REF)
 def test_engine_matches_fixtures_made_by_the_reference_code(name, dtype, golden_dir):
     """tests/golden/ref_vit*.pt were produced by the reference's own modules/models/lseg_net(_zs).py on CPU
@@ -351,7 +355,7 @@ def test_engine_matches_fixtures_made_by_the_reference_code(name, dtype, golden_
         assert (tf - tr).abs().max().item() <= 4e-3
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "strict"])
 @pytest.mark.parametrize("name", _REF_FULL)
 def test_engine_matches_the_reference_at_the_baseline_configs(name, dtype, golden_dir):
     """BASELINE.json configs[1] (ViT-L/16, 480x480, K=150) and configs[4] (K=1000 open-vocabulary prompts), B=1: fixtures made by
@@ -369,7 +373,7 @@ def test_engine_matches_the_reference_at_the_baseline_configs(name, dtype, golde
     eng.set_debug(True)
     out = eng.forward(x.cuda())
     torch.cuda.synchronize()
-    stage_tol = 0.10 if dtype == "bf16" else 0.015
+    stage_tol = STAGE_TOL[dtype]
     ntok = cfg.tokens(H, W)
     for l in range(4):
         a = eng.intermediate(f"act{l + 1}", (B, ntok, cfg.dim)).cpu()[:, ::8, :]
@@ -386,7 +390,13 @@ def test_engine_matches_the_reference_at_the_baseline_configs(name, dtype, golde
     err = max(err, err_top2)
     print(f"{name}[{dtype}]: lowres max|d| {err:.4f}, logits max|d| {err_out:.4f} (range {g['lowres_absmax']:.2f})")
     assert err <= REF_TOL[dtype] and err_out <= REF_TOL[dtype], (name, dtype, err, err_out)
-    assert_argmax_mismatches_are_ties(low, g["argmax_lowres"].long(), g["margin_lowres"].float(), err, f"{name}[{dtype}]")
+    frac = assert_argmax_mismatches_are_ties(low, g["argmax_lowres"].long(), g["margin_lowres"].float(), err, f"{name}[{dtype}]")
+    out_dir = os.path.join(os.path.dirname(golden_dir), "..", "gpurun_out")
+    if os.path.isdir(out_dir):                     # the parity table of DESIGN.md §4 is made from these lines
+        mism = low.argmax(1) != g["argmax_lowres"].long()
+        worst = g["margin_lowres"].float()[mism].max().item() if mism.any() else 0.0
+        with open(os.path.join(out_dir, "parity_table.txt"), "a") as f:
+            f.write(f"{name} {dtype}: max|dlogit| {err:.5f}  argmax mismatch fraction {frac:.6f}  max reference margin at a mismatch {worst:.5f}\n")
     tf = eng.encode_text().float().cpu()
     tr = g["text_features"].float()
     tr = tr / tr.norm(dim=-1, keepdim=True)
