@@ -211,8 +211,13 @@ int lseg_op_correlation(const float* feat, const void* text_f16, float* logits, 
     if (!r) {
         GemmArgs g;
         gemm_args_init(g);
-        g.A = a; g.W = (const uint16_t*)text_f16; g.M = (int)M; g.N = K; g.K = C; g.lda = C; g.ldw = C;
-        g.round_mid = 1; g.C = logits; g.out_dtype = DT_F32; g.map_mode = MAP_NCHW; g.p_div = P;
+        if (P % 4 == 0) {      // the engine's orientation: labels = rows, pixels = columns (16-byte stores along the label planes)
+            g.A = (const uint16_t*)text_f16; g.W = a; g.M = K; g.N = (int)M; g.K = C; g.lda = C; g.ldw = C;
+            g.round_mid = 1; g.C = logits; g.out_dtype = DT_F32; g.map_mode = MAP_LABELPLANES; g.p_div = P;
+        } else {
+            g.A = a; g.W = (const uint16_t*)text_f16; g.M = (int)M; g.N = K; g.K = C; g.lda = C; g.ldw = C;
+            g.round_mid = 1; g.C = logits; g.out_dtype = DT_F32; g.map_mode = MAP_NCHW; g.p_div = P;
+        }
         r = launch_gemm(g, DT_F16, (hipStream_t)stream);
     }
     (void)hipFreeAsync(a, (hipStream_t)stream);

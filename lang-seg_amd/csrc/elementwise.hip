@@ -272,6 +272,86 @@ __global__ __launch_bounds__(256) void l2norm_scale_f16_kernel(const float* f, u
     }
 }
 
+// ---- commuted head: the pixel features without the 240x240 GEMMs ----------------------------------------------------------------
+// scratch.head1 (1x1, lseg_net.py:185) follows refinenet1.out_conv (1x1, lseg_blocks.py:356), which follows the x2 bilinear upsample
+// (:352-354).  1x1 convs commute with the (linear, per-channel) upsample, so
+//     head1(out_conv(up(t))) = up(Wc t + bc),   Wc = Wh Wo,  bc = Wh bo + bh
+// and the two GEMMs run ONCE at the quarter resolution (3.8 GF instead of 7.5 + 15.1 GF per image; exact in real arithmetic, fp32
+// round-off apart).  combine_1x1_kernel builds (Wc, bc) in fp32 at pack time; upsample_norm_f16_kernel then produces the correlation's
+// A operand straight from g = Wc t + bc (fp32, padded NHWC): bilinear x2 (align_corners=True), fp32 L2-norm over the channels and the
+// two fp16 roundings of lseg_net.py:191,194 -- one wave per output pixel, 8 channels per lane per pass, the four taps read as float4.
+__global__ void combine_1x1_kernel(const float* __restrict__ wh, const float* __restrict__ bh, const float* __restrict__ wo,
+                                   const float* __restrict__ bo, float* __restrict__ wc, float* __restrict__ bc, int Co, int Cm, int Ci) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Co * (Ci + 1)) return;
+    const int co = idx / (Ci + 1), ci = idx - co * (Ci + 1);
+    double s = 0.0;
+    if (ci < Ci) {
+        for (int m = 0; m < Cm; ++m) s += (double)wh[(size_t)co * Cm + m] * (double)wo[(size_t)m * Ci + ci];
+        wc[(size_t)co * Ci + ci] = (float)s;
+    } else {
+        for (int m = 0; m < Cm; ++m) s += (double)wh[(size_t)co * Cm + m] * (double)bo[m];
+        bc[co] = (float)(s + (double)bh[co]);
+    }
+}
+template <int NV>      // NV float4 pairs per lane: C = 512 -> NV = 1 (8 channels per lane), C = 768 -> 2 (lanes 0-31 only on the second)
+__global__ __launch_bounds__(256) void upsample_norm_f16_kernel(const float* __restrict__ g, uint16_t* __restrict__ a, int B, int H, int W,
+                                                                int C, float scale) {
+    const int lane = threadIdx.x & 63;
+    const int Ho = 2 * H, Wo = 2 * W;
+    const size_t npix = (size_t)B * Ho * Wo;
+    const float ry = (float)(H - 1) / (float)(Ho - 1), rx = (float)(W - 1) / (float)(Wo - 1);
+    for (size_t pix = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); pix < npix; pix += (size_t)gridDim.x * 4) {
+        const int xo = (int)(pix % Wo);
+        const int yo = (int)((pix / Wo) % Ho);
+        const int b = (int)(pix / ((size_t)Wo * Ho));
+        const float sy = ry * (float)yo, sx = rx * (float)xo;
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        const size_t rowp = (size_t)(W + 2) * C;
+        const float* base = g + (size_t)b * (H + 2) * rowp;
+        const float* p00 = base + (size_t)(y0 + 1) * rowp + (size_t)(x0 + 1) * C;
+        const float* p01 = base + (size_t)(y0 + 1) * rowp + (size_t)(x1 + 1) * C;
+        const float* p10 = base + (size_t)(y1 + 1) * rowp + (size_t)(x0 + 1) * C;
+        const float* p11 = base + (size_t)(y1 + 1) * rowp + (size_t)(x1 + 1) * C;
+        float v[NV][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 8;
+            if (c < C) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float4 a00 = *reinterpret_cast<const float4*>(p00 + c + 4 * h), a01 = *reinterpret_cast<const float4*>(p01 + c + 4 * h);
+                    const float4 a10 = *reinterpret_cast<const float4*>(p10 + c + 4 * h), a11 = *reinterpret_cast<const float4*>(p11 + c + 4 * h);
+                    // same association as upsample_bilinear2d: (1-ly)*((1-lx)*v00 + lx*v01) + ly*((1-lx)*v10 + lx*v11)
+                    v[i][4 * h + 0] = (1.f - ly) * ((1.f - lx) * a00.x + lx * a01.x) + ly * ((1.f - lx) * a10.x + lx * a11.x);
+                    v[i][4 * h + 1] = (1.f - ly) * ((1.f - lx) * a00.y + lx * a01.y) + ly * ((1.f - lx) * a10.y + lx * a11.y);
+                    v[i][4 * h + 2] = (1.f - ly) * ((1.f - lx) * a00.z + lx * a01.z) + ly * ((1.f - lx) * a10.z + lx * a11.z);
+                    v[i][4 * h + 3] = (1.f - ly) * ((1.f - lx) * a00.w + lx * a01.w) + ly * ((1.f - lx) * a10.w + lx * a11.w);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += v[i][e] * v[i][e];
+            }
+        }
+        const float nrm = sqrtf(wave_sum(s));
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = (lane + 64 * i) * 8;
+            if (c < C) {
+                uint32_t o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t lo = f32_to_f16(scale * round_f16(v[i][2 * e] / nrm)), hi = f32_to_f16(scale * round_f16(v[i][2 * e + 1] / nrm));
+                    o[e] = lo | (hi << 16);
+                }
+                *reinterpret_cast<uint4*>(a + pix * C + c) = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+}
+
 // ---- text: token+positional embedding in fp16 steps ([3P] clip/model.py encode_text) ---------------
 __global__ void text_embed_kernel(const int64_t* tok, const float* emb, const float* pos, uint16_t* x,
                                   int rows, int L, int ctx, int W) {
@@ -1176,6 +1256,22 @@ int launch_l2norm_scale_f16(const float* f, void* a, int M, int C, float scale, 
     if (C <= 256) hipLaunchKernelGGL(l2norm_scale_f16_kernel<1>, dim3(blocks), dim3(256), 0, st, f, (uint16_t*)a, M, C, scale);
     else if (C <= 512) hipLaunchKernelGGL(l2norm_scale_f16_kernel<2>, dim3(blocks), dim3(256), 0, st, f, (uint16_t*)a, M, C, scale);
     else hipLaunchKernelGGL(l2norm_scale_f16_kernel<4>, dim3(blocks), dim3(256), 0, st, f, (uint16_t*)a, M, C, scale);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_combine_1x1(const float* wh, const float* bh, const float* wo, const float* bo, float* wc, float* bc, int Co, int Cm, int Ci,
+                       hipStream_t st) {
+    const int n = Co * (Ci + 1);
+    hipLaunchKernelGGL(combine_1x1_kernel, dim3((n + 255) / 256), dim3(256), 0, st, wh, bh, wo, bo, wc, bc, Co, Cm, Ci);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_upsample_norm_f16(const float* g, void* a, int B, int H, int W, int C, float scale, hipStream_t st) {
+    if (C % 8 != 0 || C > 1024) return set_error(LSEG_ERR_UNSUPPORTED, "upsample_norm: C=%d", C);
+    const size_t npix = (size_t)B * 4 * H * W;
+    const int blocks = (int)std::min<size_t>((npix + 3) / 4, 256 * 32);
+    if (C <= 512) hipLaunchKernelGGL(upsample_norm_f16_kernel<1>, dim3(blocks), dim3(256), 0, st, g, (uint16_t*)a, B, H, W, C, scale);
+    else hipLaunchKernelGGL(upsample_norm_f16_kernel<2>, dim3(blocks), dim3(256), 0, st, g, (uint16_t*)a, B, H, W, C, scale);
     CHECK_LAUNCH();
     return 0;
 }

@@ -85,7 +85,7 @@ private:
                    int cop, int cip, Lin& out, hipStream_t st);
     int conv3x3(const void* in, const Lin& w, const void* res, const void* res2, void* out, int B, int H, int W,
                 int stride, int relu_in, int relu_out, hipStream_t st);
-    int refine(int r, int B, hipStream_t st);
+    int refine(int r, int B, hipStream_t st, bool stop_before_upsample = false);
     int flush_events();
     // train.hip
     int train_alloc();
@@ -130,6 +130,8 @@ private:
     Lin readout_[4], r1x1_[4], rsmp_[4], layer_rn_[4];
     Refine refine_[4];           // index r-1
     Lin head1_;
+    Lin headc_;                  // head1 o refinenet1.out_conv as ONE 1x1 conv (applied before the x2 upsample: engine.hip "commuted head")
+    float *headc_w32_ = nullptr, *gpad_ = nullptr;
     float *hb_w_ = nullptr, *hb_b_ = nullptr;
     float *tok_emb_ = nullptr, *tpos_ = nullptr, *tlnf_g_ = nullptr, *tlnf_b_ = nullptr;
     std::vector<TextBlock> tblocks_;

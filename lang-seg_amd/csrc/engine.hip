@@ -134,6 +134,7 @@ int Engine::init() {
     }
     if (strict_) ALLOC16(relu_tmp_, B * (lh_[0] + 2) * (lw_[0] + 2) * F);
     const size_t hw1 = (size_t)4 * lh_[0] * lw_[0];
+    ALLOC(gpad_, float, B * (lh_[0] + 2) * (lw_[0] + 2) * c.out_c);
     ALLOC(feat_, float, B * hw1 * c.out_c);
     ALLOC(a16_, uint16_t, B * hw1 * c.out_c);
     ALLOC(low_, float, B * c.max_labels * hw1);
@@ -337,6 +338,22 @@ int Engine::finalize(hipStream_t st) {
         R.has_u1 = r != 4;
     }
     TRY(pack_linear("scratch.head1.weight", "scratch.head1.bias", c.out_c, F, img_dt_, head1_, st, true));
+    {   // commuted head: Wc = W_head1 . W_out_conv(refinenet1), bc = W_head1 . b_out_conv + b_head1  (fp32, then packed)
+        BoundParam wh, bh, wo, bo;
+        TRY(need("scratch.head1.weight", wh, {c.out_c, F})); TRY(need("scratch.head1.bias", bh, {c.out_c}));
+        TRY(need("scratch.refinenet1.out_conv.weight", wo, {F, F})); TRY(need("scratch.refinenet1.out_conv.bias", bo, {F}));
+        if (wh.dtype == LSEG_F32 && bh.dtype == LSEG_F32 && wo.dtype == LSEG_F32 && bo.dtype == LSEG_F32) {
+            if (!headc_w32_) ALLOC(headc_w32_, float, (size_t)c.out_c * F);
+            if (!headc_.b) ALLOC(headc_.b, float, c.out_c);
+            if (!headc_.w) ALLOC(headc_.w, uint16_t, (size_t)c.out_c * F);
+            headc_.n = c.out_c; headc_.k = F;
+            TRY(launch_combine_1x1((const float*)wh.ptr, (const float*)bh.ptr, (const float*)wo.ptr, (const float*)bo.ptr, headc_w32_, headc_.b,
+                                   c.out_c, F, F, st));
+            TRY(launch_convert(headc_w32_, DT_F32, headc_.w, img_dt_, (size_t)c.out_c * F, st));
+        } else {
+            headc_.n = 0;           // non-fp32 checkpoints: the two-GEMM path
+        }
+    }
     if (c.arch_option == 1 || c.arch_option == 2) {
         TRY(pack_f32("scratch.head_block.depthwise.depthwise.weight", 9, hb_w_, st));
         TRY(pack_f32("scratch.head_block.depthwise.depthwise.bias", 1, hb_b_, st));
@@ -473,7 +490,7 @@ int Engine::conv3x3(const void* in, const Lin& w, const void* res, const void* r
 }
 
 // FeatureFusionBlock_custom.forward (lseg_blocks.py:337-358) for refinenet r (4..1)
-int Engine::refine(int r, int B, hipStream_t st) {
+int Engine::refine(int r, int B, hipStream_t st, bool stop_before_upsample) {
     const int l = r - 1, H = lh_[l], W = lw_[l], F = cfg.features;
     Refine& R = refine_[l];
     const uint16_t* rcu2_in;
@@ -487,6 +504,7 @@ int Engine::refine(int r, int B, hipStream_t st) {
     }
     TRY(conv3x3(rcu2_in, R.u2.c1, nullptr, nullptr, t1_[l], B, H, W, 1, 1, 1, st));
     TRY(conv3x3(t1_[l], R.u2.c2, rcu2_in, nullptr, t2_[l], B, H, W, 1, 0, 0, st));
+    if (stop_before_upsample) return 0;         // the commuted head takes it from here
     if (strict_) TRY(launch_upsample2x_nhwc_split(t2_[l], pl(t2_[l]), up_[l], pl(up_[l]), B, H, W, F, st));
     else TRY(launch_upsample2x_nhwc(t2_[l], up_[l], B, H, W, F, img_dt_, st));          // :352-354
     GemmArgs g;
@@ -656,7 +674,10 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
     }
 
     // ---- refinenet4..1 (lseg_net.py:176-179) ---------------------------------------------------------------
-    for (int r = 4; r >= 1; --r) TRY(refine(r, B, st));
+    // Fast path of the head (everything but the debug taps / the split-precision mode): the two 1x1 convs after refinenet1's
+    // upsample -- out_conv and head1 -- commute with it and run as ONE GEMM at the quarter resolution (elementwise.hip "commuted head")
+    const bool commuted = !debug && !strict_ && headc_.n == c.out_c;
+    for (int r = 4; r >= 1; --r) TRY(refine(r, B, st, commuted && r == 1));
 
     if (run_text) LSEG_HIP_TRY(hipStreamWaitEvent(st, ev_join_, 0));     // join before the correlation
 
@@ -666,7 +687,13 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
     gemm_args_init(g);
     g.A = path_[0]; g.W = head1_.w; g.M = Mp; g.N = c.out_c; g.K = F; g.lda = F; g.ldw = F;
     g.bias = head1_.b;
-    if (c.out_c == 512 && !debug && !strict_) {
+    if (commuted) {
+        // g = Wc t2 + bc on every row of the padded map (border rows are never read), fp32; then x2 bilinear + L2-norm + fp16 casts
+        g.A = t2_[0]; g.W = headc_.w; g.bias = headc_.b; g.M = B * (lh_[0] + 2) * (lw_[0] + 2);
+        g.C = gpad_; g.out_dtype = DT_F32; g.ldc = c.out_c; g.map_mode = MAP_LINEAR;
+        TRY(igemm(g, st));
+        TRY(launch_upsample_norm_f16(gpad_, a16_, B, lh_[0], lw_[0], c.out_c, logit_scale, st));
+    } else if (c.out_c == 512 && !debug && !strict_) {
         // fused: head1 + fp32 L2-norm + the two fp16 roundings in one epilogue (rows are complete inside
         // a workgroup); the 118 MB/image fp32 feature map is never written
         g.C = a16_; g.out_dtype = DT_F16; g.ldc = c.out_c; g.map_mode = MAP_ROWNORM; g.rn_scale = logit_scale;
@@ -690,9 +717,11 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
             TRY(launch_gemm(g, DT_F16, st));
         }
     } else {
+    // the labels are the GEMM's rows and the pixels its columns: each lane ends up with 4 consecutive pixels of one label plane
+    // (16-byte stores into [B, K, h*w]) and K = 150 pads to 160 rows, not to 256 columns
     gemm_args_init(g);
-    g.A = a16_; g.W = tnorm_; g.M = Mp; g.N = K_; g.K = c.out_c; g.lda = c.out_c; g.ldw = c.out_c;
-    g.round_mid = 1; g.C = low_; g.out_dtype = DT_F32; g.map_mode = MAP_NCHW; g.p_div = hw1;
+    g.A = tnorm_; g.W = a16_; g.M = K_; g.N = Mp; g.K = c.out_c; g.lda = c.out_c; g.ldw = c.out_c;
+    g.round_mid = 1; g.C = low_; g.out_dtype = DT_F32; g.map_mode = MAP_LABELPLANES; g.p_div = hw1;
     TRY(launch_gemm(g, DT_F16, st));
     }
     float* low = low_;

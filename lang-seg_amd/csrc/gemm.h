@@ -15,6 +15,8 @@ enum MapMode {
                       // [b, y*s+i+1, x*s+j+1, co] of a (Ho*s+2, Wo*s+2) map
     MAP_QKV = 4,      // n=(which, head, d), m=(b,t): q,k -> [b,head,t,d] ; v -> [b,head,d,t]
     MAP_NCHW = 5,     // m=(b,p), P=p_div pixels: C[(b*N + n)*P + p]  (label-major logits planes)
+    MAP_LABELPLANES = 7, // correlation, labels as GEMM rows: m = label, n = (b, p) with P = p_div pixels per image:
+                      // C[(b*M + m)*P + p] -- the [B, K, h*w] logits planes, 4 consecutive pixels per lane (16-byte stores)
     MAP_ROWNORM = 6,  // fused head (N == 512): C[m*ldc+n] = fp16(rn_scale * fp16(v / ||v_row||_2)), v = acc + bias
 };
 enum ResMode { RES_NONE = 0, RES_DEST = 1, RES_PERIODIC = 2 };

@@ -115,6 +115,10 @@ __device__ __forceinline__ ColPart col_part(const GemmArgs& g, int n) {
             c.off = which == 2 ? ((size_t)head * 64 + d) * g.qkv_npad : (size_t)head * g.qkv_npad * 64 + d;
         } break;
         case MAP_NCHW: c.off = (size_t)n * g.p_div; break;
+        case MAP_LABELPLANES: {
+            const int b = n / g.p_div;
+            c.off = (size_t)b * g.M * g.p_div + (size_t)(n - b * g.p_div);
+        } break;
         default: break;
     }
     return c;
@@ -150,6 +154,7 @@ __device__ __forceinline__ void row_part(const GemmArgs& g, int m, size_t& r0, s
             const int b = m / g.p_div, p = m - b * g.p_div;
             r0 = (size_t)b * g.N * g.p_div + p;
         } break;
+        case MAP_LABELPLANES: r0 = (size_t)m * g.p_div; break;
         default: r0 = 0; break;
     }
 }
@@ -560,6 +565,9 @@ struct TileCfg {
     static_assert((BM / 8) % NW == 0 && (BN / 8) % NW == 0, "slabs must divide evenly over the waves");
 };
 using CfgMid = TileCfg<128, 128, 2, 2, 2>;
+// 160 rows: the pixel x text correlation with the K = 150 ADE20K labels as GEMM rows (10 MFMA row-blocks, 6 % padding instead of
+// the 41 % of two 128-row tiles); 92 KB of rings, one workgroup per CU
+using CfgLab = TileCfg<160, 128, 2, 2, 2, 1>;
 using CfgSmall = TileCfg<64, 64, 2, 2, 2>;
 using CfgHuge = TileCfg<256, 256, 4, 2, 2, 1>;     // half the operand bytes per MFMA through the CU's L1 / LDS-DMA path of Mid
 // Row config: one workgroup owns complete 512-wide output rows (fused head1 + L2-norm + fp16 casts);
@@ -994,6 +1002,8 @@ int pick_tile(const GemmArgs& g, hipStream_t stream) {
     const long t_mid = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
     static const int force = getenv("LSEG_GEMM_TILE") ? atoi(getenv("LSEG_GEMM_TILE")) : 0;   // tools/tests: 1 = 64x64, 2 = 128x128, 6 = 256x256
     int pick = t_mid >= 192 ? 2 : 1;
+    if (EPI == EPI_GENERIC && !CONV && g.map_mode == MAP_LABELPLANES && g.M > 128 && g.M <= 160 && !force)
+        return launch_one<T, CfgLab, false, false, EPI_GENERIC, TAG>(g, stream);
     if (EPI != EPI_GENERIC && pick == 2) {
         // 256x256 tiles (one 8-wave workgroup per CU) move half the operand bytes per MFMA through the
         // CU's L1/LDS-DMA path and run ~12% faster per flop than two 128x128 workgroups -- when the

@@ -16,6 +16,9 @@ int launch_cls_rows(const float* cls, const float* pos, float* x, int B, int nto
 int launch_readout_cat(const float* x, void* A, int B, int ntok, int D, int dtype, hipStream_t st);
 int launch_upsample2x_nhwc(const void* in, void* out, int B, int H, int W, int C, int dtype, hipStream_t st);
 int launch_upsample2x_planes(const float* in, float* out, int P, int H, int W, hipStream_t st);
+int launch_combine_1x1(const float* wh, const float* bh, const float* wo, const float* bo, float* wc, float* bc, int Co, int Cm, int Ci,
+                       hipStream_t st);
+int launch_upsample_norm_f16(const float* g, void* a, int B, int H, int W, int C, float scale, hipStream_t st);
 int launch_l2norm_scale_f16(const float* f, void* a, int M, int C, float scale, hipStream_t st);
 int launch_text_embed(const int64_t* tok, const float* emb, const float* pos, void* x, int rows, int L, int ctx, int W, hipStream_t st);
 int launch_text_pool(const void* x, const int* eot, void* pooled, int K, int L, int W, hipStream_t st);

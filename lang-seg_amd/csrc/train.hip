@@ -331,8 +331,8 @@ int Engine::forward_train(const float* x_in, int B, float* logits, hipStream_t s
     TRY(launch_gemm(g, img_dt_, st));
     TRY(launch_l2norm_scale_f16(feat_, a16_, Mp, c.out_c, logit_scale, st));
     gemm_args_init(g);
-    g.A = a16_; g.W = tnorm_; g.M = Mp; g.N = K_; g.K = c.out_c; g.lda = c.out_c; g.ldw = c.out_c;
-    g.round_mid = 1; g.C = low_; g.out_dtype = DT_F32; g.map_mode = MAP_NCHW; g.p_div = hw1;
+    g.A = tnorm_; g.W = a16_; g.M = K_; g.N = Mp; g.K = c.out_c; g.lda = c.out_c; g.ldw = c.out_c;
+    g.round_mid = 1; g.C = low_; g.out_dtype = DT_F32; g.map_mode = MAP_LABELPLANES; g.p_div = hw1;
     TRY(launch_gemm(g, DT_F16, st));
     // the text features as the dgrad operand of the correlation: bf16, transposed, K padded to the GEMM's K-step
     const int Kp = (int)up64(K_);
