@@ -294,59 +294,67 @@ __global__ void combine_1x1_kernel(const float* __restrict__ wh, const float* __
         bc[co] = (float)(s + (double)bh[co]);
     }
 }
+// One wave per 2x2 block of OUTPUT pixels, visited back to back: with align_corners=True and scale (H-1)/(2H-1) < 1/2 their 16 taps
+// fall on a 3x3 input window, so 7 of the 16 tap reads (2 KB each at C = 512) are served by the CU's L1 instead of the L2 (a
+// pixel-per-wave schedule re-read every tap from L2: 8 KB per output pixel, L2-bandwidth-bound at 1.4 ms for B = 36).
 template <int NV>      // NV float4 pairs per lane: C = 512 -> NV = 1 (8 channels per lane), C = 768 -> 2 (lanes 0-31 only on the second)
 __global__ __launch_bounds__(256) void upsample_norm_f16_kernel(const float* __restrict__ g, uint16_t* __restrict__ a, int B, int H, int W,
                                                                 int C, float scale) {
     const int lane = threadIdx.x & 63;
     const int Ho = 2 * H, Wo = 2 * W;
-    const size_t npix = (size_t)B * Ho * Wo;
+    const size_t nblk = (size_t)B * H * W;
     const float ry = (float)(H - 1) / (float)(Ho - 1), rx = (float)(W - 1) / (float)(Wo - 1);
-    for (size_t pix = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); pix < npix; pix += (size_t)gridDim.x * 4) {
-        const int xo = (int)(pix % Wo);
-        const int yo = (int)((pix / Wo) % Ho);
-        const int b = (int)(pix / ((size_t)Wo * Ho));
-        const float sy = ry * (float)yo, sx = rx * (float)xo;
-        const int y0 = (int)sy, x0 = (int)sx;
-        const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
-        const float ly = sy - (float)y0, lx = sx - (float)x0;
-        const size_t rowp = (size_t)(W + 2) * C;
+    const size_t rowp = (size_t)(W + 2) * C;
+    for (size_t blk = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); blk < nblk; blk += (size_t)gridDim.x * 4) {
+        const int bx = (int)(blk % W);
+        const int by = (int)((blk / W) % H);
+        const int b = (int)(blk / ((size_t)W * H));
         const float* base = g + (size_t)b * (H + 2) * rowp;
-        const float* p00 = base + (size_t)(y0 + 1) * rowp + (size_t)(x0 + 1) * C;
-        const float* p01 = base + (size_t)(y0 + 1) * rowp + (size_t)(x1 + 1) * C;
-        const float* p10 = base + (size_t)(y1 + 1) * rowp + (size_t)(x0 + 1) * C;
-        const float* p11 = base + (size_t)(y1 + 1) * rowp + (size_t)(x1 + 1) * C;
-        float v[NV][8];
-        float s = 0.f;
+#pragma unroll 1
+        for (int d = 0; d < 4; ++d) {
+            const int yo = 2 * by + (d >> 1), xo = 2 * bx + (d & 1);
+            const float sy = ry * (float)yo, sx = rx * (float)xo;
+            const int y0 = (int)sy, x0 = (int)sx;
+            const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
+            const float ly = sy - (float)y0, lx = sx - (float)x0;
+            const float* p00 = base + (size_t)(y0 + 1) * rowp + (size_t)(x0 + 1) * C;
+            const float* p01 = base + (size_t)(y0 + 1) * rowp + (size_t)(x1 + 1) * C;
+            const float* p10 = base + (size_t)(y1 + 1) * rowp + (size_t)(x0 + 1) * C;
+            const float* p11 = base + (size_t)(y1 + 1) * rowp + (size_t)(x1 + 1) * C;
+            float v[NV][8];
+            float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = (lane + 64 * i) * 8;
-            if (c < C) {
+            for (int i = 0; i < NV; ++i) {
+                const int c = (lane + 64 * i) * 8;
+                if (c < C) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const float4 a00 = *reinterpret_cast<const float4*>(p00 + c + 4 * h), a01 = *reinterpret_cast<const float4*>(p01 + c + 4 * h);
-                    const float4 a10 = *reinterpret_cast<const float4*>(p10 + c + 4 * h), a11 = *reinterpret_cast<const float4*>(p11 + c + 4 * h);
-                    // same association as upsample_bilinear2d: (1-ly)*((1-lx)*v00 + lx*v01) + ly*((1-lx)*v10 + lx*v11)
-                    v[i][4 * h + 0] = (1.f - ly) * ((1.f - lx) * a00.x + lx * a01.x) + ly * ((1.f - lx) * a10.x + lx * a11.x);
-                    v[i][4 * h + 1] = (1.f - ly) * ((1.f - lx) * a00.y + lx * a01.y) + ly * ((1.f - lx) * a10.y + lx * a11.y);
-                    v[i][4 * h + 2] = (1.f - ly) * ((1.f - lx) * a00.z + lx * a01.z) + ly * ((1.f - lx) * a10.z + lx * a11.z);
-                    v[i][4 * h + 3] = (1.f - ly) * ((1.f - lx) * a00.w + lx * a01.w) + ly * ((1.f - lx) * a10.w + lx * a11.w);
+                    for (int h = 0; h < 2; ++h) {
+                        const float4 a00 = *reinterpret_cast<const float4*>(p00 + c + 4 * h), a01 = *reinterpret_cast<const float4*>(p01 + c + 4 * h);
+                        const float4 a10 = *reinterpret_cast<const float4*>(p10 + c + 4 * h), a11 = *reinterpret_cast<const float4*>(p11 + c + 4 * h);
+                        // same association as upsample_bilinear2d: (1-ly)*((1-lx)*v00 + lx*v01) + ly*((1-lx)*v10 + lx*v11)
+                        v[i][4 * h + 0] = (1.f - ly) * ((1.f - lx) * a00.x + lx * a01.x) + ly * ((1.f - lx) * a10.x + lx * a11.x);
+                        v[i][4 * h + 1] = (1.f - ly) * ((1.f - lx) * a00.y + lx * a01.y) + ly * ((1.f - lx) * a10.y + lx * a11.y);
+                        v[i][4 * h + 2] = (1.f - ly) * ((1.f - lx) * a00.z + lx * a01.z) + ly * ((1.f - lx) * a10.z + lx * a11.z);
+                        v[i][4 * h + 3] = (1.f - ly) * ((1.f - lx) * a00.w + lx * a01.w) + ly * ((1.f - lx) * a10.w + lx * a11.w);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) s += v[i][e] * v[i][e];
                 }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) s += v[i][e] * v[i][e];
             }
-        }
-        const float nrm = sqrtf(wave_sum(s));
+            const float nrm = sqrtf(wave_sum(s));
+            const size_t pix = ((size_t)b * Ho + yo) * Wo + xo;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = (lane + 64 * i) * 8;
-            if (c < C) {
-                uint32_t o[4];
+            for (int i = 0; i < NV; ++i) {
+                const int c = (lane + 64 * i) * 8;
+                if (c < C) {
+                    uint32_t o[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const uint32_t lo = f32_to_f16(scale * round_f16(v[i][2 * e] / nrm)), hi = f32_to_f16(scale * round_f16(v[i][2 * e + 1] / nrm));
-                    o[e] = lo | (hi << 16);
+                    for (int e = 0; e < 4; ++e) {
+                        const uint32_t lo = f32_to_f16(scale * round_f16(v[i][2 * e] / nrm)), hi = f32_to_f16(scale * round_f16(v[i][2 * e + 1] / nrm));
+                        o[e] = lo | (hi << 16);
+                    }
+                    *reinterpret_cast<uint4*>(a + pix * C + c) = make_uint4(o[0], o[1], o[2], o[3]);
                 }
-                *reinterpret_cast<uint4*>(a + pix * C + c) = make_uint4(o[0], o[1], o[2], o[3]);
             }
         }
     }
@@ -1268,8 +1276,8 @@ int launch_combine_1x1(const float* wh, const float* bh, const float* wo, const 
 }
 int launch_upsample_norm_f16(const float* g, void* a, int B, int H, int W, int C, float scale, hipStream_t st) {
     if (C % 8 != 0 || C > 1024) return set_error(LSEG_ERR_UNSUPPORTED, "upsample_norm: C=%d", C);
-    const size_t npix = (size_t)B * 4 * H * W;
-    const int blocks = (int)std::min<size_t>((npix + 3) / 4, 256 * 32);
+    const size_t nblk = (size_t)B * H * W;               // 2x2 output blocks, one per wave
+    const int blocks = (int)std::min<size_t>((nblk + 3) / 4, 256 * 32);
     if (C <= 512) hipLaunchKernelGGL(upsample_norm_f16_kernel<1>, dim3(blocks), dim3(256), 0, st, g, (uint16_t*)a, B, H, W, C, scale);
     else hipLaunchKernelGGL(upsample_norm_f16_kernel<2>, dim3(blocks), dim3(256), 0, st, g, (uint16_t*)a, B, H, W, C, scale);
     CHECK_LAUNCH();

@@ -62,6 +62,14 @@ _CONFIGS = {
         reassemble=(256, 512, 1024, 1024),
         resample=(("convT", 4), ("convT", 2), ("id", 0), ("conv_s2", 3)),
     ),
+    # lseg_vit.py:240-257 (ViT-L/16 image tower + the text tower of CLIP RN50x16: width 768, 12 heads) ; lseg_net.py:121,142-143 (out_c 768)
+    "clipRN50x16_vitl16_384": LSegConfig(
+        name="clipRN50x16_vitl16_384", patch=16, dim=1024, depth=24, heads=16,
+        hooks=(5, 11, 17, 23), pos_grid=24,
+        reassemble=(256, 512, 1024, 1024),
+        resample=(("convT", 4), ("convT", 2), ("id", 0), ("conv_s2", 3)),
+        out_c=768, text=TextConfig(width=768, heads=12, layers=12, embed_dim=768),
+    ),
     # lseg_vit.py:259-272 + 275-405 ; lseg_net.py:122
     "clip_vitb32_384": LSegConfig(
         name="clip_vitb32_384", patch=32, dim=768, depth=12, heads=12,

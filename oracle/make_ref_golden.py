@@ -39,6 +39,7 @@ REF_CASES = {
     "ref_vitb32_128x128_k7": ("clip_vitb32_384", 128, 128, 1, 7, 13, 0, 0),
     "ref_vitl16_96x96_k5_arch1": ("clip_vitl16_384", 96, 96, 1, 5, 14, 1, 2),
     "ref_vitl16_96x96_k5_arch2": ("clip_vitl16_384", 96, 96, 1, 5, 15, 2, 2),
+    "ref_vitl16rn50x16_96x96_k6": ("clipRN50x16_vitl16_384", 96, 96, 1, 6, 17, 0, 0),      # out_c = 768, text width 768
 }
 # BASELINE.json configs[1] and configs[4] run through the reference's own LSegNet.forward at full size (CPU, ~10 s and
 # ~2 min): `python oracle/make_ref_golden.py --full`.  Stored sub-sampled (the full logits are 138 MB / 922 MB).
@@ -147,6 +148,8 @@ def main():
             save_full_case(name, spec, gd)
         return
     for name, spec in REF_CASES.items():
+        if "--only" in sys.argv[1:] and name not in sys.argv[1:]:
+            continue
         cfg, sd, x, text, out, taps, acts = run_ref_case(spec)
         torch.save({"spec": spec, "tokens": text.clone(), "logits": out.clone(),
                     "text_features": taps["text_features"].to(torch.float16),
@@ -155,6 +158,8 @@ def main():
                    os.path.join(gd, name + ".pt"))
         print(name, tuple(out.shape), float(out.abs().mean()))
     for name, spec in REF_ZS_CASES.items():
+        if "--only" in sys.argv[1:]:
+            continue
         cfg, sd, x, tok, out = run_ref_zs_case(spec)
         torch.save({"spec": spec, "tokens": tok.clone(), "logits": out.clone()}, os.path.join(gd, name + ".pt"))
         print(name, tuple(out.shape), float(out.abs().mean()))

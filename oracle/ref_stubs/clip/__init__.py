@@ -107,7 +107,10 @@ def convert_weights(model):
     model.apply(_h)
 
 
-_TEXT_CFG = {"ViT-B/32": dict(embed_dim=512, width=512, heads=8, layers=12)}
+_TEXT_CFG = {"ViT-B/32": dict(embed_dim=512, width=512, heads=8, layers=12),
+             # CLIP RN50x16's text tower ([3P] clip/model.py build_model: transformer_width 768, heads = width // 64, 12 layers,
+             # embed_dim 768) -- what lseg_vit.py:243 loads for backbone "clipRN50x16_vitl16_384"
+             "RN50x16": dict(embed_dim=768, width=768, heads=12, layers=12)}
 
 
 def load(name, device="cpu", jit=False):
