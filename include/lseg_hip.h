@@ -246,6 +246,14 @@ int lseg_op_attention_backward(const void* d_q, const void* d_k, const void* d_v
                                const float* d_lse2, float* d_dq, float* d_dk, float* d_dv, int B, int H, int Ntok, int Npad,
                                int dtype, int causal, float scale, void* stream);
 
+/* The attention backward the training step runs (csrc/attention_bwd2.hip): same inputs, no mask, no atomics -- a dQ kernel and a
+ * dK/dV kernel in the forward kernel's MFMA / direct-to-LDS structure, writing d(qkv Linear output) [B*Ntok, 3*H*64] (bf16/fp16)
+ * directly.  d_ws: lseg_op_attention_backward_ws_bytes(B, H, Npad) bytes of device scratch, or NULL (then allocated per call). */
+size_t lseg_op_attention_backward_ws_bytes(int B, int H, int Npad);
+int lseg_op_attention_backward_qkv(const void* d_q, const void* d_k, const void* d_vt, const void* d_o, const void* d_do,
+                                   const float* d_lse2, void* d_dqkv, void* d_ws, int B, int H, int Ntok, int Npad, int dtype,
+                                   float scale, void* stream);
+
 /* d(qkv Linear output) [B*Ntok, 3*H*64] (bf16/fp16) from the attention backward's fp32 d_dq, d_dk, d_dv [BH,Npad,64]:
  * the inverse of the QKV GEMM epilogue's head-major scatter; feeds lseg_op_linear_backward of the qkv layer. */
 int lseg_op_qkv_grad_pack(const float* d_dq, const float* d_dk, const float* d_dv, void* d_dqkv, int B, int H, int Ntok, int Npad,

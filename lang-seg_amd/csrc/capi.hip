@@ -369,6 +369,25 @@ int lseg_op_attention_backward(const void* d_q, const void* d_k, const void* d_v
     return launch_attention_backward(d_q, d_k, d_vt, d_o, d_do, d_lse2, d_dq, d_dk, d_dv, B, H, Ntok, Npad, dt, causal, scale, (hipStream_t)stream);
 }
 
+size_t lseg_op_attention_backward_ws_bytes(int B, int H, int Npad) { return attention_backward_ws_bytes(B, H, Npad); }
+
+int lseg_op_attention_backward_qkv(const void* d_q, const void* d_k, const void* d_vt, const void* d_o, const void* d_do,
+                                   const float* d_lse2, void* d_dqkv, void* d_ws, int B, int H, int Ntok, int Npad, int dtype,
+                                   float scale, void* stream) {
+    int r = require_device(); if (r) return r;
+    int dt;
+    if ((r = op_dt(dtype, &dt))) return r;
+    if (!d_q || !d_k || !d_vt || !d_o || !d_do || !d_lse2 || !d_dqkv) return set_error(LSEG_ERR_INVALID, "attention_backward_qkv: NULL pointer");
+    if (B < 1 || H < 1 || Ntok < 1) return set_error(LSEG_ERR_INVALID, "attention_backward_qkv: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    void* ws = d_ws;
+    if (!ws && hipMallocAsync(&ws, attention_backward_ws_bytes(B, H, Npad), st) != hipSuccess)
+        return set_error(LSEG_ERR_HIP, "attention_backward_qkv: out of device memory");
+    r = launch_attention_backward_qkv(d_q, d_k, d_vt, d_o, d_do, d_lse2, d_dqkv, ws, B, H, Ntok, Npad, dt, scale, st);
+    if (!d_ws) (void)hipFreeAsync(ws, st);
+    return r;
+}
+
 int lseg_op_qkv_grad_pack(const float* d_dq, const float* d_dk, const float* d_dv, void* d_dqkv, int B, int H, int Ntok, int Npad,
                           int out_dtype, void* stream) {
     int r = require_device(); if (r) return r;

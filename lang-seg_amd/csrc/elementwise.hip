@@ -298,7 +298,7 @@ __global__ void combine_1x1_kernel(const float* __restrict__ wh, const float* __
 // fall on a 3x3 input window, so 7 of the 16 tap reads (2 KB each at C = 512) are served by the CU's L1 instead of the L2 (a
 // pixel-per-wave schedule re-read every tap from L2: 8 KB per output pixel, L2-bandwidth-bound at 1.4 ms for B = 36).
 template <int NV>      // NV float4 pairs per lane: C = 512 -> NV = 1 (8 channels per lane), C = 768 -> 2 (lanes 0-31 only on the second)
-__global__ __launch_bounds__(256) void upsample_norm_f16_kernel(const float* __restrict__ g, uint16_t* __restrict__ a, int B, int H, int W,
+__global__ __launch_bounds__(256, NV == 1 ? 3 : 2) void upsample_norm_f16_kernel(const float* __restrict__ g, uint16_t* __restrict__ a, int B, int H, int W,
                                                                 int C, float scale) {
     const int lane = threadIdx.x & 63;
     const int Ho = 2 * H, Wo = 2 * W;
@@ -311,49 +311,74 @@ __global__ __launch_bounds__(256) void upsample_norm_f16_kernel(const float* __r
         const int b = (int)(blk / ((size_t)W * H));
         const float* base = g + (size_t)b * (H + 2) * rowp;
 #pragma unroll 1
-        for (int d = 0; d < 4; ++d) {
-            const int yo = 2 * by + (d >> 1), xo = 2 * bx + (d & 1);
-            const float sy = ry * (float)yo, sx = rx * (float)xo;
-            const int y0 = (int)sy, x0 = (int)sx;
-            const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
-            const float ly = sy - (float)y0, lx = sx - (float)x0;
-            const float* p00 = base + (size_t)(y0 + 1) * rowp + (size_t)(x0 + 1) * C;
-            const float* p01 = base + (size_t)(y0 + 1) * rowp + (size_t)(x1 + 1) * C;
-            const float* p10 = base + (size_t)(y1 + 1) * rowp + (size_t)(x0 + 1) * C;
-            const float* p11 = base + (size_t)(y1 + 1) * rowp + (size_t)(x1 + 1) * C;
-            float v[NV][8];
-            float s = 0.f;
+        for (int dy = 0; dy < 2; ++dy) {
+            // both pixels of the row pair are in flight together (the kernel is latency-bound: 16 independent 16-byte loads per lane)
+            const int yo = 2 * by + dy;
+            const float sy = ry * (float)yo;
+            const int y0 = (int)sy, y1 = y0 + (y0 < H - 1);
+            const float ly = sy - (float)y0;
+            float v[2][NV][8], lxs[2];
+            const float* pr0 = base + (size_t)(y0 + 1) * rowp;
+            const float* pr1 = base + (size_t)(y1 + 1) * rowp;
+            float4 tp[2][NV][2][4];
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int c = (lane + 64 * i) * 8;
-                if (c < C) {
+            for (int dx = 0; dx < 2; ++dx) {
+                const float sx = rx * (float)(2 * bx + dx);
+                const int x0 = (int)sx, x1 = x0 + (x0 < W - 1);
+                lxs[dx] = sx - (float)x0;
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const float4 a00 = *reinterpret_cast<const float4*>(p00 + c + 4 * h), a01 = *reinterpret_cast<const float4*>(p01 + c + 4 * h);
-                        const float4 a10 = *reinterpret_cast<const float4*>(p10 + c + 4 * h), a11 = *reinterpret_cast<const float4*>(p11 + c + 4 * h);
-                        // same association as upsample_bilinear2d: (1-ly)*((1-lx)*v00 + lx*v01) + ly*((1-lx)*v10 + lx*v11)
-                        v[i][4 * h + 0] = (1.f - ly) * ((1.f - lx) * a00.x + lx * a01.x) + ly * ((1.f - lx) * a10.x + lx * a11.x);
-                        v[i][4 * h + 1] = (1.f - ly) * ((1.f - lx) * a00.y + lx * a01.y) + ly * ((1.f - lx) * a10.y + lx * a11.y);
-                        v[i][4 * h + 2] = (1.f - ly) * ((1.f - lx) * a00.z + lx * a01.z) + ly * ((1.f - lx) * a10.z + lx * a11.z);
-                        v[i][4 * h + 3] = (1.f - ly) * ((1.f - lx) * a00.w + lx * a01.w) + ly * ((1.f - lx) * a10.w + lx * a11.w);
+                for (int i = 0; i < NV; ++i) {
+                    const int c = (lane + 64 * i) * 8;
+                    if (c < C) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            tp[dx][i][h][0] = *reinterpret_cast<const float4*>(pr0 + (size_t)(x0 + 1) * C + c + 4 * h);
+                            tp[dx][i][h][1] = *reinterpret_cast<const float4*>(pr0 + (size_t)(x1 + 1) * C + c + 4 * h);
+                            tp[dx][i][h][2] = *reinterpret_cast<const float4*>(pr1 + (size_t)(x0 + 1) * C + c + 4 * h);
+                            tp[dx][i][h][3] = *reinterpret_cast<const float4*>(pr1 + (size_t)(x1 + 1) * C + c + 4 * h);
+                        }
                     }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) s += v[i][e] * v[i][e];
                 }
             }
-            const float nrm = sqrtf(wave_sum(s));
-            const size_t pix = ((size_t)b * Ho + yo) * Wo + xo;
+            float s2[2] = {0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const int c = (lane + 64 * i) * 8;
-                if (c < C) {
-                    uint32_t o[4];
+            for (int dx = 0; dx < 2; ++dx) {
+                const float lx = lxs[dx];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const uint32_t lo = f32_to_f16(scale * round_f16(v[i][2 * e] / nrm)), hi = f32_to_f16(scale * round_f16(v[i][2 * e + 1] / nrm));
-                        o[e] = lo | (hi << 16);
+                for (int i = 0; i < NV; ++i) {
+                    if ((lane + 64 * i) * 8 < C) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const float4 a00 = tp[dx][i][h][0], a01 = tp[dx][i][h][1], a10 = tp[dx][i][h][2], a11 = tp[dx][i][h][3];
+                            // same association as upsample_bilinear2d: (1-ly)*((1-lx)*v00 + lx*v01) + ly*((1-lx)*v10 + lx*v11)
+                            v[dx][i][4 * h + 0] = (1.f - ly) * ((1.f - lx) * a00.x + lx * a01.x) + ly * ((1.f - lx) * a10.x + lx * a11.x);
+                            v[dx][i][4 * h + 1] = (1.f - ly) * ((1.f - lx) * a00.y + lx * a01.y) + ly * ((1.f - lx) * a10.y + lx * a11.y);
+                            v[dx][i][4 * h + 2] = (1.f - ly) * ((1.f - lx) * a00.z + lx * a01.z) + ly * ((1.f - lx) * a10.z + lx * a11.z);
+                            v[dx][i][4 * h + 3] = (1.f - ly) * ((1.f - lx) * a00.w + lx * a01.w) + ly * ((1.f - lx) * a10.w + lx * a11.w);
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) s2[dx] += v[dx][i][e] * v[dx][i][e];
                     }
-                    *reinterpret_cast<uint4*>(a + pix * C + c) = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { s2[0] += __shfl_xor(s2[0], o); s2[1] += __shfl_xor(s2[1], o); }
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const float nrm = sqrtf(s2[dx]);
+                const size_t pix = ((size_t)b * Ho + yo) * Wo + 2 * bx + dx;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int c = (lane + 64 * i) * 8;
+                    if (c < C) {
+                        uint32_t o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const uint32_t lo = f32_to_f16(scale * round_f16(v[dx][i][2 * e] / nrm)), hi = f32_to_f16(scale * round_f16(v[dx][i][2 * e + 1] / nrm));
+                            o[e] = lo | (hi << 16);
+                        }
+                        *reinterpret_cast<uint4*>(a + pix * C + c) = make_uint4(o[0], o[1], o[2], o[3]);
+                    }
                 }
             }
         }

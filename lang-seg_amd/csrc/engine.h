@@ -176,7 +176,8 @@ private:
     size_t ws_a_n_ = 0, ws_b_n_ = 0;
     float* ws_dw_ = nullptr; size_t ws_dw_n_ = 0;   // wgrad output in the engine's packed layout before the re-layout into the parameter's
     float *ws_stats_ = nullptr, *zeros_ = nullptr, *ws_ln_ = nullptr;
-    float *gx_ = nullptr, *dq_ = nullptr, *dk_ = nullptr, *dv_ = nullptr, *dpos_ = nullptr, *logits_ = nullptr, *dlogits_ = nullptr;
+    float *gx_ = nullptr, *dpos_ = nullptr, *logits_ = nullptr, *dlogits_ = nullptr;
+    char* attn_ws_ = nullptr;              // per-layer scratch of the attention backward (transposed / head-major operand copies)
     uint16_t *g16_ = nullptr, *dmlp_ = nullptr, *dln_ = nullptr, *datt_ = nullptr, *dqkv_ = nullptr, *dtok_ = nullptr;
     uint16_t *drows_ = nullptr, *da_ = nullptr, *df_ = nullptr, *tnT_ = nullptr;
     unsigned long long* counts_ = nullptr; double* nll_ = nullptr;

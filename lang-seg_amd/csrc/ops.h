@@ -72,6 +72,10 @@ int launch_relu_split(const void* in, size_t in_plane, void* out, size_t out_pla
 int launch_attention_strict(const void* q, const void* k, const void* vt, void* out, size_t qk_plane, size_t vt_plane, size_t out_plane,
                             int B, int H, int ntok, int npad, float scale, hipStream_t st);
 
+size_t attention_backward_ws_bytes(int B, int H, int npad);
+int launch_attention_backward_qkv(const void* q, const void* k, const void* vt, const void* o, const void* d_o, const float* lse2, void* dqkv,
+                                  void* ws, int B, int H, int ntok, int npad, int dtype, float scale, hipStream_t stream);
+
 // ---- engine-level training step (train.hip) --------------------------------------------------------------------------------
 int launch_attention_lse(const void* q, const void* k, const void* vt, void* out, float* lse2, int B, int H, int ntok, int npad, int dtype,
                          int causal, float scale, hipStream_t stream);

@@ -153,7 +153,7 @@ int Engine::train_alloc() {
     TALLOC(zeros_, float, 16 * 1024);
     TALLOC(ws_ln_, float, (size_t)LN_BWD_PARTIAL_BLOCKS * 2 * D);
     TALLOC(gx_, float, M * D); TALLOC(dpos_, float, (size_t)ntok_ * D);
-    TALLOC(dq_, float, B * H * npad_ * 64); TALLOC(dk_, float, B * H * npad_ * 64); TALLOC(dv_, float, B * H * npad_ * 64);
+    TALLOC(attn_ws_, char, attention_backward_ws_bytes((int)B, (int)H, npad_));
     TALLOC(g16_, uint16_t, M * D); TALLOC(dmlp_, uint16_t, M * 4 * D); TALLOC(dln_, uint16_t, M * D); TALLOC(datt_, uint16_t, M * D);
     TALLOC(dqkv_, uint16_t, M * 3 * D); TALLOC(dtok_, uint16_t, Mr * D);
     const size_t hw1 = (size_t)4 * lh_[0] * lw_[0], Kp = up64(c.max_labels);
@@ -521,9 +521,7 @@ int Engine::block_backward(int i, int B, int acc, hipStream_t st) {
     // x_mid = x_in + proj(attention(qkv(LN1(x_in))))
     TRY(launch_convert(gx_, DT_F32, g16_, img_dt_, (size_t)M * D, st));
     TRY(lin_bwd(g16_, M, D, D, s.att, b.proj.wt, datt_, G("attn.proj.weight", (size_t)D * D), G("attn.proj.bias", D), acc, st));
-    LSEG_HIP_TRY(hipMemsetAsync(dq_, 0, (size_t)B * H * npad_ * 64 * sizeof(float), st));
-    TRY(launch_attention_backward(s.q, s.k, s.vt, s.att, datt_, s.lse, dq_, dk_, dv_, B, H, ntok_, npad_, img_dt_, 0, 0.125f, st));
-    TRY(launch_qkv_grad_pack(dq_, dk_, dv_, dqkv_, B, H, ntok_, npad_, img_dt_, st));
+    TRY(launch_attention_backward_qkv(s.q, s.k, s.vt, s.att, datt_, s.lse, dqkv_, attn_ws_, B, H, ntok_, npad_, img_dt_, 0.125f, st));
     TRY(lin_bwd(dqkv_, M, 3 * D, D, s.ln1, b.qkv.wt, dln_, G("attn.qkv.weight", (size_t)3 * D * D), G("attn.qkv.bias", 3 * D), acc, st));
     TRY(launch_layernorm_backward(dln_, img_dt_, s.xin, b.g1, gx_, dg1, db1, M, D, 1e-6f, 1, st, acc, ws_ln_));
     return 0;

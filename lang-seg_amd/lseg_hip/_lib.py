@@ -81,6 +81,8 @@ SIGNATURES = {
     "lseg_op_seg_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "lseg_op_linear_backward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "lseg_op_attention_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
+    "lseg_op_attention_backward_ws_bytes": (_sz, [_i, _i, _i]),
+    "lseg_op_attention_backward_qkv": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "lseg_op_quickgelu_backward": (_i, [_vp, _vp, _vp, C.c_int64, _i, _vp]),
     "lseg_op_bn_train_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "lseg_op_bn_train_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),

@@ -97,11 +97,9 @@ def test_vit_block_backward_through_the_bricks(B, N, H):
         dx1 = dy.clone()
         dg2, dbt2 = _ln_bwd(lib, d_ln2, x1.contiguous(), par["g2"], dx1)
         d_o, dwp, dbp = _lin_bwd(lib, dx1.to(BF), o2.contiguous(), wb["wp"])
-        dq, dk, dv = (torch.empty((B * H, Npad, 64), dtype=torch.float32, device="cuda") for _ in range(3))
-        _lib.check(lib.lseg_op_attention_backward(P(qp), P(kp), P(vt), P(o), P(d_o.reshape(B, N, D).contiguous()), P(lse2),
-                                                  P(dq), P(dk), P(dv), B, H, N, Npad, _lib.LSEG_BF16, 0, 0.125, _st()))
         d_qkv = torch.empty((M, 3 * D), dtype=BF, device="cuda")
-        _lib.check(lib.lseg_op_qkv_grad_pack(P(dq), P(dk), P(dv), P(d_qkv), B, H, N, Npad, _lib.LSEG_BF16, _st()))
+        _lib.check(lib.lseg_op_attention_backward_qkv(P(qp), P(kp), P(vt), P(o), P(d_o.reshape(B, N, D).contiguous()), P(lse2),
+                                                      P(d_qkv), None, B, H, N, Npad, _lib.LSEG_BF16, 0.125, _st()))
         d_ln1, dwqkv, dbqkv = _lin_bwd(lib, d_qkv, ln1, wb["wqkv"])
         dx = dx1.clone()
         dg1, dbt1 = _ln_bwd(lib, d_ln1, x.contiguous(), par["g1"], dx)

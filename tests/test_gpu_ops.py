@@ -386,6 +386,39 @@ def test_attention_backward(lib, dtype, B, H, N, causal):
     assert dk[:, N:((N + 63) // 64) * 64].abs().max().item() == 0 if N % 64 else True      # masked keys get no gradient
 
 
+@pytest.mark.parametrize("dtype,B,H,N", [(torch.bfloat16, 1, 2, 130), (torch.float16, 2, 3, 64), (torch.bfloat16, 1, 2, 901),
+                                          (torch.bfloat16, 2, 1, 37), (torch.bfloat16, 3, 4, 257)])
+def test_attention_backward_qkv(lib, dtype, B, H, N):
+    """The attention backward the training step runs (csrc/attention_bwd2.hip: dQ kernel + dK/dV kernel, no atomics, output written
+    straight as d(qkv Linear output) [B*N, 3*H*64]) against torch autograd in fp32 on the same 16-bit-rounded q, k, v."""
+    Npad = ((N + 127) // 128) * 128
+    D = H * 64
+    q, k, v = rnd((B, H, N, 64), dtype, 70), rnd((B, H, N, 64), dtype, 71), rnd((B, H, N, 64), dtype, 72)
+    d_o = rnd((B, N, D), dtype, 73)
+    qp = torch.zeros((B * H, Npad, 64), dtype=dtype).cuda(); qp[:, :N] = q.reshape(B * H, N, 64)
+    kp = torch.zeros((B * H, Npad, 64), dtype=dtype).cuda(); kp[:, :N] = k.reshape(B * H, N, 64)
+    vt = torch.zeros((B * H, 64, Npad), dtype=dtype).cuda(); vt[:, :, :N] = v.reshape(B * H, N, 64).transpose(1, 2)
+    out = torch.zeros((B, N, D), dtype=dtype).cuda()
+    _lib.check(lib.lseg_op_attention(P(qp), P(kp), P(vt), P(out), B, H, N, Npad, DT[dtype], 0, 0.125, stream()))
+    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
+    s = (qr @ kr.transpose(-1, -2)) * 0.125
+    ref = (s.softmax(-1) @ vr).transpose(1, 2).reshape(B, N, D)
+    ref.backward(d_o.float())
+    lse2 = torch.zeros((B * H, Npad), dtype=torch.float32).cuda()
+    lse2[:, :N] = (torch.logsumexp(s.detach(), dim=-1) * 1.4426950408889634).reshape(B * H, N)
+    dqkv = torch.full((B * N, 3 * D), float("nan"), dtype=dtype).cuda()
+    assert lib.lseg_op_attention_backward_ws_bytes(B, H, Npad) >= 5 * B * H * Npad * 64 * 2
+    _lib.check(lib.lseg_op_attention_backward_qkv(P(qp), P(kp), P(vt), P(out), P(d_o), P(lse2), P(dqkv), None, B, H, N, Npad,
+                                                  DT[dtype], 0.125, stream()))
+    torch.cuda.synchronize()
+    got = dqkv.float().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)             # [3, B, H, N, 64]
+    tol = 3e-2 if dtype == torch.bfloat16 else 6e-3
+    for i, (want, name) in enumerate(((qr.grad, "dq"), (kr.grad, "dk"), (vr.grad, "dv"))):
+        err = (got[i] - want).abs().max().item()
+        rel = ((got[i] - want).norm() / want.norm()).item()
+        assert math.isfinite(err) and err <= tol * max(1.0, want.abs().max().item()) and rel <= tol, (name, err, rel)
+
+
 @pytest.mark.parametrize("B,H,W,Cc", [(2, 15, 15, 64), (1, 12, 20, 256)])
 def test_batchnorm_train_forward_backward(lib, B, H, W, Cc):
     """Train-mode BatchNorm2d (batch statistics, biased variance) on the padded-NHWC bf16 maps and its backward against
