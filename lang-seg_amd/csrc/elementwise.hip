@@ -675,6 +675,38 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __rest
         if (c < C && r < ldo) out[(size_t)c * ldo + r] = t[rr][cc];
     }
 }
+// the same with 16-byte accesses on both sides (C, ldi, ldo multiples of 8): a thread loads 8 consecutive columns of a row and stores 8
+// consecutive rows of a column; the 2-byte shuffling happens in LDS
+__global__ __launch_bounds__(256) void transpose16_vec_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
+                                                             int R, int C, int ldi, int ldo, int shift, int relu) {
+    __shared__ uint16_t t[64][72];
+    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = threadIdx.x + k * 256;
+        const int rr = i >> 3, c8 = (i & 7) * 8, r = r0 + rr + shift, c = c0 + c8;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (r >= 0 && r < R && c < C) v = *reinterpret_cast<const uint4*>(in + (size_t)r * ldi + c);
+        if (relu) {
+            uint32_t* w = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = ((w[e] & 0x8000u) ? 0u : (w[e] & 0xffffu)) | ((w[e] & 0x80000000u) ? 0u : (w[e] & 0xffff0000u));
+        }
+        *reinterpret_cast<uint4*>(&t[rr][c8]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = threadIdx.x + k * 256;
+        const int cc = i >> 3, r8 = (i & 7) * 8, c = c0 + cc, r = r0 + r8;
+        if (c < C && r < ldo) {
+            uint32_t w[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = (uint32_t)t[r8 + 2 * e][cc] | ((uint32_t)t[r8 + 2 * e + 1][cc] << 16);
+            *reinterpret_cast<uint4*>(out + (size_t)c * ldo + r) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+}
 // 3x3 conv dgrad weights: Wd[ci, t', co] = Wp[co, 8 - t', ci]  (taps flipped, channels swapped) so that
 // dX = conv3x3(dY, Wd) runs on the forward implicit-GEMM kernel.  Wp [Co, 9, Ci] tap-major (16-bit).
 __global__ void conv_dgrad_pack_kernel(const uint16_t* __restrict__ wp, uint16_t* __restrict__ wd, int Co, int Ci) {
@@ -974,13 +1006,32 @@ __global__ __launch_bounds__(256) void colsum16_kernel(const uint16_t* __restric
         atomicAdd(&out[c], t);
     }
 }
-// dst[c] (+)= sum over the nb partial rows of src [nb, ld] (fixed order: deterministic)
-__global__ void colreduce_kernel(const float* __restrict__ src, float* __restrict__ dst, int nb, int C, int ld, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// dst[c] (+)= sum over the nb partial rows of src [nb, ld] (fixed order: deterministic).  Block = 64 columns x 4 row lanes.
+__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ src, float* __restrict__ dst, int nb, int C, int ld, int accumulate) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int r = 0; r < nb; ++r) s += src[(size_t)r * ld + c];
-    dst[c] = accumulate ? dst[c] + s : s;
+    if (c < C)
+        for (int r = rl; r < nb; r += 4) s += src[(size_t)r * ld + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        const float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        dst[c] = accumulate ? dst[c] + t : t;
+    }
+}
+// split-K partial results [nsplit][n] -> dst[n] (+)= sum_s part[s][n]   (n % 4 == 0; 16 bytes per lane)
+__global__ void sum_partials_kernel(const float* __restrict__ part, float* __restrict__ dst, int nsplit, size_t n4, size_t stride4, int accumulate) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 a = reinterpret_cast<const float4*>(part)[i];
+        for (int s = 1; s < nsplit; ++s) {
+            const float4 b = reinterpret_cast<const float4*>(part)[(size_t)s * stride4 + i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        if (accumulate) { const float4 d = reinterpret_cast<float4*>(dst)[i]; a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w; }
+        reinterpret_cast<float4*>(dst)[i] = a;
+    }
 }
 
 // ---- segmentation statistics on device -------------------------------------------------------------------------------
@@ -1176,11 +1227,13 @@ __global__ void pos_resize_bwd_kernel(const float* __restrict__ dpos, float* __r
 //   conv3x3  : dw tap-major [Co_p, 9, Ci_p] -> OIHW [Co, Ci, 3, 3]
 //   convT k=s: dw [(i*s+j)*Cp + co, Cp(ci)] -> [Ci, Co, s, s]          (ConvTranspose2d weight layout, lseg_vit.py:457-466)
 //   fold     : dst[c] (+)= sum_r src[r*ld + c], r < R                    (ConvTranspose bias: the s*s column groups share one bias)
-__global__ void conv_wgrad_unpack_kernel(const float* __restrict__ dw, float* __restrict__ dst, int Co, int Ci, int Cip, int accumulate) {
+__global__ void conv_wgrad_unpack_kernel(const float* __restrict__ dw, float* __restrict__ dst, int Co, int Ci, int Cip, int accumulate,
+                                         int nsplit, size_t split_stride) {
     const size_t n = (size_t)Co * Ci * 9;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int t = (int)(i % 9), ci = (int)((i / 9) % Ci), co = (int)(i / ((size_t)9 * Ci));
-        const float v = dw[((size_t)co * 9 + t) * Cip + ci];
+        float v = 0.f;
+        for (int s = 0; s < nsplit; ++s) v += dw[(size_t)s * split_stride + ((size_t)co * 9 + t) * Cip + ci];     // split-K partials
         dst[i] = accumulate ? dst[i] + v : v;
     }
 }
@@ -1392,8 +1445,8 @@ int launch_layernorm_backward(const void* dy, int dy_dtype, const float* x, cons
 #undef LN_BWD
     CHECK_LAUNCH();
     if (partial_ws) {
-        hipLaunchKernelGGL(colreduce_kernel, dim3((D + 255) / 256), dim3(256), 0, st, partial_ws, dgamma, blocks, D, 2 * D, accumulate_params);
-        hipLaunchKernelGGL(colreduce_kernel, dim3((D + 255) / 256), dim3(256), 0, st, partial_ws + D, dbeta, blocks, D, 2 * D, accumulate_params);
+        hipLaunchKernelGGL(colreduce_kernel, dim3((D + 63) / 64), dim3(256), 0, st, partial_ws, dgamma, blocks, D, 2 * D, accumulate_params);
+        hipLaunchKernelGGL(colreduce_kernel, dim3((D + 63) / 64), dim3(256), 0, st, partial_ws + D, dbeta, blocks, D, 2 * D, accumulate_params);
         CHECK_LAUNCH();
     }
     return 0;
@@ -1401,7 +1454,10 @@ int launch_layernorm_backward(const void* dy, int dy_dtype, const float* x, cons
 
 int launch_transpose16(const void* in, void* out, int R, int C, int ldi, int ldo, hipStream_t st, int shift, int relu) {
     dim3 grid((ldo + 63) / 64, (C + 63) / 64);
-    hipLaunchKernelGGL(transpose16_kernel, grid, dim3(256), 0, st, (const uint16_t*)in, (uint16_t*)out, R, C, ldi, ldo, shift, relu);
+    if (!(C & 7) && !(ldi & 7) && !(ldo & 7) && !((uintptr_t)in & 15) && !((uintptr_t)out & 15))
+        hipLaunchKernelGGL(transpose16_vec_kernel, grid, dim3(256), 0, st, (const uint16_t*)in, (uint16_t*)out, R, C, ldi, ldo, shift, relu);
+    else
+        hipLaunchKernelGGL(transpose16_kernel, grid, dim3(256), 0, st, (const uint16_t*)in, (uint16_t*)out, R, C, ldi, ldo, shift, relu);
     CHECK_LAUNCH();
     return 0;
 }
@@ -1569,8 +1625,15 @@ int launch_pos_resize_bwd(const float* dpos, float* dposemb, float* dcls, int g_
     CHECK_LAUNCH();
     return 0;
 }
-int launch_conv_wgrad_unpack(const float* dw, float* dst, int Co, int Ci, int Cip, int accumulate, hipStream_t st) {
-    hipLaunchKernelGGL(conv_wgrad_unpack_kernel, dim3(grid_for((size_t)Co * Ci * 9)), dim3(256), 0, st, dw, dst, Co, Ci, Cip, accumulate);
+int launch_sum_partials(const float* part, float* dst, int nsplit, size_t n, size_t stride, int accumulate, hipStream_t st) {
+    if ((n & 3) || (stride & 3)) return set_error(LSEG_ERR_INVALID, "sum_partials: n and stride must be multiples of 4");
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(grid_for(n / 4)), dim3(256), 0, st, part, dst, nsplit, n / 4, stride / 4, accumulate);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_conv_wgrad_unpack(const float* dw, float* dst, int Co, int Ci, int Cip, int accumulate, hipStream_t st, int nsplit, size_t split_stride) {
+    hipLaunchKernelGGL(conv_wgrad_unpack_kernel, dim3(grid_for((size_t)Co * Ci * 9)), dim3(256), 0, st, dw, dst, Co, Ci, Cip, accumulate,
+                       nsplit, split_stride);
     CHECK_LAUNCH();
     return 0;
 }

@@ -97,6 +97,7 @@ private:
                 int acc, hipStream_t st, int dw_rows = -1);
     int conv_bwd(const uint16_t* dy_pad, const uint16_t* x_pad, int relu_x, const Lin& w, uint16_t* dx_pad, float* dw_dst, int B, int H,
                  int W, int Cin, int Cout, int Ci_real, int Co_real, int acc, hipStream_t st);
+    int pick_split(int M, int N, int nk, GemmArgs& g);
     int block_backward(int i, int B, int acc, hipStream_t st);
     int readout_backward(int l, int B, int acc, hipStream_t st);
     int reassemble_backward(int l, int B, int acc, hipStream_t st);
@@ -174,6 +175,7 @@ private:
     float* last_logits_ = nullptr;
     uint16_t *ws_a_ = nullptr, *ws_b_ = nullptr;    // transposed operands of the wgrad GEMMs
     size_t ws_a_n_ = 0, ws_b_n_ = 0;
+    float* ws_part_ = nullptr; size_t ws_part_n_ = 0;   // split-K partial results of the weight-gradient GEMMs
     float* ws_dw_ = nullptr; size_t ws_dw_n_ = 0;   // wgrad output in the engine's packed layout before the re-layout into the parameter's
     float *ws_stats_ = nullptr, *zeros_ = nullptr, *ws_ln_ = nullptr;
     float *gx_ = nullptr, *dpos_ = nullptr, *logits_ = nullptr, *dlogits_ = nullptr;

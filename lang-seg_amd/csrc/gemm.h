@@ -59,6 +59,12 @@ struct GemmArgs {
     int split;                  // 0 off, 1 on
     size_t a_plane, w_plane;    // element offset of the lo plane of A / W
     size_t c_plane, ck_plane, cv_plane, res_plane;   // lo planes of C / Ck / Cv / res (and res2)
+    // ---- split-K: the K-steps are cut into `nsplit` ranges of `split_steps` (64-wide) steps; range s of every output tile is its own
+    // work item and writes a PARTIAL result at C + s * c_split_stride (the caller sums the partials).  For contractions with a small
+    // output and a huge K (weight gradients: [256 x 2304] over K = 119,072): fills the chip with 128x128 tiles instead of 64x64 ones,
+    // whose operand bytes per flop are twice as high on the per-CU L2->LDS path.  Needs bias == NULL, no residual, MAP_LINEAR.
+    int nsplit, split_steps;
+    size_t c_split_stride;
 };
 
 void gemm_args_init(GemmArgs& g);

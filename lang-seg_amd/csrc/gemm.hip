@@ -260,9 +260,10 @@ __device__ __forceinline__ bool epilogue_cols(const GemmArgs& g, int n_first, in
 template <typename T, int NI>
 __device__ __forceinline__ void epilogue_row(const GemmArgs& g, int m, const int (&ncol)[NI], const ColPart (&cp)[NI],
                                              const ColPart (&cpw)[NI / 2], bool wide, const float4 (&bias)[NI],
-                                             f32x4_t (&acc)[NI]) {
+                                             f32x4_t (&acc)[NI], size_t c_extra) {
     size_t r0, r1;
     row_part(g, m, r0, r1);
+    r0 += c_extra;                                   // split-K: this work item's partial-result slab
     size_t rres = 0;
     if (g.res_mode == RES_PERIODIC) rres = (size_t)((m % g.p_div) + g.p_off) * g.ldr;
     const bool fast = (g.N % 4) == 0;          // every group of 4 columns is fully in range
@@ -618,7 +619,9 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
     // panels).  Tiles are n-fastest.
     const int tiles_n = (g.N + BN - 1) / BN;
     const int tiles_m = (g.M + BM - 1) / BM;
-    const int total = tiles_m * tiles_n;
+    const int per_split = tiles_m * tiles_n;             // output tiles; with split-K every (tile, K-range) pair is a work item
+    const int nsplit = g.nsplit > 1 ? g.nsplit : 1;
+    const int total = per_split * nsplit;
     const int wpx = gridDim.x >> 3;                       // gridDim.x is a multiple of 8
     int tile, tile_end;
     {
@@ -636,7 +639,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
     const int lrow = lane >> 3;                           // row inside an 8-row slab
     auto setup_a = [&](int t) {
         int mb, nb;
-        tile_coords(t, tiles_m, tiles_n, mb, nb, g.group_m);
+        tile_coords(t % per_split, tiles_m, tiles_n, mb, nb, g.group_m);
         const int m0 = mb * BM;
 #pragma unroll
         for (int s = 0; s < A_SPW; ++s) {
@@ -657,7 +660,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
     };
     auto setup_w = [&](int t) {
         int mb, nb;
-        tile_coords(t, tiles_m, tiles_n, mb, nb, g.group_m);
+        tile_coords(t % per_split, tiles_m, tiles_n, mb, nb, g.group_m);
         const int n0 = nb * BN;
 #pragma unroll
         for (int s = 0; s < W_SPW; ++s) {
@@ -674,8 +677,11 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
     constexpr int W_RING_OFF = CFG::A_RING * A_BYTES;
     // After the last tile a cursor keeps re-issuing that tile (never consumed): every step issues exactly
     // SPW loads per wave, so the counted vmcnt stays exact.
-    int atile = tile, akt = 0, aslot = 0, aseg = 0;
-    int wtile = tile, wkt = 0, wslot = 0, wseg = 0;
+    // K-step range of a work item: everything without split-K, [s * split_steps, ...) with it
+    auto k_beg = [&](int t) { return nsplit > 1 ? (t / per_split) * g.split_steps : 0; };
+    auto k_end = [&](int t) { const int e = nsplit > 1 ? (t / per_split + 1) * g.split_steps : nk; return e < nk ? e : nk; };
+    int atile = tile, akt = k_beg(tile), aend = k_end(tile), aslot = 0, aseg = 0;
+    int wtile = tile, wkt = akt, wend = aend, wslot = 0, wseg = 0;
     setup_a(atile);
     setup_w(wtile);
     const char *abase = nullptr, *wbase = nullptr;        // source bases of the K-steps the cursors point at
@@ -692,24 +698,26 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
     };
     auto advance_a = [&]() {
         aslot = aslot + 1 == CFG::A_RING ? 0 : aslot + 1;
-        if (++akt == nk) {
-            akt = 0;
+        if (++akt == aend) {
             if (++aseg == nseg) {
                 aseg = 0;
                 if (atile + wpx < tile_end) atile += wpx;
                 setup_a(atile);
+                aend = k_end(atile);
             }
+            akt = k_beg(atile);
         }
     };
     auto advance_w = [&]() {
         wslot ^= 1;
-        if (++wkt == nk) {
-            wkt = 0;
+        if (++wkt == wend) {
             if (++wseg == nseg) {
                 wseg = 0;
                 if (wtile + wpx < tile_end) wtile += wpx;
                 setup_w(wtile);
+                wend = k_end(wtile);
             }
+            wkt = k_beg(wtile);
         }
     };
     // One issue GROUP = the W panel at the W cursor, then the A panel at the A cursor (one K-step further on);
@@ -860,7 +868,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
         int pm0, pn0;
         {   // this tile's origin and, for the specialised epilogues, its bias (consumed after the K-loop)
             int mbc, nbc;
-            tile_coords(tile, tiles_m, tiles_n, mbc, nbc, g.group_m);
+            tile_coords(tile % per_split, tiles_m, tiles_n, mbc, nbc, g.group_m);
             pm0 = mbc * BM; pn0 = nbc * BN;
             if constexpr (EPI != EPI_GENERIC && BIAS_PREFETCH) {
 #pragma unroll
@@ -872,7 +880,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
         for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < MI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < nk * nseg; ++kt) step();
+        for (int kt = (k_end(tile) - k_beg(tile)) * nseg; kt > 0; --kt) step();
         // ---- epilogue: the next tile's first K-step is already in flight / in registers
         unsigned long long te0 = 0;
         if ((g.dbg & 4)) te0 = __builtin_readcyclecounter();
@@ -955,7 +963,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
             });
             const int m = m0c + wm * WM + j * 16 + (lane & 15);
             if ((g.dbg & 3) == 2) { asm volatile("" ::"v"(row[0][0]), "v"(row[NI - 1][3])); continue; }
-            if (m < g.M) epilogue_row<T, NI>(g, m, ncol, cp, cpw, wide, bias, row);
+            if (m < g.M) epilogue_row<T, NI>(g, m, ncol, cp, cpw, wide, bias, row, nsplit > 1 ? (size_t)(tile / per_split) * g.c_split_stride : 0);
         }
         }
         }
@@ -972,7 +980,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
 
 template <typename T, typename CFG, bool CONV, bool RELU_IN, int EPI, int TAG>
 int launch_one(const GemmArgs& g, hipStream_t stream) {
-    const int tiles = ((g.M + CFG::BM - 1) / CFG::BM) * ((g.N + CFG::BN - 1) / CFG::BN);
+    const int tiles = ((g.M + CFG::BM - 1) / CFG::BM) * ((g.N + CFG::BN - 1) / CFG::BN) * (g.nsplit > 1 ? g.nsplit : 1);
     const size_t lds = CFG::LDS + (CFG::BN == 512 ? 1024 : 0);
     // persistent grid: a multiple of 8 (one slice per XCD), at most `slots` resident workgroups
     constexpr int by_lds = 163840 / CFG::LDS, by_waves = 8 / (CFG::NW / 4);
@@ -999,7 +1007,7 @@ int launch_one(const GemmArgs& g, hipStream_t stream) {
 
 template <typename T, bool CONV, bool RELU_IN, int EPI, int TAG>
 int pick_tile(const GemmArgs& g, hipStream_t stream) {
-    const long t_mid = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+    const long t_mid = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.nsplit > 1 ? g.nsplit : 1);
     static const int force = getenv("LSEG_GEMM_TILE") ? atoi(getenv("LSEG_GEMM_TILE")) : 0;   // tools/tests: 1 = 64x64, 2 = 128x128, 6 = 256x256
     int pick = t_mid >= 192 ? 2 : 1;
     if (EPI == EPI_GENERIC && !CONV && g.map_mode == MAP_LABELPLANES && g.M > 128 && g.M <= 160 && !force)
@@ -1028,7 +1036,7 @@ template <typename T>
 int select_epi(const GemmArgs& g) {
     constexpr int dt = std::is_same<T, BF16>::value ? DT_BF16 : DT_F16;
     static const bool off = getenv("LSEG_GEMM_GENERIC_EPI") != nullptr;       // A/B switch (tools)
-    if (off || g.split || (g.dbg & 3) || !g.bias || g.bias_mod || g.round_mid || (g.N % 128) != 0) return EPI_GENERIC;
+    if (off || g.split || g.nsplit > 1 || (g.dbg & 3) || !g.bias || g.bias_mod || g.round_mid || (g.N % 128) != 0) return EPI_GENERIC;
     if (g.res2 && !(g.dbg & 4) && g.map_mode != MAP_PADDED) return EPI_GENERIC;
     if ((reinterpret_cast<uintptr_t>(g.C) & 15) || (reinterpret_cast<uintptr_t>(g.bias) & 15)) return EPI_GENERIC;
     if (g.map_mode == MAP_PADDED && g.out_dtype == dt && (g.ldc % 8) == 0 && (g.act == ACT_NONE || g.act == ACT_RELU) &&
@@ -1093,6 +1101,9 @@ int launch_gemm(const GemmArgs& g_in, int ab_dtype, hipStream_t stream) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return set_error(LSEG_ERR_INVALID, "gemm: empty problem %dx%dx%d", g.M, g.N, g.K);
     if (g.K % 64 != 0) return set_error(LSEG_ERR_UNSUPPORTED, "gemm: K=%d must be a multiple of 64", g.K);
     if (g.conv && (g.cin % 64 != 0)) return set_error(LSEG_ERR_UNSUPPORTED, "conv: Cin=%d must be a multiple of 64", g.cin);
+    if (g.nsplit > 1 && (g.bias || g.res_mode != RES_NONE || g.map_mode != MAP_LINEAR || g.split || g.split_steps < 1 ||
+                         (long)g.nsplit * g.split_steps < (g.K >> 6) || (long)(g.nsplit - 1) * g.split_steps >= (g.K >> 6)))
+        return set_error(LSEG_ERR_INVALID, "split-K: needs a plain MAP_LINEAR GEMM without bias / residual and ranges that tile K exactly");
     if (g.split && g.relu_in) return set_error(LSEG_ERR_UNSUPPORTED, "split precision: ReLU on the A fragments is not representable (materialise relu(A))");
     if ((g.lda % 8) || (g.ldw % 8)) return set_error(LSEG_ERR_UNSUPPORTED, "gemm: lda/ldw must be multiples of 8 elements");
     {   // per-lane source offsets are 32-bit byte offsets

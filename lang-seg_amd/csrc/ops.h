@@ -94,7 +94,8 @@ int launch_unpixshuf(const void* dl, void* dg, int B, int gh, int gw, int s, int
 int launch_readout_cat_bwd(const void* dcat, float* gx, int B, int ntok, int D, int dtype, hipStream_t st);
 int launch_embed_bwd(const float* gx, void* dtok, float* dpos, int B, int ntok, int D, int dtype, hipStream_t st);
 int launch_pos_resize_bwd(const float* dpos, float* dposemb, float* dcls, int g_old, int gh, int gw, int D, hipStream_t st);
-int launch_conv_wgrad_unpack(const float* dw, float* dst, int Co, int Ci, int Cip, int accumulate, hipStream_t st);
+int launch_conv_wgrad_unpack(const float* dw, float* dst, int Co, int Ci, int Cip, int accumulate, hipStream_t st, int nsplit = 1, size_t split_stride = 0);
+int launch_sum_partials(const float* part, float* dst, int nsplit, size_t n, size_t stride, int accumulate, hipStream_t st);
 int launch_convT_wgrad_unpack(const float* dw, float* dst, int C, int Cp, int s, int accumulate, hipStream_t st);
 int launch_fold_rows(const float* src, float* dst, int R, int C, int ld, int accumulate, hipStream_t st);
 int launch_sgd(float* w, const float* g, float* m, void* w16, size_t n, float lr, float mu, float wd, int first, int dtype, hipStream_t st);

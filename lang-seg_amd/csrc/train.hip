@@ -149,6 +149,8 @@ int Engine::train_alloc() {
     TALLOC(dpath0_, uint16_t, B * 4 * lh_[0] * lw_[0] * F);
     ws_a_n_ = wsa; ws_b_n_ = wsb; ws_dw_n_ = wdw;
     TALLOC(ws_a_, uint16_t, wsa); TALLOC(ws_b_, uint16_t, wsb); TALLOC(ws_dw_, float, wdw);
+    ws_part_n_ = (size_t)16 << 20;                   // 64 MB of fp32 split-K partials
+    TALLOC(ws_part_, float, ws_part_n_);
     TALLOC(ws_stats_, float, 2 * std::max<size_t>(F, 16 * 1024));
     TALLOC(zeros_, float, 16 * 1024);
     TALLOC(ws_ln_, float, (size_t)LN_BWD_PARTIAL_BLOCKS * 2 * D);
@@ -346,6 +348,21 @@ int Engine::forward_train(const float* x_in, int B, float* logits, hipStream_t s
     return 0;
 }
 
+// split-K plan of a weight-gradient GEMM [M x N] over nk K-steps: enough (tile, K-range) work items to fill the chip twice with
+// 128x128 tiles, ranges of at least 8 K-steps, partials within the workspace.  Fills g.nsplit / g.split_steps; returns the split count.
+int Engine::pick_split(int M, int N, int nk, GemmArgs& g) {
+    const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
+    long ns = (2L * 256 + tiles - 1) / tiles;
+    if (ns > nk / 8) ns = nk / 8;
+    while (ns > 1 && (size_t)ns * M * N > ws_part_n_) --ns;
+    if (ns <= 1) return 1;
+    const int steps = (int)((nk + ns - 1) / ns);
+    ns = (nk + steps - 1) / steps;                  // every range non-empty, the last one possibly shorter
+    if (ns <= 1) return 1;
+    g.nsplit = (int)ns; g.split_steps = steps;
+    return (int)ns;
+}
+
 // ---- Linear backward on the forward MFMA kernel (contraction dimension transposed onto the fast axis) ---------------------------
 //   dx [M,K] = dy [M,N] . W [N,K]     (A = dy, "weights" = wt = W^T [K,N])
 //   dw [N,K] = dy^T . x               (A = dy^T [N,Mp], "weights" = x^T [K,Mp]; fp32, written in the parameter's own layout)
@@ -367,8 +384,15 @@ int Engine::lin_bwd(const uint16_t* dy, int M, int N, int K, const uint16_t* x, 
         gemm_args_init(g);
         g.A = ws_a_; g.W = ws_b_; g.M = dw_rows > 0 ? dw_rows : N; g.N = K; g.K = Mp; g.lda = Mp; g.ldw = Mp;
         g.C = dw; g.out_dtype = DT_F32; g.ldc = K; g.map_mode = MAP_LINEAR;
-        if (acc) { g.res_mode = RES_DEST; g.res = dw; g.res_dtype = DT_F32; }
-        TRY(launch_gemm(g, img_dt_, st));
+        const int ns = pick_split(g.M, g.N, Mp / 64, g);
+        if (ns > 1) {      // small output, long contraction: split-K partials, summed (and accumulated) afterwards
+            g.C = ws_part_; g.c_split_stride = (size_t)g.M * K;
+            TRY(launch_gemm(g, img_dt_, st));
+            TRY(launch_sum_partials(ws_part_, dw, ns, (size_t)g.M * K, g.c_split_stride, acc, st));
+        } else {
+            if (acc) { g.res_mode = RES_DEST; g.res = dw; g.res_dtype = DT_F32; }
+            TRY(launch_gemm(g, img_dt_, st));
+        }
     }
     if (db) TRY(launch_colsum16(dy, img_dt_, db, M, dw_rows > 0 ? dw_rows : N, N, st, acc));
     return 0;
@@ -394,8 +418,10 @@ int Engine::conv_bwd(const uint16_t* dy_pad, const uint16_t* x_pad, int relu_x, 
         gemm_args_init(g);
         g.A = ws_a_; g.W = ws_b_; g.M = Cout; g.N = 9 * Cin; g.K = Mpp; g.lda = Mpp; g.ldw = Mpp;
         g.C = ws_dw_; g.out_dtype = DT_F32; g.ldc = 9 * Cin; g.map_mode = MAP_LINEAR;
+        const int ns = pick_split(Cout, 9 * Cin, Mpp / 64, g);
+        if (ns > 1) { g.C = ws_part_; g.c_split_stride = (size_t)Cout * 9 * Cin; }
         TRY(launch_gemm(g, img_dt_, st));
-        TRY(launch_conv_wgrad_unpack(ws_dw_, dw_dst, Co_real, Ci_real, Cin, acc, st));
+        TRY(launch_conv_wgrad_unpack(ns > 1 ? ws_part_ : ws_dw_, dw_dst, Co_real, Ci_real, Cin, acc, st, ns, g.c_split_stride));
     }
     return 0;
 }
