@@ -130,10 +130,17 @@ int lseg_set_text_grouping(lseg_handle h, int labels_per_image);
  *   dev_x          fp32 [B,3,img_h,img_w] NCHW, normalised like lseg_module.py:37-50
  *   dev_logits_out fp32 [B,K,img_h,img_w], caller-allocated, freshly written (the caller
  *                  may mutate it afterwards: encoding_models.py:138).  May be NULL.
- *   dev_argmax_out uint8 [B,img_h/2,img_w/2] argmax over K of the low-resolution
- *                  logits (before the x2 upsample); optional, may be NULL. */
+ *   dev_argmax_out uint8 [B,img_h,img_w]: the mask = argmax over the labels of the output logits (first maximum wins, like
+ *                  torch.max(pred, 1) at lsegmentation_module.py:114-117), computed from the low-resolution logits through the
+ *                  x2 bilinear on the fly; optional, may be NULL.  With dev_logits_out == NULL the full-resolution logits
+ *                  (138 MB per image at K = 150) are never materialised.  K <= 256. */
 int lseg_forward(lseg_handle h, const float* dev_x, int B, float* dev_logits_out,
                  uint8_t* dev_argmax_out, void* stream);
+
+/* The metric / loss step after the path, without the full-resolution logits: statistics of the LAST lseg_forward's output against a
+ * target mask -- replaces batch_pix_accuracy + batch_intersection_union on `pred` (lsegmentation_module.py:49-50,59-60) and the value
+ * of the criterion (:72).  dev_target int64 [B,img_h,img_w]; dev_counts / dev_nll as in lseg_op_seg_stats. */
+int lseg_forward_stats(lseg_handle h, const int64_t* dev_target, int ignore_index, int64_t* dev_counts, double* dev_nll, void* stream);
 
 /* Intermediate taps for parity tests (names: "act1".."act4", "layer1".."layer4",
  * "rn1".."rn4", "path1".."path4", "image_features", "lowres").  Copies the tensor in the oracle's layout
@@ -201,6 +208,12 @@ int lseg_op_head_features(const void* d_x_bf16, const void* d_w_bf16, const floa
  * d_nll double [2] = {sum over valid pixels of -log_softmax(scores)[target], number of valid pixels}. */
 int lseg_op_seg_stats(const float* d_scores, const int64_t* d_target, int B, int K, int H, int W, int ignore_index,
                       int64_t* d_counts, double* d_nll, void* stream);
+/* The same statistics (and / or the masks) straight from the LOW-resolution logits [B,K,h,w] the engine keeps before
+ * scratch.output_conv (lseg_net.py:203): every pixel of the [B,2h,2w] grid reads them through the x2 bilinear (align_corners=True)
+ * on the fly, so the metric / mask step needs no full-resolution logits.  d_target int64 [B,2h,2w] or NULL (then d_counts / d_nll
+ * are not touched); d_argmax uint8 [B,2h,2w] or NULL. */
+int lseg_op_seg_stats_lowres(const float* d_low, const int64_t* d_target, int B, int K, int h, int w, int ignore_index,
+                             int64_t* d_counts, double* d_nll, uint8_t* d_argmax, void* stream);
 
 /* Backward of one Linear layer y = x W^T + b -- first brick of the training step (the reference gets
  * it from torch autograd under LSegmentationModule.training_step, lsegmentation_module.py:66-81).  bf16/fp16 operands,

@@ -88,6 +88,11 @@ int lseg_forward(lseg_handle h, const float* dev_x, int B, float* dev_logits_out
     return h->e->forward(dev_x, B, dev_logits_out, dev_argmax_out, (hipStream_t)stream);
 }
 
+int lseg_forward_stats(lseg_handle h, const int64_t* dev_target, int ignore_index, int64_t* dev_counts, double* dev_nll, void* stream) {
+    GUARD(h);
+    return h->e->forward_stats(dev_target, ignore_index, dev_counts, dev_nll, (hipStream_t)stream);
+}
+
 int lseg_set_debug(lseg_handle h, int enabled) { GUARD(h); h->e->debug = enabled != 0; return LSEG_OK; }
 int lseg_get_intermediate(lseg_handle h, const char* name, float* dev_out, size_t cap, size_t* n, void* stream) {
     GUARD(h);
@@ -241,6 +246,15 @@ int lseg_op_seg_stats(const float* d_scores, const int64_t* d_target, int B, int
     if (B < 1 || K < 1 || K > 4096 || H < 1 || W < 1) return set_error(LSEG_ERR_INVALID, "seg_stats: bad shape B=%d K=%d %dx%d", B, K, H, W);
     return launch_seg_stats(d_scores, d_target, B, K, H * W, ignore_index, reinterpret_cast<unsigned long long*>(d_counts),
                             d_nll, (hipStream_t)stream);
+}
+
+int lseg_op_seg_stats_lowres(const float* d_low, const int64_t* d_target, int B, int K, int h, int w, int ignore_index,
+                             int64_t* d_counts, double* d_nll, uint8_t* d_argmax, void* stream) {
+    int r = require_device(); if (r) return r;
+    if (!d_low || (!d_target && !d_argmax) || (d_target && (!d_counts || !d_nll))) return set_error(LSEG_ERR_INVALID, "seg_stats_lowres: NULL pointer");
+    if (B < 1 || K < 1 || h < 2 || w < 2) return set_error(LSEG_ERR_INVALID, "seg_stats_lowres: bad shape");
+    return launch_seg_stats_ex(d_low, d_target, B, K, 4 * h * w, ignore_index, reinterpret_cast<unsigned long long*>(d_counts), d_nll,
+                               d_argmax, 1, h, w, (hipStream_t)stream);
 }
 
 int lseg_op_linear_backward(const void* d_dy, const void* d_x, const void* d_w, int ab_dtype, void* d_dx, float* d_dw,

@@ -1043,23 +1043,48 @@ __global__ void sum_partials_kernel(const float* __restrict__ part, float* __res
 //                           (call site lsegmentation_module.py:72): sum of -log_softmax(scores)[target] and the pixel count
 // counts: [0] correct, [1] labeled, [2..2+K) area_inter, [2+K..2+2K) area_pred, [2+2K..2+3K) area_lab ; nll: [0] sum, [1] count.
 // Integer counts are exact (atomics on integers); the NLL sum is a double atomic (order-dependent in the last bits).
+// `up` != 0: `scores` is the LOW-resolution logits [B,K,h,w] and every pixel of the [B,2h,2w] output grid reads them through
+// output_conv's x2 bilinear (align_corners=True, lseg_net.py:203) on the fly -- the 138 MB / image full-resolution logits are never
+// written when the caller only wants masks and / or metrics.  `target` may be NULL (masks only), `argmax_out` (uint8 [B,2h,2w] or
+// [B,H,W]) may be NULL (metrics only).
 __global__ __launch_bounds__(256) void seg_stats_kernel(const float* __restrict__ scores, const long long* __restrict__ target,
                                                         int K, int HW, size_t npix, int ignore_index,
-                                                        unsigned long long* __restrict__ counts, double* __restrict__ nll) {
+                                                        unsigned long long* __restrict__ counts, double* __restrict__ nll,
+                                                        uint8_t* __restrict__ argmax_out, int up, int h, int w) {
     extern __shared__ unsigned int hist[];                // [3K] per-block class histograms + [2] pixel counts
     for (int i = threadIdx.x; i < 3 * K + 2; i += blockDim.x) hist[i] = 0;
     __syncthreads();
     double loss = 0.0;
     unsigned int nvalid = 0;
+    const int Wo = 2 * w;
+    const float ry = up ? (float)(h - 1) / (float)(2 * h - 1) : 0.f, rx = up ? (float)(w - 1) / (float)(2 * w - 1) : 0.f;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < npix; i += (size_t)gridDim.x * blockDim.x) {
         const int p = (int)(i % HW);
         const size_t b = i / HW;
-        const float* col = scores + b * (size_t)K * HW + p;
-        const long long t = target[i];
+        const float* col;
+        size_t kstride;
+        int o01 = 0, o10 = 0, o11 = 0;
+        float ly = 0.f, lx = 0.f;
+        if (up) {
+            const int yo = p / Wo, xo = p - yo * Wo;
+            const float sy = ry * (float)yo, sx = rx * (float)xo;
+            const int y0 = (int)sy, x0 = (int)sx;
+            const int y1 = y0 + (y0 < h - 1), x1 = x0 + (x0 < w - 1);
+            ly = sy - (float)y0; lx = sx - (float)x0;
+            kstride = (size_t)h * w;
+            col = scores + b * (size_t)K * kstride + (size_t)y0 * w + x0;
+            o01 = x1 - x0; o10 = (y1 - y0) * w; o11 = o10 + o01;
+        } else {
+            kstride = (size_t)HW;
+            col = scores + b * (size_t)K * HW + p;
+        }
+        const long long t = target ? target[i] : -1;
         float m = -INFINITY, ssum = 0.f, at_t = 0.f;
         int arg = 0;
         for (int k = 0; k < K; ++k) {
-            const float v = col[(size_t)k * HW];
+            const float* c = col + (size_t)k * kstride;
+            // same association as upsample_bilinear2d (and upsample2x_planes_kernel): bit-identical to the materialised logits
+            const float v = up ? (1.f - ly) * ((1.f - lx) * c[0] + lx * c[o01]) + ly * ((1.f - lx) * c[o10] + lx * c[o11]) : c[0];
             if (v > m) {                                  // first maximum wins (torch.max / argmax tie rule)
                 ssum = ssum * __expf(m - v) + 1.f;        // online log-sum-exp (exp(-inf) = 0 on the first label)
                 m = v; arg = k;
@@ -1068,6 +1093,8 @@ __global__ __launch_bounds__(256) void seg_stats_kernel(const float* __restrict_
             }
             if (k == t) at_t = v;
         }
+        if (argmax_out) argmax_out[i] = (uint8_t)arg;
+        if (!target) continue;
         const long long t1 = t + 1;                        // metrics.py: target + 1, predict + 1
         const int pred1 = arg + 1;
         if (t1 > 0) {
@@ -1084,6 +1111,7 @@ __global__ __launch_bounds__(256) void seg_stats_kernel(const float* __restrict_
             ++nvalid;
         }
     }
+    if (!target) return;                                   // uniform: nothing was accumulated
     // block reduction of the loss, then one atomic per block / per non-empty histogram bin
     __shared__ double lred[256];
     __shared__ unsigned int nred[256];
@@ -1576,13 +1604,21 @@ int launch_colsum16(const void* in, int dtype, float* out, int R, int C, int ld,
 
 int launch_seg_stats(const float* scores, const int64_t* target, int B, int K, int HW, int ignore_index,
                      unsigned long long* counts, double* nll, hipStream_t st) {
-    if (K < 1 || K > 4096) return -1;
-    LSEG_HIP_TRY(hipMemsetAsync(counts, 0, (size_t)(2 + 3 * K) * sizeof(unsigned long long), st));
-    LSEG_HIP_TRY(hipMemsetAsync(nll, 0, 2 * sizeof(double), st));
+    return launch_seg_stats_ex(scores, target, B, K, HW, ignore_index, counts, nll, nullptr, 0, 0, 0, st);
+}
+// up != 0: scores = low-resolution logits [B,K,h,w], statistics / masks on the x2-upsampled grid (HW = 4*h*w)
+int launch_seg_stats_ex(const float* scores, const int64_t* target, int B, int K, int HW, int ignore_index, unsigned long long* counts,
+                        double* nll, uint8_t* argmax_out, int up, int h, int w, hipStream_t st) {
+    if (K < 1 || K > 4096) return set_error(LSEG_ERR_INVALID, "seg_stats: K=%d", K);
+    if (argmax_out && K > 256) return set_error(LSEG_ERR_UNSUPPORTED, "uint8 masks need K <= 256 (K=%d)", K);
+    if (target) {
+        LSEG_HIP_TRY(hipMemsetAsync(counts, 0, (size_t)(2 + 3 * K) * sizeof(unsigned long long), st));
+        LSEG_HIP_TRY(hipMemsetAsync(nll, 0, 2 * sizeof(double), st));
+    }
     const size_t npix = (size_t)B * HW;
-    int grid = (int)std::min<size_t>((npix + 255) / 256, 2048);
+    int grid = (int)std::min<size_t>((npix + 255) / 256, 256 * 16);
     hipLaunchKernelGGL(seg_stats_kernel, dim3(grid), dim3(256), (size_t)(3 * K + 2) * sizeof(unsigned int), st,
-                       scores, reinterpret_cast<const long long*>(target), K, HW, npix, ignore_index, counts, nll);
+                       scores, reinterpret_cast<const long long*>(target), K, HW, npix, ignore_index, counts, nll, argmax_out, up, h, w);
     CHECK_LAUNCH();
     return 0;
 }

@@ -56,6 +56,7 @@ public:
     int encode_text(hipStream_t st);
     int forward(const float* x, int B, float* logits, uint8_t* argmax_out, hipStream_t st);
     int get_text_features(void* out_f16, hipStream_t st);
+    int forward_stats(const int64_t* target, int ignore_index, int64_t* counts, double* nll, hipStream_t st);
     int get_intermediate(const char* name, float* out, size_t cap, size_t* n, hipStream_t st);
     int get_profile(const char* family, double* ms, int64_t* launches, double* flops);
     // ---- training step (train.hip; modules/lsegmentation_module.py:66-81) ----
@@ -109,7 +110,8 @@ private:
     std::map<std::string, BoundParam> bound_;
     std::vector<void*> allocs_;
     bool finalized_ = false, inited_ = false;
-    int last_B_ = 0;
+    int last_B_ = 0, last_kout_ = 0;
+    const float* last_low_ = nullptr;
 
     // derived geometry
     int gh_, gw_, np_, ntok_, npad_, img_dt_;

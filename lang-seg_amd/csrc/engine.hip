@@ -735,12 +735,26 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
         TRY(launch_head_block(src, dst, hb_w_, hb_b_, B, Kout, h1, w1, bott, c.activation, 0, st));
         low = dst;
     }
-    if (argmax_out && Kout > 256) return set_error(LSEG_ERR_UNSUPPORTED, "uint8 argmax needs K <= 256 (K=%d)", Kout);
-    if (argmax_out) TRY(launch_argmax_planes(low, argmax_out, B, Kout, hw1, st));
+    // masks = argmax over the labels of the x2-upsampled logits (what every caller of the reference computes from the full tensor:
+    // torch.max(pred, 1), lsegmentation_module.py:114-117), read through the bilinear on the fly: no 138 MB / image logits needed
+    last_low_ = low; last_kout_ = Kout;
+    if (argmax_out && Kout > 256) return set_error(LSEG_ERR_UNSUPPORTED, "uint8 masks need K <= 256 (K=%d)", Kout);
+    if (argmax_out) TRY(launch_seg_stats_ex(low, nullptr, B, Kout, 4 * hw1, -1, nullptr, nullptr, argmax_out, 1, h1, w1, st));
     // ---- scratch.output_conv: bilinear x2, align_corners=True (lseg_net.py:203) ----------------------------------
     if (logits) TRY(launch_upsample2x_planes(low, logits, B * Kout, h1, w1, st));
     if (profiling && fwd0 && fwd1) { (void)hipEventRecord(fwd1, st); ev_fwd_.push_back({fwd0, fwd1}); }
     return 0;
+}
+
+// pixAcc / IoU counts and the cross-entropy sum of the LAST forward's output against a target mask, from the low-resolution logits
+// through the x2 bilinear on the fly (lsegmentation_module.py:49-50,59-60,72: the metric / loss step after the path)
+int Engine::forward_stats(const int64_t* target, int ignore_index, int64_t* counts, double* nll, hipStream_t st) {
+    if (!last_low_ || last_B_ < 1) return set_error(LSEG_ERR_STATE, "no forward has run");
+    if (!target || !counts || !nll) return set_error(LSEG_ERR_INVALID, "forward_stats: NULL pointer");
+    LSEG_HIP_TRY(hipSetDevice(device));
+    const int h1 = 2 * lh_[0], w1 = 2 * lw_[0];
+    return launch_seg_stats_ex(last_low_, target, last_B_, last_kout_, 4 * h1 * w1, ignore_index, reinterpret_cast<unsigned long long*>(counts),
+                               nll, nullptr, 1, h1, w1, st);
 }
 
 int Engine::get_text_features(void* out, hipStream_t st) {

@@ -59,6 +59,8 @@ int launch_softmax_ce_backward(const float* scores, const int64_t* target, float
 int launch_conv_dgrad_pack(const void* wp, void* wd, int Co, int Ci, hipStream_t st);
 int launch_colsum16(const void* in, int dtype, float* out, int R, int C, int ld, hipStream_t st, int accumulate = 0);
 int launch_relu_backward_add(const void* dy, const void* x, const void* add, void* dx, size_t n, int dtype, hipStream_t st);
+int launch_seg_stats_ex(const float* scores, const int64_t* target, int B, int K, int HW, int ignore_index, unsigned long long* counts,
+                        double* nll, uint8_t* argmax_out, int up, int h, int w, hipStream_t st);
 int launch_seg_stats(const float* scores, const int64_t* target, int B, int K, int HW, int ignore_index,
                      unsigned long long* counts, double* nll, hipStream_t st);
 

@@ -343,6 +343,7 @@ int Engine::forward_train(const float* x_in, int B, float* logits, hipStream_t s
     float* out = logits ? logits : logits_;
     TRY(launch_upsample2x_planes(low_, out, B * K_, h1, w1, st));
     last_logits_ = out;
+    last_low_ = low_; last_kout_ = K_;
     train_B_ = B;
     train_fwd_valid_ = true;
     return 0;

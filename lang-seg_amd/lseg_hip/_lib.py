@@ -57,6 +57,7 @@ SIGNATURES = {
     "lseg_get_text_features": (_i, [_vp, _vp, _vp]),
     "lseg_set_text_grouping": (_i, [_vp, _i]),
     "lseg_forward": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "lseg_forward_stats": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "lseg_get_intermediate": (_i, [_vp, C.c_char_p, _vp, _sz, C.POINTER(_sz), _vp]),
     "lseg_set_debug": (_i, [_vp, _i]),
     "lseg_set_profiling": (_i, [_vp, _i]),
@@ -79,6 +80,7 @@ SIGNATURES = {
     "lseg_op_correlation": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "lseg_op_head_features": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "lseg_op_seg_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "lseg_op_seg_stats_lowres": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "lseg_op_linear_backward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "lseg_op_attention_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "lseg_op_attention_backward_ws_bytes": (_sz, [_i, _i, _i]),

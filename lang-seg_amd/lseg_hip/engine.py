@@ -143,7 +143,7 @@ class HipEngine:
         if self._group > 0 and self._K != B * self._group:
             raise ValueError(f"per-image label sets: {self._K} token rows != batch {B} x {self._group}")
         logits = torch.empty((B, Kout, H, W), dtype=torch.float32, device=self.device) if want_logits else None
-        amax = torch.empty((B, H // 2, W // 2), dtype=torch.uint8, device=self.device) if want_argmax else None
+        amax = torch.empty((B, H, W), dtype=torch.uint8, device=self.device) if want_argmax else None      # the masks
         _lib.check(self.lib.lseg_forward(
             self._h, C.c_void_p(x.data_ptr()), B,
             C.c_void_p(logits.data_ptr()) if logits is not None else None,
@@ -224,6 +224,20 @@ class HipEngine:
         """fn(dev_ptr, n_floats) must sum the n floats at dev_ptr over the ranks, ordered on the current stream."""
         self._bn_cb = _lib.REDUCE_CB(lambda user, p, n, stream: fn(int(p), int(n))) if fn is not None else None
         _lib.check(self.lib.lseg_set_bn_sync(self._h, C.cast(self._bn_cb, C.c_void_p) if fn else None, None, int(world_size)))
+
+    def forward_stats(self, target: torch.Tensor, ignore_index: int = -1) -> dict:
+        """pixAcc / IoU counts + CE sum of the last forward's output vs `target` int64 [B,H,W] (lseg_forward_stats): computed from the
+        engine's low-resolution logits through the x2 bilinear on the fly -- pair it with forward(x, want_logits=False)."""
+        t = target.detach().to(self.device, torch.int64).contiguous()
+        K = self._group if self._group > 0 else self._K
+        counts = torch.empty(2 + 3 * K, dtype=torch.int64, device=self.device)
+        nll = torch.empty(2, dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.lseg_forward_stats(self._h, C.c_void_p(t.data_ptr()), int(ignore_index), C.c_void_p(counts.data_ptr()),
+                                               C.c_void_p(nll.data_ptr()), C.c_void_p(_stream_ptr(self.device))))
+        c, n = counts.cpu(), nll.cpu()
+        inter, pred, lab = c[2:2 + K], c[2 + K:2 + 2 * K], c[2 + 2 * K:2 + 3 * K]
+        return {"correct": int(c[0]), "labeled": int(c[1]), "area_inter": inter, "area_pred": pred, "area_lab": lab,
+                "area_union": pred + lab - inter, "nll_sum": float(n[0]), "nll_count": int(n[1])}
 
     # ---- taps / measurement ----------------------------------------------------------------------------
     def set_debug(self, enabled: bool):

@@ -46,6 +46,11 @@ class LSegmentationModule(_Base):
         return self.net(x)
 
     def evaluate(self, x, target=None):                       # :43-52
+        if target is not None and hasattr(self.net, "forward_metrics"):
+            # metric-only call: the counts come from the engine's low-resolution logits through the x2 bilinear on the fly
+            # (lseg_forward_stats) -- the [B,K,H,W] logits (138 MB per image) are not even written
+            r = self.net.forward_metrics(x, target, ignore_index=self.other_kwargs.get("ignore_index", -1))
+            return r["correct"], r["labeled"], r["area_inter"].numpy(), r["area_union"].numpy()
         pred = self.net.forward(x)
         if isinstance(pred, (tuple, list)):
             pred = pred[0]

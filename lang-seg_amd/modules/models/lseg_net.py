@@ -103,9 +103,6 @@ class LSeg(BaseModel):
         self.cache_text = kwargs.get("cache_text", False)
 
     # ---- engine plumbing -----------------------------------------------------------------------
-    def _stamp(self):
-        return tuple((p.data_ptr(), p._version) for p in self.state_dict(keep_vars=True).values()
-                     if isinstance(p, torch.Tensor))
 
     def _engine(self, B, H, W, K, device):
         """One engine per (image size, device): each holds its own packed weights + activation plan (~1 GB for ViT-L/16).  The
@@ -137,7 +134,36 @@ class LSeg(BaseModel):
             eng._tok = None
         return eng
 
-    def forward(self, x, labelset=""):
+    def _stamp(self):
+        # (storage, version) of every tensor of the state dict: changes on load_state_dict, optimizer steps, .cuda(), .half() ...
+        # The tensor list is cached (building the state dict costs ~1 ms on ViT-L; it only changes when a module is replaced, which
+        # _apply / load_state_dict signal by bumping _stamp_epoch)
+        ep = getattr(self, "_stamp_epoch", 0)
+        if getattr(self, "_stamp_cache", None) is None or self._stamp_cache[0] != ep:
+            self._stamp_cache = (ep, [p for p in self.state_dict(keep_vars=True).values() if isinstance(p, torch.Tensor)])
+        return tuple((p.data_ptr(), p._version) for p in self._stamp_cache[1])
+
+    def _apply(self, fn, *a, **k):
+        self._stamp_epoch = getattr(self, "_stamp_epoch", 0) + 1
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._stamp_epoch = getattr(self, "_stamp_epoch", 0) + 1
+        return super().load_state_dict(*a, **k)
+
+    def forward_metrics(self, x, target, labelset="", ignore_index=-1):
+        """evaluate(x, target) of the Lightning module without the full-resolution logits (lseg_forward_stats)."""
+        was = self.training
+        self.eval()
+        try:
+            with torch.no_grad():
+                self.forward(x, labelset, _want_logits=False)
+            eng = self._last_engine
+            return eng.forward_stats(target, ignore_index)
+        finally:
+            self.train(was)
+
+    def forward(self, x, labelset="", _want_logits=True):
         if labelset == "":
             text = self.text
         else:
@@ -161,7 +187,8 @@ class LSeg(BaseModel):
         if train:
             named = [(k, p) for k, p in self.named_parameters() if k in eng.grads]
             return _EngineTrainFn.apply(x.float(), self, eng, tuple(k for k, _ in named), *[p for _, p in named])
-        return eng.forward(x.float())
+        self._last_engine = eng
+        return eng.forward(x.float(), want_logits=_want_logits)
 
 
 class LSegNet(LSeg):

@@ -90,7 +90,7 @@ def check_case(spec, image_dtype="bf16", stage_tol=0.10):
     assert report["logits_maxabs"] <= LOGIT_TOL * (1 if cfg.arch_option == 0 else 4), report
     # argmax: mismatches only where the oracle's own top-2 margin is inside the tolerance
     if cfg.arch_option == 0:
-        lo = inter["lowres"]
+        lo = ref                                   # the masks are argmax of the OUTPUT logits (engine: through the x2 bilinear on the fly)
         ref_am = lo.argmax(1)
         mism = amax.cpu().long() != ref_am
         top2 = lo.topk(2, dim=1).values
@@ -280,6 +280,7 @@ def test_vitl16_batch_of_8_equals_single_image_runs():
     eng.load_state_dict(sd)
     eng.set_tokens(tok)
     batch = eng.forward(x, want_logits=False, want_argmax=True)
+    assert batch.shape == (8, H, W)
     low8 = eng.intermediate("lowres", (8, K, H // 2, W // 2))
     for b in (0, 5):
         am1 = eng.forward(x[b:b + 1], want_logits=False, want_argmax=True)
@@ -406,3 +407,67 @@ def test_engine_matches_the_reference_at_the_baseline_configs(name, dtype, golde
     tr = g["text_features"].float()
     tr = tr / tr.norm(dim=-1, keepdim=True)
     assert (tf - tr).abs().max().item() <= 4e-3
+
+
+def test_masks_and_metrics_without_the_full_resolution_logits():
+    """lseg_forward(logits = NULL, masks) and lseg_op_seg_stats_lowres read the low-resolution logits through the x2 bilinear on the
+    fly: same masks as argmax of the materialised output (except exact fp32 ties), same integer metric counts, same loss."""
+    import ctypes as C
+    from lseg_hip import _lib
+    cfg, sd, tok, x, eng, logits, amax = run_engine(MG.CASES["tiny16_96x64_k7"], debug=False)
+    B, K, H, W = logits.shape
+    top2 = logits.topk(2, dim=1).values
+    decisive = (top2[:, 0] - top2[:, 1]) > 1e-5
+    assert torch.equal(amax.long()[decisive], logits.argmax(1)[decisive]) and decisive.float().mean().item() > 0.99
+    only = eng.forward(x.cuda(), want_logits=False, want_argmax=True)
+    assert torch.equal(only, amax)
+    g = torch.Generator().manual_seed(3)
+    target = torch.randint(0, K, (B, H, W), generator=g)
+    target[torch.rand((B, H, W), generator=g) < 0.2] = -1
+    target = target.cuda()
+    lib = _lib.load()
+    low = eng.intermediate("lowres", (B, K, H // 2, W // 2))
+    P = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    res = []
+    for fused in (False, True):
+        counts = torch.zeros(2 + 3 * K, dtype=torch.int64, device="cuda")
+        nll = torch.zeros(2, dtype=torch.float64, device="cuda")
+        if fused:
+            am = torch.empty((B, H, W), dtype=torch.uint8, device="cuda")
+            _lib.check(lib.lseg_op_seg_stats_lowres(P(low), P(target), B, K, H // 2, W // 2, -1, P(counts), P(nll), P(am), st))
+        else:
+            _lib.check(lib.lseg_op_seg_stats(P(logits), P(target), B, K, H, W, -1, P(counts), P(nll), st))
+        torch.cuda.synchronize()
+        res.append((counts.cpu(), nll.cpu()))
+    assert torch.equal(am, amax)
+    # counts may differ only through pixels with an exact fp32 tie between the two best labels (none on this input)
+    assert (res[0][0] - res[1][0]).abs().max().item() <= int((~decisive).sum().item())
+    assert abs(res[0][1][0] - res[1][1][0]).item() <= 1e-6 * abs(res[0][1][0]).item() and res[0][1][1] == res[1][1][1]
+
+
+def test_module_metrics_path_needs_no_logits():
+    """LSegmentationModule.evaluate(x, target) (lsegmentation_module.py:43-52) through LSegNet.forward_metrics: the engine's
+    lseg_forward_stats on the low-resolution logits == the device metric pass over the materialised [B,K,H,W] logits."""
+    import warnings
+    warnings.simplefilter("ignore")
+    from lseg_hip import metrics
+    from modules.models.lseg_net import LSegNet
+    cfg = get_config("tiny16")
+    sd = synthetic_state_dict(cfg, seed=2)
+    labels = read_labels(MG.LABELS)[:6]
+    net = LSegNet(labels=labels, backbone="tiny16", features=cfg.features, arch_option=0, block_depth=0, activation="lrelu")
+    net.load_state_dict(sd)
+    net = net.eval().cuda()
+    x = synthetic_images(2, 64, 96, seed=2).cuda()
+    g = torch.Generator().manual_seed(4)
+    target = torch.randint(0, 6, (2, 64, 96), generator=g)
+    target[torch.rand((2, 64, 96), generator=g) < 0.25] = -1
+    with torch.no_grad():
+        full = metrics.seg_stats(net(x), target.cuda())
+    fused = net.forward_metrics(x, target.cuda())
+    for k in ("correct", "labeled", "nll_count"):
+        assert full[k] == fused[k], k
+    for k in ("area_inter", "area_pred", "area_lab", "area_union"):
+        assert torch.equal(full[k], fused[k]), k
+    assert abs(full["nll_sum"] - fused["nll_sum"]) <= 1e-6 * abs(full["nll_sum"])

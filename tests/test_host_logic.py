@@ -17,7 +17,7 @@ def test_capi_library_loads_and_exports_every_declared_symbol(repo_root):
     from lseg_hip import _lib
     lib = _lib.load()
     hdr = open(os.path.join(repo_root, "include", "lseg_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(lseg_[a-z0-9_]+)\s*\(", hdr, re.M))
+    declared = set(re.findall(r"^(?:int|size_t|const char\*)\s+(lseg_[a-z0-9_]+)\s*\(", hdr, re.M))
     assert len(declared) >= 20
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in lseg_hip.h but not exported"
