@@ -29,6 +29,9 @@ import torch  # noqa: E402
 
 GF_IMAGE = lambda K: 799.4 + 0.05898 * K        # image tower GF / image
 GF_TEXT = lambda K: 5.959 * K                   # CLIP text tower GF / forward call, the reference's 77-position schedule
+# executed by the engine: refinenet1.out_conv (7.55 GF) and head1 (15.10 GF) at 240x240 are replaced by ONE combined 1x1 conv on the
+# padded 122x122 map below the upsample (3.90 GF): DESIGN.md §3.4
+GF_IMAGE_EXEC = lambda K: GF_IMAGE(K) - 7.55 - 15.10 + 3.90
 PEAK_BF16_TFLOPS = 2500.0                       # MI355X_MICROARCH.md dense bf16 MFMA peak
 
 
@@ -54,6 +57,9 @@ def parse():
     ap.add_argument("--cpu-samples", type=int, default=3, help="timed CPU-baseline forwards (each ~5 s)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the batch sweep and the training-step leg")
     ap.add_argument("--train-batch", type=int, default=8, help="per-GPU batch of the training-step leg (BASELINE configs[3])")
+    ap.add_argument("--train-sync-bn", action="store_true",
+                    help="multi-GPU training leg with SyncBatchNorm (the reference's utils.py:34: 56 tiny all-reduces per step); default "
+                         "for N > 1 is per-GPU statistics = no collective besides the gradient all-reduce (BASELINE north_star)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = min(32, cores))")
     return ap.parse_args()
 
@@ -95,7 +101,7 @@ def time_forward(eng, x, steps, warmup, sync):
     return (time.perf_counter() - t0) / steps
 
 
-def train_leg(cfg, sd, tok, size, B, rank, sync, D):
+def train_leg(cfg, sd, tok, size, B, rank, sync, D, sync_bn=True):
     """BASELINE configs[3]: one data-parallel training step per GPU batch B -- train-mode forward, fused CE, backward with the
     bucketed RCCL all-reduce overlapped, fused SGD (lseg_hip/train.py).  1 warm-up + 3 timed steps."""
     from lseg_hip.engine import HipEngine
@@ -105,7 +111,7 @@ def train_leg(cfg, sd, tok, size, B, rank, sync, D):
     eng = HipEngine(cfg, size, size, max_batch=B, max_labels=tok.shape[0])
     eng.load_state_dict(sd_dev)
     eng.set_tokens(tok)
-    tr = DataParallelTrainer(eng, sd_dev, sync_bn=True)
+    tr = DataParallelTrainer(eng, sd_dev, sync_bn=sync_bn)
     x = synthetic_images(B, size, size, seed=100 + rank).cuda()
     g = torch.Generator().manual_seed(7 + rank)
     t = torch.randint(0, tok.shape[0], (B, size, size), generator=g)
@@ -189,19 +195,6 @@ def main():
     if not selfcheck <= 1e-2:
         raise SystemExit(f"bench self-check failed: batch-of-{B} logits differ from the single-image run by {selfcheck}")
 
-    # extra legs, outside the headline's timed region: per-GPU batch sweep (config 3 runs 4 images per GPU) and the training step
-    sweep, train = None, None
-    if not args.no_sweep:
-        sweep = {}
-        for b in (1, 4, 8, 16):
-            if b >= B:
-                continue
-            tb = D.max_over_ranks(time_forward(eng, x[:b], 10 if b > 1 else 30, 3, sync), device="cuda")
-            sweep[str(b)] = round(world * b / tb, 1)
-        sweep[str(B)] = round(world * B * args.steps / dt, 1)
-        if args.backbone == "clip_vitl16_384" and args.dtype == "bf16":
-            train = train_leg(cfg, sd, tok, args.size, args.train_batch, rank, sync, D)
-
     if rank == 0:
         ms = dt / args.steps * 1e3
         ips = world * B * args.steps / dt
@@ -229,7 +222,7 @@ def main():
         # truncated to max(EOT)+1 positions: exact); REFERENCE-ALGORITHM = what the reference's schedule would spend
         # on the same inputs (77 text positions).  Roofline fractions use the executed count only.
         L_exec = int(tok.argmax(dim=-1).max().item()) + 1
-        gf_step = B * GF_IMAGE(K) + gf_text_executed(K, L_exec)
+        gf_step = B * GF_IMAGE_EXEC(K) + gf_text_executed(K, L_exec)
         gf_step_ref = B * GF_IMAGE(K) + GF_TEXT(K)
         line = {
             "metric": "images/sec at 480x480, ViT-L/16 + 150 ADE20K labels",
@@ -242,19 +235,54 @@ def main():
                        "parallelism": f"dp{world} (batch sharded, no collectives)"},
             "path_tflops": round(world * gf_step / (ms * 1e-3) / 1e3, 2),
             "path_frac_of_mfma_peak": round(gf_step / (ms * 1e-3) / 1e3 / PEAK_BF16_TFLOPS, 4),
-            "path_flops_convention": f"executed FLOPs: image tower {GF_IMAGE(K):.1f} GF/image + text tower at {L_exec} of 77 positions "
-                                     f"({gf_text_executed(K, L_exec):.1f} GF/call)",
+            "path_flops_convention": f"executed FLOPs: image tower {GF_IMAGE_EXEC(K):.1f} GF/image (head 1x1 convs commuted below the "
+                                     f"upsample: -18.75 GF) + text tower at {L_exec} of 77 positions ({gf_text_executed(K, L_exec):.1f} GF/call); "
+                                     f"the reference's schedule on the same inputs = {GF_IMAGE(K):.1f} + {GF_TEXT(K):.1f}",
             "path_tflops_reference_algorithm": round(world * gf_step_ref / (ms * 1e-3) / 1e3, 2),
-            "batch_sweep_images_per_sec": sweep,
-            "train_step": train,
             "engine_forward_ms_hip_events": round(fwd["total_ms"] / max(1, fwd["launches"]), 4),
             "roofline": roof,
             "selfcheck_batch_vs_single_max_abs": round(selfcheck, 6),
         }
+    else:
+        line = None
+
+    # ---- extra legs, outside the headline's timed region: per-GPU batch sweep (config 3 runs 4 images per GPU), the training step
+    # (config 4) and the CPU baseline.  A watchdog guarantees the contract line: if a leg does not come back (a collective that
+    # never completes on some rank), rank 0 prints the line without it and every rank leaves.
+    import threading
+
+    def give_up():
+        if rank == 0:
+            line["extra_legs"] = "abandoned after 240 s"
+            print(json.dumps(line), flush=True)
+        os._exit(0)
+
+    dog = threading.Timer(240.0, give_up)
+    dog.daemon = True
+    dog.start()
+    sweep, train = None, None
+    if not args.no_sweep:
+        sweep = {}
+        for b in (1, 4, 8, 16):
+            if b >= B:
+                continue
+            tb = D.max_over_ranks(time_forward(eng, x[:b], 10 if b > 1 else 30, 3, sync), device="cuda")
+            sweep[str(b)] = round(world * b / tb, 1)
+        sweep[str(B)] = round(world * B * args.steps / dt, 1)
+        if args.backbone == "clip_vitl16_384" and args.dtype == "bf16":
+            try:
+                train = train_leg(cfg, sd, tok, args.size, args.train_batch, rank, sync, D, sync_bn=args.train_sync_bn or world == 1)
+            except Exception as e:                       # noqa: BLE001  (the headline must survive a failing extra leg)
+                train = {"error": f"{type(e).__name__}: {e}"}
+    if rank == 0:
+        line["batch_sweep_images_per_sec"] = sweep
+        line["train_step"] = train
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or min(32, os.cpu_count() or 1)
             line["cpu_baseline"] = cpu_baseline(cfg, sd, tok, args.size, threads, args.cpu_samples)
+        dog.cancel()
         print(json.dumps(line), flush=True)
+    dog.cancel()
     if dist is not None:
         dist.destroy_process_group()
 
