@@ -1020,6 +1020,10 @@ int pick_tile(const GemmArgs& g, hipStream_t stream) {
         const double time_huge = (double)((t_huge + 255) / 256) * 4.0 / 1.12;
         const double time_mid = (double)((t_mid + 511) / 512) * 2.0;
         if (time_huge < time_mid) pick = 6;
+        // tools: A/B switch -- residual-epilogue GEMMs with a short K-loop (attention proj, K = 1024) on 128x128 tiles, where a
+        // second workgroup on the CU computes under the first one's fp32 read-modify-write epilogue
+        static const int res32_mid = getenv("LSEG_RES32_MID") ? atoi(getenv("LSEG_RES32_MID")) : 0;
+        if (res32_mid && EPI == EPI_RES32 && g.K <= res32_mid) pick = 2;
     }
     if (force) pick = force;
     if (pick == 6 && (g.N % 256) != 0) pick = 2;      // the specialised epilogues write whole tile rows: N must be a multiple of BN

@@ -9,7 +9,7 @@ DESIGN.md "Parity":
   * image tower, bf16 MFMA operands / fp32 accumulate vs the fp32 reference on the seeded
     random-weight network (an error amplifier: boosted qkv scale, peaky 901-key softmax):
     relative RMS error <= 10% per stage (measured 5.9-8.6% ViT-L, 0.7-5% tiny),
-    logits |d| <= 0.35 (measured 0.18) on logits that live in [-14.3, 14.3]
+    logits |d| <= 0.30 (measured 0.04-0.22) on logits that live in [-14.3, 14.3]; x the head blocks' own gain for arch_option 1/2
   * same with fp16 operands (8x finer mantissa, same MFMA rate): <= 1.5% per stage, |d| <= 0.06
   * argmax masks: every mismatching pixel must have an oracle top-2 margin below twice the
     measured logit error (bit-parity is only meaningful where the reference itself is decisive)
@@ -28,7 +28,16 @@ from lseg_hip.synth import (synthetic_state_dict, synthetic_tokens, synthetic_im
 from oracle.lseg_oracle import lseg_forward                  # noqa: E402
 from oracle import make_golden as MG                        # noqa: E402
 
-LOGIT_TOL = 0.35
+LOGIT_TOL = 0.30          # bf16 operands; measured 0.04-0.22 (the largest at ViT-L/16, 480x480).  fp16: 0.06 (measured <= 0.03)
+
+
+def head_block_gain(cfg, sd):
+    """Worst-case amplification of a logit error by the arch_option 1/2 head blocks (lseg_net.py:43-79): each applies ONE shared 3x3
+    filter per label plane (+ the channel max for the bottleneck) and a 1-Lipschitz activation -> sum|w| (+1) per block."""
+    if cfg.arch_option == 0:
+        return 1.0
+    per_block = sd["scratch.head_block.depthwise.depthwise.weight"].abs().sum().item() + (1.0 if cfg.arch_option == 1 else 0.0)
+    return max(1.0, per_block) ** cfg.block_depth
 
 
 def relrms(a, b):
@@ -87,7 +96,7 @@ def check_case(spec, image_dtype="bf16", stage_tol=0.10):
             assert v <= stage_tol, (k, report)
     if cfg.arch_option == 0:
         assert report["lowres_maxabs"] <= LOGIT_TOL, report
-    assert report["logits_maxabs"] <= LOGIT_TOL * (1 if cfg.arch_option == 0 else 4), report
+    assert report["logits_maxabs"] <= LOGIT_TOL * head_block_gain(cfg, sd), report
     # argmax: mismatches only where the oracle's own top-2 margin is inside the tolerance
     if cfg.arch_option == 0:
         lo = ref                                   # the masks are argmax of the OUTPUT logits (engine: through the x2 bilinear on the fly)
@@ -112,7 +121,7 @@ def test_tiny_forward_matches_oracle(name):
 def test_tiny_forward_matches_golden(name, golden_dir):
     g = torch.load(os.path.join(golden_dir, name + ".pt"))
     cfg, sd, tok, x, eng, logits, amax = run_engine(MG.CASES[name], debug=False)
-    tol = LOGIT_TOL * (1 if cfg.arch_option == 0 else 4)
+    tol = LOGIT_TOL * head_block_gain(cfg, sd)
     assert (logits.cpu() - g["logits"]).abs().max().item() <= tol
 
 
