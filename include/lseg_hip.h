@@ -293,6 +293,14 @@ int lseg_op_upsample2x_planes_backward_rows(const float* d_dout, void* d_rows, i
                                             void* stream);
 int lseg_op_l2norm_scale_backward(const void* d_da, int da_dtype, const float* d_x, void* d_dx, int dx_dtype, int M, int C, float scale,
                                   void* stream);
+/* Fused backward of the loss the reference takes on the full-resolution logits -- CrossEntropyLoss(ignore_index)(output_conv(low)),
+ * lsegmentation_module.py:72 on lseg_net.py:203 -- from the LOW-resolution logits d_low fp32 [B,K,h,w] and the target mask int64
+ * [B,2h,2w]: the x2 bilinear, the softmax and the bilinear's transpose in registers, so the [B,K,2h,2w] logits and their gradient
+ * (2 x 138 MB per image at K = 150, 480x480) never exist.  Outputs: d_nll double [2] = {sum of -log_softmax[target] over the valid
+ * pixels, number of valid pixels} (the loss is their ratio), d_rows [B*h*w, ldk] bf16|fp16 = d loss / d low in the row layout the
+ * correlation backward consumes (all ldk columns written, zeros beyond K; ldk % 8 == 0), d_lse_ws fp32 [B*2h*2w] scratch. */
+int lseg_op_upsample_ce_backward_rows(const float* d_low, const int64_t* d_target, int B, int K, int h, int w, int ignore_index,
+                                      double* d_nll, float* d_lse_ws, void* d_rows, int ldk, int out_dtype, void* stream);
 
 /* ---- training step ------------------------------------------------------------------------------------------------------------
  * replaces: LSegmentationModule.training_step (modules/lsegmentation_module.py:66-81) -- `out = self(img)` in train() mode,

@@ -257,6 +257,23 @@ int lseg_op_seg_stats_lowres(const float* d_low, const int64_t* d_target, int B,
                                d_argmax, 1, h, w, (hipStream_t)stream);
 }
 
+int lseg_op_upsample_ce_backward_rows(const float* d_low, const int64_t* d_target, int B, int K, int h, int w, int ignore_index,
+                                      double* d_nll, float* d_lse_ws, void* d_rows, int ldk, int out_dtype, void* stream) {
+    int r = require_device(); if (r) return r;
+    if (!d_low || !d_target || !d_nll || !d_lse_ws || !d_rows) return set_error(LSEG_ERR_INVALID, "upsample_ce_backward_rows: NULL pointer");
+    if (B < 1 || K < 1 || h < 2 || w < 2) return set_error(LSEG_ERR_INVALID, "upsample_ce_backward_rows: bad shape");
+    int dt;
+    if (out_dtype == LSEG_BF16) dt = DT_BF16; else if (out_dtype == LSEG_F16) dt = DT_F16;
+    else return set_error(LSEG_ERR_INVALID, "upsample_ce_backward_rows: out_dtype %d", out_dtype);
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long* counts = nullptr;
+    LSEG_HIP_TRY(hipMallocAsync((void**)&counts, (size_t)(2 + 3 * K) * sizeof(unsigned long long), st));
+    r = launch_seg_stats_ex(d_low, d_target, B, K, 4 * h * w, ignore_index, counts, d_nll, nullptr, 1, h, w, st, d_lse_ws);
+    if (!r) r = launch_upsample_ce_backward_rows(d_low, d_target, d_lse_ws, d_nll, d_rows, B, K, h, w, ldk, ignore_index, dt, st);
+    (void)hipFreeAsync(counts, st);
+    return r;
+}
+
 int lseg_op_linear_backward(const void* d_dy, const void* d_x, const void* d_w, int ab_dtype, void* d_dx, float* d_dw,
                             float* d_db, int M, int N, int K, void* stream) {
     int r = require_device(); if (r) return r;

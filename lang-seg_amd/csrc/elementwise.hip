@@ -552,7 +552,8 @@ template <int MAXV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restrict__ dy, int dy_dtype, const float* __restrict__ x,
                                                             const float* __restrict__ gamma, float* __restrict__ dx,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int M, int D, float eps, int accumulate, float* __restrict__ partial) {
+                                                            int M, int D, float eps, int accumulate, float* __restrict__ partial,
+                                                            uint16_t* __restrict__ dx16) {
     const int lane = threadIdx.x & 63;
     const int nv = D >> 2;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
@@ -618,6 +619,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const void* __restri
                                        rstd * (gv[i].z - a - xv[i].z * b), rstd * (gv[i].w - a - xv[i].w * b));
                 if (accumulate) { const float4 p = *o; r.x += p.x; r.y += p.y; r.z += p.z; r.w += p.w; }
                 *o = r;
+                if (dx16) {          // the 16-bit copy the next Linear backward reads as its dY (saves a conversion pass)
+                    uint2 pk;
+                    pk.x = pack2_dt(r.x, r.y, dy_dtype); pk.y = pack2_dt(r.z, r.w, dy_dtype);
+                    reinterpret_cast<uint2*>(dx16 + (size_t)row * D)[g] = pk;
+                }
             }
         }
     }
@@ -677,10 +683,8 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __rest
 }
 // the same with 16-byte accesses on both sides (C, ldi, ldo multiples of 8): a thread loads 8 consecutive columns of a row and stores 8
 // consecutive rows of a column; the 2-byte shuffling happens in LDS
-__global__ __launch_bounds__(256) void transpose16_vec_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
-                                                             int R, int C, int ldi, int ldo, int shift, int relu) {
-    __shared__ uint16_t t[64][72];
-    const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+__device__ __forceinline__ void transpose16_vec_tile(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, int R, int C, int ldi, int ldo,
+                                                     int shift, int relu, int r0, int c0, uint16_t (*t)[72]) {
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int i = threadIdx.x + k * 256;
@@ -707,6 +711,24 @@ __global__ __launch_bounds__(256) void transpose16_vec_kernel(const uint16_t* __
         }
     }
 }
+__global__ __launch_bounds__(256) void transpose16_vec_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
+                                                             int R, int C, int ldi, int ldo, int shift, int relu) {
+    __shared__ uint16_t t[64][72];
+    transpose16_vec_tile(in, out, R, C, ldi, ldo, shift, relu, blockIdx.x * 64, blockIdx.y * 64, t);
+}
+// many transposes in one launch (the W^T copies of every Linear after an optimizer step): block -> (matrix, tile) through a
+// table sorted by first block
+__global__ __launch_bounds__(256) void transpose16_multi_kernel(const TransposeJob* __restrict__ jobs, int njobs) {
+    __shared__ uint16_t t[64][72];
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) {                                     // last job whose first block <= blockIdx.x (uniform)
+        const int mid = (lo + hi + 1) >> 1;
+        if (jobs[mid].blk0 <= blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const TransposeJob j = jobs[lo];
+    const int tile = (int)(blockIdx.x - j.blk0), tr = tile % j.tiles_r, tc = tile / j.tiles_r;
+    transpose16_vec_tile(j.src, j.dst, j.R, j.C, j.C, j.R, 0, 0, tr * 64, tc * 64, t);
+}
 // 3x3 conv dgrad weights: Wd[ci, t', co] = Wp[co, 8 - t', ci]  (taps flipped, channels swapped) so that
 // dX = conv3x3(dY, Wd) runs on the forward implicit-GEMM kernel.  Wp [Co, 9, Ci] tap-major (16-bit).
 __global__ void conv_dgrad_pack_kernel(const uint16_t* __restrict__ wp, uint16_t* __restrict__ wd, int Co, int Ci) {
@@ -718,18 +740,29 @@ __global__ void conv_dgrad_pack_kernel(const uint16_t* __restrict__ wp, uint16_t
 }
 // GELU (erf form, timm Mlp.act) backward: dx = dy * (Phi(z) + z * phi(z)), z = the pre-activation (fc1 output + bias).
 // quick != 0: CLIP's QuickGELU x * sigmoid(1.702 x): d/dx = sg * (1 + 1.702 x (1 - sg)), sg = sigmoid(1.702 x)
+__device__ __forceinline__ float gelu_grad(float z, int quick) {
+    if (quick) {
+        const float sg = 1.0f / (1.0f + __expf(-1.702f * z));
+        return sg * (1.0f + 1.702f * z * (1.0f - sg));
+    }
+    return 0.5f * (1.0f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z);
+}
 __global__ void gelu_backward_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ pre, uint16_t* __restrict__ dx,
                                      size_t n, int dtype, int quick) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float z = load_as_f32(pre, i, dtype), g = load_as_f32(dy, i, dtype);
-        float d;
-        if (quick) {
-            const float sg = 1.0f / (1.0f + __expf(-1.702f * z));
-            d = sg * (1.0f + 1.702f * z * (1.0f - sg));
-        } else {
-            d = 0.5f * (1.0f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z);
-        }
-        store_from_f32(dx, i, dtype, g * d);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        store_from_f32(dx, i, dtype, load_as_f32(dy, i, dtype) * gelu_grad(load_as_f32(pre, i, dtype), quick));
+}
+// 16 bytes per lane on all three tensors (n % 8 == 0, 16-byte aligned bases)
+__global__ void gelu_backward_vec_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ pre, uint16_t* __restrict__ dx,
+                                         size_t n8, int dtype, int quick) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 ug = reinterpret_cast<const uint4*>(dy)[i], uz = reinterpret_cast<const uint4*>(pre)[i];
+        const uint16_t *eg = reinterpret_cast<const uint16_t*>(&ug), *ez = reinterpret_cast<const uint16_t*>(&uz);
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = load_as_f32(eg, k, dtype) * gelu_grad(load_as_f32(ez, k, dtype), quick);
+        reinterpret_cast<uint4*>(dx)[i] = make_uint4(pack2_dt(v[0], v[1], dtype), pack2_dt(v[2], v[3], dtype),
+                                                     pack2_dt(v[4], v[5], dtype), pack2_dt(v[6], v[7], dtype));
     }
 }
 // x2 bilinear (align_corners=True) backward, NHWC 16-bit: d_in (padded [B,H+2,W+2,C], interior written) gathers the
@@ -817,84 +850,180 @@ __global__ void qkv_grad_pack_kernel(const float* __restrict__ dq, const float* 
 }
 // ---- train-mode BatchNorm2d on the padded-NHWC maps (DPT ResidualConvUnit bn1/bn2, lseg_blocks.py:276-283, train()) ----
 // The maps carry a zero border, so per-channel sums over ALL padded positions equal the sums over the image; n = B*H*W.
-// stats[0..C) = sum_x, stats[C..2C) = sum_x^2   (fp32 atomics over row chunks; zeroed by the launcher)
-__global__ void bn_stats_kernel(const uint16_t* __restrict__ x, int dtype, float* __restrict__ stats, int Mp, int C, int rows_per_block) {
+// Column statistics of 16-bit row-major matrices, 16 bytes per lane: a block = 32 column groups of 8 columns x 8 row lanes over
+// `rows_per_block` rows; the row lanes are summed through LDS, then one fp32 atomic per column and block (out zeroed by the launcher).
+//   MODE 0: out[c] += sum_r a[r,c]                                   (bias gradients)
+//   MODE 1: out[c] += sum a ; out[C+c] += sum a^2                    (BatchNorm batch statistics)
+//   MODE 2: out[c] += sum a ; out[C+c] += sum a * (b - mean_c) * rstd_c   (BatchNorm backward: a = dy, b = x, mean/rstd from `stats`)
+template <int MODE>
+__global__ __launch_bounds__(256) void colstats16_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
+                                                         const float* __restrict__ stats, float inv_n, float eps, int dtype,
+                                                         float* __restrict__ out, int R, int C, int ld, int rows_per_block) {
+    __shared__ float red[MODE == 0 ? 1 : 2][8][32][8];
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c0 = (blockIdx.x * 32 + cg) * 8;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, q[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float mean[8], rstd[8];
+    if (MODE == 2) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = c0 + k < C ? c0 + k : C - 1;
+            mean[k] = stats[c] * inv_n;
+            rstd[k] = rsqrtf(fmaxf(stats[C + c] * inv_n - mean[k] * mean[k], 0.f) + eps);
+        }
+    }
+    if (c0 + 8 <= C) {
+        for (int r = r0 + rl; r < r1; r += 8) {
+            const uint4 u = *reinterpret_cast<const uint4*>(a + (size_t)r * ld + c0);
+            const uint16_t* e = reinterpret_cast<const uint16_t*>(&u);
+            if (MODE == 2) {
+                const uint4 ux = *reinterpret_cast<const uint4*>(b + (size_t)r * ld + c0);
+                const uint16_t* ex = reinterpret_cast<const uint16_t*>(&ux);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float g = load_as_f32(e, k, dtype);
+                    s[k] += g;
+                    q[k] += g * (load_as_f32(ex, k, dtype) - mean[k]) * rstd[k];      // border rows: g = 0
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float v = load_as_f32(e, k, dtype);
+                    s[k] += v;
+                    if (MODE == 1) q[k] += v * v;
+                }
+            }
+        }
+    } else if (c0 < C) {
+        for (int r = r0 + rl; r < r1; r += 8)
+            for (int k = 0; k < 8 && c0 + k < C; ++k) {
+                const float v = load_as_f32(a, (size_t)r * ld + c0 + k, dtype);
+                s[k] += v;
+                if (MODE == 1) q[k] += v * v;
+                if (MODE == 2) q[k] += v * (load_as_f32(b, (size_t)r * ld + c0 + k, dtype) - mean[k]) * rstd[k];
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        red[0][rl][cg][k] = s[k];
+        if (MODE != 0) red[MODE == 0 ? 0 : 1][rl][cg][k] = q[k];
+    }
+    __syncthreads();
+    const int k = threadIdx.x & 7, g = threadIdx.x >> 3;        // 256 threads = 32 groups x 8 columns
+    const int c = (blockIdx.x * 32 + g) * 8 + k;
+    if (c < C) {
+        float t = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            t += red[0][j][g][k];
+            if (MODE != 0) t2 += red[MODE == 0 ? 0 : 1][j][g][k];
+        }
+        atomicAdd(&out[c], t);
+        if (MODE != 0) atomicAdd(&out[C + c], t2);
+    }
+}
+__global__ void colsum16_scalar_kernel(const uint16_t* __restrict__ in, int dtype, float* __restrict__ out, int R, int C, int ld, int rows_per_block) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const int r0 = blockIdx.y * rows_per_block, r1 = min(Mp, r0 + rows_per_block);
-    float s = 0.f, q = 0.f;
-    for (int r = r0; r < r1; ++r) { const float v = load_as_f32(x, (size_t)r * C + c, dtype); s += v; q += v * v; }
-    atomicAdd(&stats[c], s);
-    atomicAdd(&stats[C + c], q);
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += load_as_f32(in, (size_t)r * ld + c, dtype);
+    atomicAdd(&out[c], s);
 }
-// y = gamma * (x - mean) * rstd + beta on the interior pixels (the border stays zero); mean/var from bn_stats (biased var)
+// y = gamma * (x - mean) * rstd + beta on the interior pixels (the border stays zero); mean/var from the batch sums (biased var)
 // res1 / res2 (same geometry, may be NULL): y += res1 + res2 -- the RCU skip connection and the fusion add (lseg_blocks.py:288,347).
 // inv_n = 1 / (pixels the sums were taken over): B*H*W, times the world size once the sums are all-reduced (SyncBatchNorm).
+// 8 channels (16 bytes) per lane; C % 8 == 0.
 __global__ void bn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, const float* __restrict__ stats,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, int B, int H, int W, int C,
                                 float eps, int dtype, float inv_n, const uint16_t* __restrict__ res1, const uint16_t* __restrict__ res2) {
-    const size_t n = (size_t)B * H * W * C;
+    const int c8n = C >> 3;
+    const size_t n = (size_t)B * H * W * c8n;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        size_t p = i / C;
+        const int c0 = (int)(i % c8n) * 8;
+        size_t p = i / c8n;
         const int xx = (int)(p % W); p /= W;
         const int yy = (int)(p % H);
         const int b = (int)(p / H);
-        const size_t off = (((size_t)b * (H + 2) + yy + 1) * (W + 2) + xx + 1) * C + c;
-        const float mean = stats[c] * inv_n;
-        const float var = fmaxf(stats[C + c] * inv_n - mean * mean, 0.f);
-        float v = gamma[c] * (load_as_f32(x, off, dtype) - mean) * rsqrtf(var + eps) + beta[c];
-        if (res1) v += load_as_f32(res1, off, dtype);
-        if (res2) v += load_as_f32(res2, off, dtype);
-        store_from_f32(y, off, dtype, v);
+        const size_t off = (((size_t)b * (H + 2) + yy + 1) * (W + 2) + xx + 1) * C + c0;
+        const uint4 ux = *reinterpret_cast<const uint4*>(x + off);
+        uint4 u1 = make_uint4(0u, 0u, 0u, 0u), u2 = u1;
+        if (res1) u1 = *reinterpret_cast<const uint4*>(res1 + off);
+        if (res2) u2 = *reinterpret_cast<const uint4*>(res2 + off);
+        const uint16_t *ex = reinterpret_cast<const uint16_t*>(&ux), *e1 = reinterpret_cast<const uint16_t*>(&u1), *e2 = reinterpret_cast<const uint16_t*>(&u2);
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = c0 + k;
+            const float mean = stats[c] * inv_n;
+            const float var = fmaxf(stats[C + c] * inv_n - mean * mean, 0.f);
+            v[k] = gamma[c] * (load_as_f32(ex, k, dtype) - mean) * rsqrtf(var + eps) + beta[c];
+            if (res1) v[k] += load_as_f32(e1, k, dtype);
+            if (res2) v[k] += load_as_f32(e2, k, dtype);
+        }
+        *reinterpret_cast<uint4*>(y + off) = make_uint4(pack2_dt(v[0], v[1], dtype), pack2_dt(v[2], v[3], dtype),
+                                                        pack2_dt(v[4], v[5], dtype), pack2_dt(v[6], v[7], dtype));
     }
 }
-// backward sums: bstats[0..C) = sum dy, bstats[C..2C) = sum dy * xhat
-__global__ void bn_bwd_stats_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x, const float* __restrict__ stats,
-                                    float* __restrict__ bstats, int Mp, int C, float inv_n, float eps, int dtype, int rows_per_block) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float mean = stats[c] * inv_n;
-    const float rstd = rsqrtf(fmaxf(stats[C + c] * inv_n - mean * mean, 0.f) + eps);
-    const int r0 = blockIdx.y * rows_per_block, r1 = min(Mp, r0 + rows_per_block);
-    float s = 0.f, q = 0.f;
-    for (int r = r0; r < r1; ++r) {
-        const float g = load_as_f32(dy, (size_t)r * C + c, dtype);
-        s += g;
-        q += g * (load_as_f32(x, (size_t)r * C + c, dtype) - mean) * rstd;      // border: g = 0
-    }
-    atomicAdd(&bstats[c], s);
-    atomicAdd(&bstats[C + c], q);
-}
-// dx = gamma * rstd * (dy - mean(dy) - xhat * mean(dy * xhat)) on the interior
+// dx = gamma * rstd * (dy - mean(dy) - xhat * mean(dy * xhat)) on the interior; bstats = [sum dy, sum dy * xhat]
 __global__ void bn_bwd_apply_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x, uint16_t* __restrict__ dx,
                                     const float* __restrict__ stats, const float* __restrict__ bstats, const float* __restrict__ gamma,
                                     int B, int H, int W, int C, float eps, int dtype, float inv_n) {
-    const size_t n = (size_t)B * H * W * C;
+    const int c8n = C >> 3;
+    const size_t n = (size_t)B * H * W * c8n;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        size_t p = i / C;
+        const int c0 = (int)(i % c8n) * 8;
+        size_t p = i / c8n;
         const int xx = (int)(p % W); p /= W;
         const int yy = (int)(p % H);
         const int b = (int)(p / H);
-        const size_t off = (((size_t)b * (H + 2) + yy + 1) * (W + 2) + xx + 1) * C + c;
-        const float mean = stats[c] * inv_n;
-        const float rstd = rsqrtf(fmaxf(stats[C + c] * inv_n - mean * mean, 0.f) + eps);
-        const float xh = (load_as_f32(x, off, dtype) - mean) * rstd;
-        store_from_f32(dx, off, dtype, gamma[c] * rstd * (load_as_f32(dy, off, dtype) - bstats[c] * inv_n - xh * bstats[C + c] * inv_n));
+        const size_t off = (((size_t)b * (H + 2) + yy + 1) * (W + 2) + xx + 1) * C + c0;
+        const uint4 ux = *reinterpret_cast<const uint4*>(x + off), ug = *reinterpret_cast<const uint4*>(dy + off);
+        const uint16_t *ex = reinterpret_cast<const uint16_t*>(&ux), *eg = reinterpret_cast<const uint16_t*>(&ug);
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = c0 + k;
+            const float mean = stats[c] * inv_n;
+            const float rstd = rsqrtf(fmaxf(stats[C + c] * inv_n - mean * mean, 0.f) + eps);
+            const float xh = (load_as_f32(ex, k, dtype) - mean) * rstd;
+            v[k] = gamma[c] * rstd * (load_as_f32(eg, k, dtype) - bstats[c] * inv_n - xh * bstats[C + c] * inv_n);
+        }
+        *reinterpret_cast<uint4*>(dx + off) = make_uint4(pack2_dt(v[0], v[1], dtype), pack2_dt(v[2], v[3], dtype),
+                                                         pack2_dt(v[4], v[5], dtype), pack2_dt(v[6], v[7], dtype));
     }
 }
-// ReLU backward: dx = dy where x > 0 (16-bit tensors of any shape)
+// ReLU backward: dx = dy where x > 0 (16-bit tensors of any shape); positive <=> sign bit clear and not zero (bf16 and fp16)
+__device__ __forceinline__ uint32_t relu_mask2(uint32_t x2) {
+    return (((x2 & 0xffffu) != 0 && !(x2 & 0x8000u)) ? 0xffffu : 0u) | (((x2 >> 16) != 0 && !(x2 & 0x80000000u)) ? 0xffff0000u : 0u);
+}
 __global__ void relu_backward_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x, uint16_t* __restrict__ dx, size_t n) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n8 = n >> 3;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 g = reinterpret_cast<const uint4*>(dy)[i], v = reinterpret_cast<const uint4*>(x)[i];
+        reinterpret_cast<uint4*>(dx)[i] = make_uint4(g.x & relu_mask2(v.x), g.y & relu_mask2(v.y), g.z & relu_mask2(v.z), g.w & relu_mask2(v.w));
+    }
+    for (size_t i = (n8 << 3) + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const uint16_t v = x[i];
-        dx[i] = (v != 0 && !(v & 0x8000)) ? dy[i] : (uint16_t)0;       // positive <=> sign bit clear and not zero (bf16 and fp16)
+        dx[i] = (v != 0 && !(v & 0x8000)) ? dy[i] : (uint16_t)0;
     }
 }
 // dx = (x > 0 ? dy : 0) + add : ReLU backward merged with the skip connection's gradient (RCU: out = f(relu(x)) + x)
 __global__ void relu_backward_add_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x, const uint16_t* __restrict__ add,
                                          uint16_t* __restrict__ dx, size_t n, int dtype) {
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n8 = n >> 3;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const uint4 ug = reinterpret_cast<const uint4*>(dy)[i], uv = reinterpret_cast<const uint4*>(x)[i], ua = reinterpret_cast<const uint4*>(add)[i];
+        const uint16_t *eg = reinterpret_cast<const uint16_t*>(&ug), *ev = reinterpret_cast<const uint16_t*>(&uv), *ea = reinterpret_cast<const uint16_t*>(&ua);
+        float r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] = ((ev[k] != 0 && !(ev[k] & 0x8000)) ? load_as_f32(eg, k, dtype) : 0.f) + load_as_f32(ea, k, dtype);
+        reinterpret_cast<uint4*>(dx)[i] = make_uint4(pack2_dt(r[0], r[1], dtype), pack2_dt(r[2], r[3], dtype),
+                                                     pack2_dt(r[4], r[5], dtype), pack2_dt(r[6], r[7], dtype));
+    }
+    for (size_t i = (n8 << 3) + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const uint16_t v = x[i];
         const float g = (v != 0 && !(v & 0x8000)) ? load_as_f32(dy, i, dtype) : 0.f;
         store_from_f32(dx, i, dtype, g + load_as_f32(add, i, dtype));
@@ -935,6 +1064,109 @@ __global__ void upsample2x_planes_bwd_rows_kernel(const float* __restrict__ dout
         store_from_f32(rows, ((size_t)b * H * W + (size_t)y * W + x) * ldk + k, dtype, acc);
     }
 }
+// Fused backward of  CrossEntropyLoss(ignore_index)( output_conv(low) )  (lsegmentation_module.py:72 on lseg_net.py:203): the rows
+// d_low_rows[(b*h*w + p), k] of the correlation's dY straight from the LOW-resolution logits `low` [B,K,h,w], the target mask
+// [B,2h,2w] and the per-pixel log-sum-exp seg_stats saved -- the [B,K,2h,2w] logits and their gradient (2 x 138 MB per image at
+// K = 150, 480x480) are never materialised:
+//   d_low[b,k,y,x] = sum over the full-resolution pixels P whose bilinear footprint touches (y,x) of
+//                    w(P -> y,x) * (exp(z_k(P) - lse(P)) - [k = t(P)]) / n_valid,     z_k(P) = the x2 bilinear of low[b,k] at P.
+// With align_corners=True and an exact x2 grid the rows touching y are Y in [2y-1, 2y+2] (checked on the host for the geometry at
+// hand), and every tap of those rows lies in the 3x3 neighbourhood of (y,x): one lane = one low-resolution pixel, 9 loads per class.
+__global__ __launch_bounds__(256) void upsample_ce_bwd_rows_kernel(const float* __restrict__ low, const long long* __restrict__ target,
+                                                                   const float* __restrict__ lse, const double* __restrict__ nll,
+                                                                   uint16_t* __restrict__ rows, int B, int K, int H, int W, int ldk,
+                                                                   int ignore_index, int dtype) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const size_t npix = (size_t)B * H * W;
+    const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const int x = (int)(i % W);
+    const int y = (int)((i / W) % H);
+    const int b = (int)(i / ((size_t)W * H));
+    const float inv_n = nll[1] > 0.0 ? (float)(1.0 / nll[1]) : 0.f;
+    const float ry = (float)(H - 1) / (float)(Ho - 1), rx = (float)(W - 1) / (float)(Wo - 1);
+    // the 4 candidate rows / columns: weight onto (y, x), and where their own two taps sit inside the 3x3 neighbourhood
+    float wy[4], ly[4], wx[4], lx[4];
+    int jy[4], jx[4];                       // index of the first tap relative to y-1 / x-1 (0 or 1)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int yo = 2 * y - 1 + r;
+        wy[r] = 0.f; ly[r] = 0.f; jy[r] = 0;
+        if (yo >= 0 && yo < Ho) {
+            const float sy = ry * (float)yo;
+            const int y0 = (int)sy, y1 = y0 + (y0 < H - 1);
+            const float l = sy - (float)y0;
+            wy[r] = (y0 == y ? 1.f - l : 0.f) + (y1 == y ? l : 0.f);
+            ly[r] = l; jy[r] = y0 - (y - 1);
+        }
+        const int xo = 2 * x - 1 + r;
+        wx[r] = 0.f; lx[r] = 0.f; jx[r] = 0;
+        if (xo >= 0 && xo < Wo) {
+            const float sx = rx * (float)xo;
+            const int x0 = (int)sx, x1 = x0 + (x0 < W - 1);
+            const float l = sx - (float)x0;
+            wx[r] = (x0 == x ? 1.f - l : 0.f) + (x1 == x ? l : 0.f);
+            lx[r] = l; jx[r] = x0 - (x - 1);
+        }
+    }
+    // per footprint pixel: coefficient (0 outside the image / ignored / zero weight), its log-sum-exp and its label
+    float coef[4][4], lz[4][4];
+    int tl[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int yo = 2 * y - 1 + r, xo = 2 * x - 1 + c;
+            coef[r][c] = 0.f; lz[r][c] = 1e30f; tl[r][c] = -1;      // inactive: exp(z - 1e30) = 0
+            const float wgt = wy[r] * wx[c];
+            if (wgt != 0.f) {
+                const size_t pi = ((size_t)b * Ho + yo) * Wo + xo;
+                const long long t = target[pi];
+                if (t != (long long)ignore_index && t >= 0 && t < K) { coef[r][c] = wgt * inv_n; lz[r][c] = lse[pi]; tl[r][c] = (int)t; }
+            }
+        }
+    // clamped 3x3 neighbourhood offsets (rows / columns outside the map are never selected with a non-zero weight)
+    const int ya = y > 0 ? y - 1 : 0, yb = y < H - 1 ? y + 1 : H - 1, xa = x > 0 ? x - 1 : 0, xb = x < W - 1 ? x + 1 : W - 1;
+    const int ro[3] = {ya * W, y * W, yb * W}, co[3] = {xa, x, xb};
+    const float* plane = low + (size_t)b * K * H * W;
+    uint16_t* orow = rows + i * (size_t)ldk;
+    for (int k0 = 0; k0 < ldk; k0 += 8) {
+        float out[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int k = k0 + kk;
+            float acc = 0.f;
+            if (k < K) {
+                const float* pl = plane + (size_t)k * H * W;
+                float L[3][3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) L[a][c] = pl[ro[a] + co[c]];
+                // horizontal interpolation of the three low rows at the 4 footprint columns (upsample_bilinear2d's association)
+                float Hc[3][4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        const float p0 = jx[c] ? L[a][1] : L[a][0], p1 = jx[c] ? L[a][2] : L[a][1];
+                        Hc[a][c] = (1.f - lx[c]) * p0 + lx[c] * p1;
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float q0 = jy[r] ? Hc[1][c] : Hc[0][c], q1 = jy[r] ? Hc[2][c] : Hc[1][c];
+                        const float z = (1.f - ly[r]) * q0 + ly[r] * q1;
+                        acc += coef[r][c] * (__expf(z - lz[r][c]) - (tl[r][c] == k ? 1.f : 0.f));
+                    }
+            }
+            out[kk] = acc;
+        }
+        *reinterpret_cast<uint4*>(orow + k0) = make_uint4(pack2_dt(out[0], out[1], dtype), pack2_dt(out[2], out[3], dtype),
+                                                          pack2_dt(out[4], out[5], dtype), pack2_dt(out[6], out[7], dtype));
+    }
+}
 // backward of a = scale * x / ||x||_2 (row-wise; the fp16 roundings of the forward are treated as identity):
 //   dx = (scale / ||x||) * (da - xh * (xh . da)),  xh = x / ||x||      x fp32 [M,C], da 16-bit, dx 16-bit
 template <int MAXV>
@@ -973,52 +1205,24 @@ __global__ __launch_bounds__(256) void l2norm_scale_bwd_kernel(const uint16_t* _
         }
     }
 }
-// out[c] += sum_r in[r, c] (bias gradient); out must be zeroed; fp32 atomics across row chunks.
-// A block = 32 column groups of 8 columns (16-byte loads) x 8 row lanes; the row lanes are summed through LDS.
-__global__ __launch_bounds__(256) void colsum16_kernel(const uint16_t* __restrict__ in, int dtype, float* __restrict__ out, int R, int C,
-                                                       int ld, int rows_per_block) {
-    __shared__ float red[8][32][8];
-    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
-    const int c0 = (blockIdx.x * 32 + cg) * 8;
-    const int r0 = blockIdx.y * rows_per_block;
-    const int r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
-    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (c0 + 8 <= C) {
-        for (int r = r0 + rl; r < r1; r += 8) {
-            const uint4 u = *reinterpret_cast<const uint4*>(in + (size_t)r * ld + c0);
-            const uint16_t* e = reinterpret_cast<const uint16_t*>(&u);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) s[k] += load_as_f32(e, k, dtype);
-        }
-    } else if (c0 < C) {
-        for (int r = r0 + rl; r < r1; r += 8)
-            for (int k = 0; k < 8 && c0 + k < C; ++k) s[k] += load_as_f32(in, (size_t)r * ld + c0 + k, dtype);
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) red[rl][cg][k] = s[k];
-    __syncthreads();
-    const int k = threadIdx.x & 7, g = threadIdx.x >> 3;        // 256 threads = 32 groups x 8 columns
-    const int c = (blockIdx.x * 32 + g) * 8 + k;
-    if (c < C) {
-        float t = 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) t += red[q][g][k];
-        atomicAdd(&out[c], t);
-    }
-}
-// dst[c] (+)= sum over the nb partial rows of src [nb, ld] (fixed order: deterministic).  Block = 64 columns x 4 row lanes.
-__global__ __launch_bounds__(256) void colreduce_kernel(const float* __restrict__ src, float* __restrict__ dst, int nb, int C, int ld, int accumulate) {
-    __shared__ float red[4][64];
+// dst[c] (+)= sum over the nb partial rows of src [nb, ld] (fixed order: deterministic).  Block = 64 columns x 16 row lanes;
+// columns >= C go to dst2[c - C] (LayerNorm backward: one launch reduces [d gamma | d beta]).
+__global__ __launch_bounds__(1024) void colreduce_kernel(const float* __restrict__ src, float* __restrict__ dst, float* __restrict__ dst2,
+                                                         int nb, int C, int C2, int ld, int accumulate) {
+    __shared__ float red[16][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     float s = 0.f;
-    if (c < C)
-        for (int r = rl; r < nb; r += 4) s += src[(size_t)r * ld + c];
+    if (c < C + C2)
+        for (int r = rl; r < nb; r += 16) s += src[(size_t)r * ld + c];
     red[rl][cl] = s;
     __syncthreads();
-    if (rl == 0 && c < C) {
-        const float t = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
-        dst[c] = accumulate ? dst[c] + t : t;
+    if (rl == 0 && c < C + C2) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += red[j][cl];
+        float* o = c < C ? dst + c : dst2 + (c - C);
+        *o = accumulate ? *o + t : t;
     }
 }
 // split-K partial results [nsplit][n] -> dst[n] (+)= sum_s part[s][n]   (n % 4 == 0; 16 bytes per lane)
@@ -1050,7 +1254,7 @@ __global__ void sum_partials_kernel(const float* __restrict__ part, float* __res
 __global__ __launch_bounds__(256) void seg_stats_kernel(const float* __restrict__ scores, const long long* __restrict__ target,
                                                         int K, int HW, size_t npix, int ignore_index,
                                                         unsigned long long* __restrict__ counts, double* __restrict__ nll,
-                                                        uint8_t* __restrict__ argmax_out, int up, int h, int w) {
+                                                        uint8_t* __restrict__ argmax_out, int up, int h, int w, float* __restrict__ lse_out) {
     extern __shared__ unsigned int hist[];                // [3K] per-block class histograms + [2] pixel counts
     for (int i = threadIdx.x; i < 3 * K + 2; i += blockDim.x) hist[i] = 0;
     __syncthreads();
@@ -1094,6 +1298,7 @@ __global__ __launch_bounds__(256) void seg_stats_kernel(const float* __restrict_
             if (k == t) at_t = v;
         }
         if (argmax_out) argmax_out[i] = (uint8_t)arg;
+        if (lse_out) lse_out[i] = m + __logf(ssum);          // saved for the fused cross-entropy backward
         if (!target) continue;
         const long long t1 = t + 1;                        // metrics.py: target + 1, predict + 1
         const int pred1 = arg + 1;
@@ -1197,19 +1402,47 @@ __global__ void unpixshuf_kernel(const uint16_t* __restrict__ dl, uint16_t* __re
 // backward of the ProjectReadout concat (lseg_vit.py:87-88): d_cat [B*np, 2D] (16-bit) accumulated into the fp32 gradient of
 // the hooked activation gx [B, ntok, D]:  gx[b, 1+p, :] += d_cat[b*np+p, :D] ;  gx[b, 0, :] += sum_p d_cat[b*np+p, D:]
 __global__ void readout_cat_bwd_kernel(const uint16_t* __restrict__ dcat, float* __restrict__ gx, int B, int ntok, int D, int dtype) {
-    const int np = ntok - 1;
-    const size_t total = (size_t)B * ntok * D;
+    const int np = ntok - 1, d8n = D >> 3;                // patch rows: 8 columns (16 bytes of d_cat, 32 bytes of gx) per lane
+    const size_t total = (size_t)B * np * d8n;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int d = (int)(idx % D);
-        const size_t bt = idx / D;
-        const int t = (int)(bt % ntok), b = (int)(bt / ntok);
-        float acc = 0.f;
-        if (t > 0) {
-            acc = load_as_f32(dcat, ((size_t)b * np + t - 1) * 2 * D + d, dtype);
-        } else {
-            for (int p = 0; p < np; ++p) acc += load_as_f32(dcat, ((size_t)b * np + p) * 2 * D + D + d, dtype);
+        const int d0 = (int)(idx % d8n) * 8;
+        const size_t bp = idx / d8n;
+        const int p = (int)(bp % np), b = (int)(bp / np);
+        const uint4 u = *reinterpret_cast<const uint4*>(dcat + bp * 2 * D + d0);
+        const uint16_t* e = reinterpret_cast<const uint16_t*>(&u);
+        float4* o = reinterpret_cast<float4*>(gx + ((size_t)b * ntok + 1 + p) * D + d0);
+        float4 a0 = o[0], a1 = o[1];
+        a0.x += load_as_f32(e, 0, dtype); a0.y += load_as_f32(e, 1, dtype); a0.z += load_as_f32(e, 2, dtype); a0.w += load_as_f32(e, 3, dtype);
+        a1.x += load_as_f32(e, 4, dtype); a1.y += load_as_f32(e, 5, dtype); a1.z += load_as_f32(e, 6, dtype); a1.w += load_as_f32(e, 7, dtype);
+        o[0] = a0; o[1] = a1;
+    }
+}
+// the cls row: one block per (image, 256 columns) = 32 column groups x 32 row lanes, fixed summation order (no atomics)
+__global__ __launch_bounds__(1024) void readout_cls_bwd_kernel(const uint16_t* __restrict__ dcat, float* __restrict__ gx, int ntok, int D, int dtype) {
+    __shared__ float red[32][32][9];
+    const int np = ntok - 1, b = blockIdx.y;
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c0 = (blockIdx.x * 32 + cg) * 8;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c0 < D) {
+        for (int p = rl; p < np; p += 32) {
+            const uint4 u = *reinterpret_cast<const uint4*>(dcat + ((size_t)b * np + p) * 2 * D + D + c0);
+            const uint16_t* e = reinterpret_cast<const uint16_t*>(&u);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += load_as_f32(e, k, dtype);
         }
-        gx[idx] += acc;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[rl][cg][k] = s[k];
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int k = threadIdx.x & 7, g = threadIdx.x >> 3;
+        const int c = (blockIdx.x * 32 + g) * 8 + k;
+        if (c < D) {
+            float t = 0.f;
+            for (int j = 0; j < 32; ++j) t += red[j][g][k];
+            gx[(size_t)b * ntok * D + c] += t;
+        }
     }
 }
 // gradient of the embedding stage (lseg_vit.py:179-193) from gx = d x_0 [B, ntok, D] fp32:
@@ -1302,6 +1535,53 @@ __global__ void sgd_kernel(float* __restrict__ w, const float* __restrict__ g, f
         const float wn = wi - lr * mi;
         w[i] = wn;
         if (w16) store_from_f32(w16, i, dtype, wn);
+    }
+}
+
+// the whole optimizer step in ONE launch: block -> (parameter, 4096-element chunk) through a table sorted by first block.  Besides the
+// master / momentum update it refreshes the engine's same-layout copies of the parameter (16-bit MFMA operand and / or fp32 copy).
+__global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdSeg* __restrict__ segs, int nseg, float lr_pre, float lr_scr, float mu, float wd,
+                                                        int first, int dtype) {
+    int lo = 0, hi = nseg - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (segs[mid].blk0 <= blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const SgdSeg sg = segs[lo];
+    const float lr = sg.scratch ? lr_scr : lr_pre;
+    const size_t base = (size_t)(blockIdx.x - sg.blk0) * 4096;
+    if (sg.vec) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const size_t e = base + (size_t)it * 1024 + threadIdx.x * 4;
+            if (e + 4 <= sg.n) {
+                const float4 wi = *reinterpret_cast<const float4*>(sg.w + e), gi = *reinterpret_cast<const float4*>(sg.g + e);
+                float4 mi = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!first) mi = *reinterpret_cast<const float4*>(sg.m + e);
+                const float g0 = gi.x + wd * wi.x, g1 = gi.y + wd * wi.y, g2 = gi.z + wd * wi.z, g3 = gi.w + wd * wi.w;
+                mi.x = first ? g0 : mu * mi.x + g0; mi.y = first ? g1 : mu * mi.y + g1;
+                mi.z = first ? g2 : mu * mi.z + g2; mi.w = first ? g3 : mu * mi.w + g3;
+                const float4 wn = make_float4(wi.x - lr * mi.x, wi.y - lr * mi.y, wi.z - lr * mi.z, wi.w - lr * mi.w);
+                *reinterpret_cast<float4*>(sg.m + e) = mi;
+                *reinterpret_cast<float4*>(sg.w + e) = wn;
+                if (sg.w32) *reinterpret_cast<float4*>(sg.w32 + e) = wn;
+                if (sg.w16) *reinterpret_cast<uint2*>(sg.w16 + e) = make_uint2(pack2_dt(wn.x, wn.y, dtype), pack2_dt(wn.z, wn.w, dtype));
+            }
+        }
+        return;
+    }
+    for (int it = 0; it < 16; ++it) {
+        const size_t e = base + (size_t)it * 256 + threadIdx.x;
+        if (e < sg.n) {
+            const float wi = sg.w[e];
+            const float gi = sg.g[e] + wd * wi;
+            const float mi = first ? gi : mu * sg.m[e] + gi;       // torch: the momentum buffer starts as a copy of the first gradient
+            sg.m[e] = mi;
+            const float wn = wi - lr * mi;
+            sg.w[e] = wn;
+            if (sg.w32) sg.w32[e] = wn;
+            if (sg.w16) store_from_f32(sg.w16, e, dtype, wn);
+        }
     }
 }
 
@@ -1456,8 +1736,9 @@ int launch_argmax_planes(const float* in, uint8_t* out, int B, int K, int HW, hi
 
 int launch_layernorm_backward(const void* dy, int dy_dtype, const float* x, const float* gamma, float* dx, float* dgamma,
                               float* dbeta, int M, int D, float eps, int accumulate, hipStream_t st, int accumulate_params,
-                              float* partial_ws) {
+                              float* partial_ws, void* dx16) {
     if (D % 4 != 0 || D > 64 * 4 * 4) return set_error(LSEG_ERR_UNSUPPORTED, "layernorm backward: D=%d", D);
+    if (dx16 && dy_dtype == DT_F32) return set_error(LSEG_ERR_INVALID, "layernorm backward: the 16-bit copy takes dy's 16-bit type");
     int blocks = (M + 3) / 4;
     if (partial_ws) {
         if (blocks > LN_BWD_PARTIAL_BLOCKS) blocks = LN_BWD_PARTIAL_BLOCKS;
@@ -1468,13 +1749,12 @@ int launch_layernorm_backward(const void* dy, int dy_dtype, const float* x, cons
             LSEG_HIP_TRY(hipMemsetAsync(dbeta, 0, (size_t)D * sizeof(float), st));
         }
     }
-#define LN_BWD(V) hipLaunchKernelGGL(layernorm_bwd_kernel<V>, dim3(blocks), dim3(256), 0, st, dy, dy_dtype, x, gamma, dx, dgamma, dbeta, M, D, eps, accumulate, partial_ws)
+#define LN_BWD(V) hipLaunchKernelGGL(layernorm_bwd_kernel<V>, dim3(blocks), dim3(256), 0, st, dy, dy_dtype, x, gamma, dx, dgamma, dbeta, M, D, eps, accumulate, partial_ws, (uint16_t*)dx16)
     if (D <= 256) LN_BWD(1); else if (D <= 512) LN_BWD(2); else LN_BWD(4);
 #undef LN_BWD
     CHECK_LAUNCH();
     if (partial_ws) {
-        hipLaunchKernelGGL(colreduce_kernel, dim3((D + 63) / 64), dim3(256), 0, st, partial_ws, dgamma, blocks, D, 2 * D, accumulate_params);
-        hipLaunchKernelGGL(colreduce_kernel, dim3((D + 63) / 64), dim3(256), 0, st, partial_ws + D, dbeta, blocks, D, 2 * D, accumulate_params);
+        hipLaunchKernelGGL(colreduce_kernel, dim3((2 * D + 63) / 64), dim3(1024), 0, st, partial_ws, dgamma, dbeta, blocks, D, D, 2 * D, accumulate_params);
         CHECK_LAUNCH();
     }
     return 0;
@@ -1495,7 +1775,10 @@ int launch_conv_dgrad_pack(const void* wp, void* wd, int Co, int Ci, hipStream_t
     return 0;
 }
 int launch_gelu_backward(const void* dy, const void* pre, void* dx, size_t n, int dtype, hipStream_t st, int quick) {
-    hipLaunchKernelGGL(gelu_backward_kernel, dim3(grid_for(n)), dim3(256), 0, st, (const uint16_t*)dy, (const uint16_t*)pre, (uint16_t*)dx, n, dtype, quick);
+    if (!(n & 7) && !(((uintptr_t)dy | (uintptr_t)pre | (uintptr_t)dx) & 15))
+        hipLaunchKernelGGL(gelu_backward_vec_kernel, dim3(grid_for(n / 8)), dim3(256), 0, st, (const uint16_t*)dy, (const uint16_t*)pre, (uint16_t*)dx, n / 8, dtype, quick);
+    else
+        hipLaunchKernelGGL(gelu_backward_kernel, dim3(grid_for(n)), dim3(256), 0, st, (const uint16_t*)dy, (const uint16_t*)pre, (uint16_t*)dx, n, dtype, quick);
     CHECK_LAUNCH();
     return 0;
 }
@@ -1523,32 +1806,42 @@ int launch_qkv_grad_pack(const float* dq, const float* dk, const float* dv, void
 }
 // BatchNorm in train mode, split so that a SyncBatchNorm exchange (all-reduce of the [2C] sums) can sit between the two halves.
 // `count` = pixels behind the sums (B*H*W, times the world size after the exchange).
+// rows per block of the column-statistics kernels: ~1500 blocks over the chip, at least 32 rows (4 per row lane) per block
+static int colstats_rows(int R, int C) {
+    const int cb = (C + 255) / 256;
+    int rpb = (int)(((long)R * cb + 1499) / 1500);
+    rpb = (rpb + 7) / 8 * 8;
+    return rpb < 32 ? 32 : rpb;
+}
 int launch_bn_stats(const void* x, float* stats, int B, int H, int W, int C, int dtype, hipStream_t st) {
-    const int Mp = B * (H + 2) * (W + 2), rpb = 128;
+    const int Mp = B * (H + 2) * (W + 2), rpb = colstats_rows(Mp, C);
     LSEG_HIP_TRY(hipMemsetAsync(stats, 0, (size_t)2 * C * sizeof(float), st));
-    hipLaunchKernelGGL(bn_stats_kernel, dim3((C + 255) / 256, (Mp + rpb - 1) / rpb), dim3(256), 0, st, (const uint16_t*)x, dtype, stats, Mp, C, rpb);
+    hipLaunchKernelGGL(colstats16_kernel<1>, dim3((C + 255) / 256, (Mp + rpb - 1) / rpb), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)nullptr,
+                       (const float*)nullptr, 0.f, 0.f, dtype, stats, Mp, C, C, rpb);
     CHECK_LAUNCH();
     return 0;
 }
 int launch_bn_apply(const void* x, void* y, const float* stats, const float* gamma, const float* beta, const void* res1, const void* res2,
                     int B, int H, int W, int C, float eps, double count, int dtype, hipStream_t st) {
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for((size_t)B * H * W * C)), dim3(256), 0, st, (const uint16_t*)x, (uint16_t*)y,
+    if (C % 8) return set_error(LSEG_ERR_UNSUPPORTED, "batch norm: C=%d must be a multiple of 8", C);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for((size_t)B * H * W * (C / 8))), dim3(256), 0, st, (const uint16_t*)x, (uint16_t*)y,
                        stats, gamma, beta, B, H, W, C, eps, dtype, (float)(1.0 / count), (const uint16_t*)res1, (const uint16_t*)res2);
     CHECK_LAUNCH();
     return 0;
 }
 int launch_bn_bwd_stats(const void* dy, const void* x, const float* stats, float* bstats, int B, int H, int W, int C, float eps,
                         double count, int dtype, hipStream_t st) {
-    const int Mp = B * (H + 2) * (W + 2), rpb = 128;
+    const int Mp = B * (H + 2) * (W + 2), rpb = colstats_rows(Mp, C);
     LSEG_HIP_TRY(hipMemsetAsync(bstats, 0, (size_t)2 * C * sizeof(float), st));
-    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((C + 255) / 256, (Mp + rpb - 1) / rpb), dim3(256), 0, st, (const uint16_t*)dy,
-                       (const uint16_t*)x, stats, bstats, Mp, C, (float)(1.0 / count), eps, dtype, rpb);
+    hipLaunchKernelGGL(colstats16_kernel<2>, dim3((C + 255) / 256, (Mp + rpb - 1) / rpb), dim3(256), 0, st, (const uint16_t*)dy, (const uint16_t*)x,
+                       stats, (float)(1.0 / count), eps, dtype, bstats, Mp, C, C, rpb);
     CHECK_LAUNCH();
     return 0;
 }
 int launch_bn_bwd_apply(const void* dy, const void* x, const float* stats, const float* bstats, const float* gamma, void* dx,
                         int B, int H, int W, int C, float eps, double count, int dtype, hipStream_t st) {
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((size_t)B * H * W * C)), dim3(256), 0, st, (const uint16_t*)dy,
+    if (C % 8) return set_error(LSEG_ERR_UNSUPPORTED, "batch norm: C=%d must be a multiple of 8", C);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((size_t)B * H * W * (C / 8))), dim3(256), 0, st, (const uint16_t*)dy,
                        (const uint16_t*)x, (uint16_t*)dx, stats, bstats, gamma, B, H, W, C, eps, dtype, (float)(1.0 / count));
     CHECK_LAUNCH();
     return 0;
@@ -1567,12 +1860,12 @@ int launch_bn_train_backward(const void* dy, const void* x, const float* stats, 
     return launch_bn_bwd_apply(dy, x, stats, bstats, gamma, dx, B, H, W, C, eps, count, dtype, st);
 }
 int launch_relu_backward(const void* dy, const void* x, void* dx, size_t n, hipStream_t st) {
-    hipLaunchKernelGGL(relu_backward_kernel, dim3(grid_for(n)), dim3(256), 0, st, (const uint16_t*)dy, (const uint16_t*)x, (uint16_t*)dx, n);
+    hipLaunchKernelGGL(relu_backward_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, st, (const uint16_t*)dy, (const uint16_t*)x, (uint16_t*)dx, n);
     CHECK_LAUNCH();
     return 0;
 }
 int launch_relu_backward_add(const void* dy, const void* x, const void* add, void* dx, size_t n, int dtype, hipStream_t st) {
-    hipLaunchKernelGGL(relu_backward_add_kernel, dim3(grid_for(n)), dim3(256), 0, st, (const uint16_t*)dy, (const uint16_t*)x,
+    hipLaunchKernelGGL(relu_backward_add_kernel, dim3(grid_for(n / 8 + 1)), dim3(256), 0, st, (const uint16_t*)dy, (const uint16_t*)x,
                        (const uint16_t*)add, (uint16_t*)dx, n, dtype);
     CHECK_LAUNCH();
     return 0;
@@ -1581,6 +1874,29 @@ int launch_upsample2x_planes_backward_rows(const float* dout, void* rows, int B,
     if (ldk < K) return set_error(LSEG_ERR_INVALID, "upsample2x_planes backward: ldk=%d < K=%d", ldk, K);
     hipLaunchKernelGGL(upsample2x_planes_bwd_rows_kernel, dim3(grid_for((size_t)B * K * H * W)), dim3(256), 0, st, dout, (uint16_t*)rows,
                        B, K, H, W, ldk, dtype);
+    CHECK_LAUNCH();
+    return 0;
+}
+// every output row Y whose bilinear footprint touches low row y lies in [2y-1, 2y+2] (same fp32 arithmetic as the kernels)
+static bool x2_footprint_is_4(int H) {
+    const int Ho = 2 * H;
+    const float ry = (float)(H - 1) / (float)(Ho - 1);
+    for (int yo = 0; yo < Ho; ++yo) {
+        const float sy = ry * (float)yo;
+        const int y0 = (int)sy, y1 = y0 + (y0 < H - 1);
+        const float l = sy - (float)y0;
+        if (1.f - l != 0.f && (yo < 2 * y0 - 1 || yo > 2 * y0 + 2)) return false;
+        if (l != 0.f && y1 != y0 && (yo < 2 * y1 - 1 || yo > 2 * y1 + 2)) return false;
+    }
+    return true;
+}
+int launch_upsample_ce_backward_rows(const float* low, const int64_t* target, const float* lse, const double* nll, void* rows, int B, int K,
+                                     int H, int W, int ldk, int ignore_index, int dtype, hipStream_t st) {
+    if (ldk < K || (ldk & 7)) return set_error(LSEG_ERR_INVALID, "fused CE backward: ldk=%d must be a multiple of 8 and >= K=%d", ldk, K);
+    if (!x2_footprint_is_4(H) || !x2_footprint_is_4(W)) return set_error(LSEG_ERR_UNSUPPORTED, "fused CE backward: %dx%d map outside the 4-tap footprint", H, W);
+    const size_t npix = (size_t)B * H * W;
+    hipLaunchKernelGGL(upsample_ce_bwd_rows_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, low,
+                       reinterpret_cast<const long long*>(target), lse, nll, (uint16_t*)rows, B, K, H, W, ldk, ignore_index, dtype);
     CHECK_LAUNCH();
     return 0;
 }
@@ -1595,9 +1911,16 @@ int launch_l2norm_scale_backward(const void* da, int da_dtype, const float* x, v
 }
 int launch_colsum16(const void* in, int dtype, float* out, int R, int C, int ld, hipStream_t st, int accumulate) {
     if (!accumulate) LSEG_HIP_TRY(hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st));
-    const int rpb = R >= 65536 ? 2048 : 256;
+    const bool vec = !(ld & 7) && !((uintptr_t)in & 15);
+    const int rpb = colstats_rows(R, C);
     dim3 grid((C + 255) / 256, (R + rpb - 1) / rpb);
-    hipLaunchKernelGGL(colsum16_kernel, grid, dim3(256), 0, st, (const uint16_t*)in, dtype, out, R, C, ld, rpb);
+    if (!vec) {          // odd leading dimensions (op-level tests): one thread per column and row chunk
+        hipLaunchKernelGGL(colsum16_scalar_kernel, grid, dim3(256), 0, st, (const uint16_t*)in, dtype, out, R, C, ld, rpb);
+        CHECK_LAUNCH();
+        return 0;
+    }
+    hipLaunchKernelGGL(colstats16_kernel<0>, grid, dim3(256), 0, st, (const uint16_t*)in, (const uint16_t*)nullptr, (const float*)nullptr, 0.f, 0.f,
+                       dtype, out, R, C, ld, rpb);
     CHECK_LAUNCH();
     return 0;
 }
@@ -1608,7 +1931,7 @@ int launch_seg_stats(const float* scores, const int64_t* target, int B, int K, i
 }
 // up != 0: scores = low-resolution logits [B,K,h,w], statistics / masks on the x2-upsampled grid (HW = 4*h*w)
 int launch_seg_stats_ex(const float* scores, const int64_t* target, int B, int K, int HW, int ignore_index, unsigned long long* counts,
-                        double* nll, uint8_t* argmax_out, int up, int h, int w, hipStream_t st) {
+                        double* nll, uint8_t* argmax_out, int up, int h, int w, hipStream_t st, float* lse_out) {
     if (K < 1 || K > 4096) return set_error(LSEG_ERR_INVALID, "seg_stats: K=%d", K);
     if (argmax_out && K > 256) return set_error(LSEG_ERR_UNSUPPORTED, "uint8 masks need K <= 256 (K=%d)", K);
     if (target) {
@@ -1618,7 +1941,7 @@ int launch_seg_stats_ex(const float* scores, const int64_t* target, int B, int K
     const size_t npix = (size_t)B * HW;
     int grid = (int)std::min<size_t>((npix + 255) / 256, 256 * 16);
     hipLaunchKernelGGL(seg_stats_kernel, dim3(grid), dim3(256), (size_t)(3 * K + 2) * sizeof(unsigned int), st,
-                       scores, reinterpret_cast<const long long*>(target), K, HW, npix, ignore_index, counts, nll, argmax_out, up, h, w);
+                       scores, reinterpret_cast<const long long*>(target), K, HW, npix, ignore_index, counts, nll, argmax_out, up, h, w, lse_out);
     CHECK_LAUNCH();
     return 0;
 }
@@ -1647,7 +1970,9 @@ int launch_unpixshuf(const void* dl, void* dg, int B, int gh, int gw, int s, int
     return 0;
 }
 int launch_readout_cat_bwd(const void* dcat, float* gx, int B, int ntok, int D, int dtype, hipStream_t st) {
-    hipLaunchKernelGGL(readout_cat_bwd_kernel, dim3(grid_for((size_t)B * ntok * D)), dim3(256), 0, st, (const uint16_t*)dcat, gx, B, ntok, D, dtype);
+    if (D % 8) return set_error(LSEG_ERR_UNSUPPORTED, "readout backward: D=%d must be a multiple of 8", D);
+    hipLaunchKernelGGL(readout_cat_bwd_kernel, dim3(grid_for((size_t)B * (ntok - 1) * (D / 8))), dim3(256), 0, st, (const uint16_t*)dcat, gx, B, ntok, D, dtype);
+    hipLaunchKernelGGL(readout_cls_bwd_kernel, dim3((D + 255) / 256, B), dim3(1024), 0, st, (const uint16_t*)dcat, gx, ntok, D, dtype);
     CHECK_LAUNCH();
     return 0;
 }
@@ -1691,6 +2016,20 @@ int launch_bn_running_update(const float* stats, float* rmean, float* rvar, int 
 }
 int launch_sgd(float* w, const float* g, float* m, void* w16, size_t n, float lr, float mu, float wd, int first, int dtype, hipStream_t st) {
     hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n)), dim3(256), 0, st, w, g, m, (uint16_t*)w16, n, lr, mu, wd, first, dtype);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_sgd_multi(const SgdSeg* dev_segs, int nseg, unsigned blocks, float lr_pre, float lr_scr, float mu, float wd, int first, int dtype,
+                     hipStream_t st) {
+    if (nseg < 1 || blocks < 1) return 0;
+    hipLaunchKernelGGL(sgd_multi_kernel, dim3(blocks), dim3(256), 0, st, dev_segs, nseg, lr_pre, lr_scr, mu, wd, first, dtype);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_transpose16_multi(const TransposeJob* dev_jobs, int njobs, unsigned blocks, hipStream_t st) {
+    if (njobs < 1 || blocks < 1) return 0;
+    hipLaunchKernelGGL(transpose16_multi_kernel, dim3(blocks), dim3(256), 0, st, dev_jobs, njobs);
     CHECK_LAUNCH();
     return 0;
 }

@@ -174,21 +174,33 @@ private:
     uint16_t *rowsA_ = nullptr, *rowsB_ = nullptr;  // row-major 16-bit temporaries (GEMM operand views of gradient maps)
     uint16_t *ddil_ = nullptr, *dtmp_ = nullptr;    // stride-2 reassemble conv: dilated dY, d(1x1 output)
     uint16_t *tn16_ = nullptr;
-    float* last_logits_ = nullptr;
     uint16_t *ws_a_ = nullptr, *ws_b_ = nullptr;    // transposed operands of the wgrad GEMMs
     size_t ws_a_n_ = 0, ws_b_n_ = 0;
     float* ws_part_ = nullptr; size_t ws_part_n_ = 0;   // split-K partial results of the weight-gradient GEMMs
     float* ws_dw_ = nullptr; size_t ws_dw_n_ = 0;   // wgrad output in the engine's packed layout before the re-layout into the parameter's
     float *ws_stats_ = nullptr, *zeros_ = nullptr, *ws_ln_ = nullptr;
-    float *gx_ = nullptr, *dpos_ = nullptr, *logits_ = nullptr, *dlogits_ = nullptr;
+    float *gx_ = nullptr, *dpos_ = nullptr, *lse_px_ = nullptr;     // lse_px_: per-pixel log-sum-exp of the up-sampled logits [B, 2h, 2w]
     char* attn_ws_ = nullptr;              // per-layer scratch of the attention backward (transposed / head-major operand copies)
     uint16_t *g16_ = nullptr, *dmlp_ = nullptr, *dln_ = nullptr, *datt_ = nullptr, *dqkv_ = nullptr, *dtok_ = nullptr;
+    bool g16_valid_ = false;                             // g16_ currently equals the 16-bit rounding of gx_ (written by the LayerNorm backward)
     uint16_t *drows_ = nullptr, *da_ = nullptr, *df_ = nullptr, *tnT_ = nullptr;
     unsigned long long* counts_ = nullptr; double* nll_ = nullptr;
     struct GradSlot { float* ptr = nullptr; size_t n = 0; bool bound = false; };
     std::map<std::string, GradSlot> grads_;
-    std::map<std::string, float*> moms_;   // SGD momentum buffers (fused optimizer)
     bool sgd_first_ = true;
+    // the optimizer step as table-driven launches: one multi-tensor SGD (which also refreshes the same-layout copies finalize() keeps of a
+    // parameter: `direct_`), one multi-matrix transpose for the W^T copies, then only the packs with a real re-layout
+    struct DirectDst { uint16_t* w16 = nullptr; float* w32 = nullptr; bool conflict = false; };
+    std::map<std::string, DirectDst> direct_;
+    void note_direct(const std::string& key, uint16_t* w16, float* w32);
+    bool sgd_owns(const std::string& key) const { return partial_pack_ && sgd_keys_.count(key) != 0; }
+    std::map<std::string, int> sgd_keys_;   // parameters the SGD table updates (and whose direct copies it writes)
+    bool partial_pack_ = false;            // finalize() running inside sgd_step: skip what the optimizer kernel already wrote and the frozen text tower
+    bool eval_stale_ = false;              // eval-only packs (BN-folded convs, commuted head) are behind the masters: refreshed by the next eval forward
+    SgdSeg* sgd_table_ = nullptr; int sgd_nseg_ = 0; unsigned sgd_blocks_ = 0; bool sgd_dirty_ = true;
+    float* mom_flat_ = nullptr; size_t mom_flat_n_ = 0;
+    TransposeJob* wt_table_ = nullptr; int wt_n_ = 0; unsigned wt_blocks_ = 0;
+    int build_sgd_table();
 
     // ---- side stream: the (small, latency-bound) text tower overlaps the image tower ----------------
     hipStream_t text_stream_ = nullptr;

@@ -173,7 +173,15 @@ int Engine::bind(const char* key, const void* p, int dtype, const int64_t* shape
     b.shape.assign(shape, shape + ndim);
     bound_[key] = b;
     finalized_ = false;
+    sgd_dirty_ = true;
     return 0;
+}
+
+void Engine::note_direct(const std::string& key, uint16_t* w16, float* w32) {
+    DirectDst& d = direct_[key];
+    if ((w16 && d.w16 && d.w16 != w16) || (w32 && d.w32 && d.w32 != w32)) d.conflict = true;
+    if (w16) d.w16 = w16;
+    if (w32) d.w32 = w32;
 }
 
 int Engine::need(const std::string& key, BoundParam& out, std::initializer_list<int64_t> shape) {
@@ -191,6 +199,8 @@ int Engine::pack_f32(const std::string& key, size_t n, float*& out, hipStream_t 
     BoundParam p;
     TRY(need(key, p, {(int64_t)n}));
     if (!out) ALLOC(out, float, n);
+    if (p.dtype == LSEG_F32) note_direct(key, nullptr, out);
+    if (sgd_owns(key)) return 0;               // written by the optimizer kernel
     return launch_convert(p.ptr, p.dtype, out, DT_F32, n, st);
 }
 
@@ -217,8 +227,9 @@ int Engine::pack_linear(const std::string& wkey, const std::string& bkey, int n,
     const bool split = image && strict_;
     if (!out.w) { ALLOC(out.w, uint16_t, (size_t)n * k * (split ? 2 : 1)); if (split) plane_[out.w] = (size_t)n * k; }
     out.n = n; out.k = k;
+    if (!split && w.dtype == LSEG_F32 && dt == img_dt_) note_direct(wkey, out.w, nullptr);
     if (split) TRY(launch_convert_split(w.ptr, w.dtype, out.w, (size_t)n * k, (size_t)n * k, st));
-    else TRY(launch_convert(w.ptr, w.dtype, out.w, dt, (size_t)n * k, st));
+    else if (!sgd_owns(wkey)) TRY(launch_convert(w.ptr, w.dtype, out.w, dt, (size_t)n * k, st));
     if (!bkey.empty()) TRY(pack_f32(bkey, n, out.b, st));
     return 0;
 }
@@ -330,6 +341,7 @@ int Engine::finalize(hipStream_t st) {
         TRY(pack_linear(p + "out_conv.weight", p + "out_conv.bias", F, F, img_dt_, R.out_conv, st, true));
         for (int u = 1; u <= 2; ++u) {
             if (u == 1 && r == 4) continue;      // refinenet4.resConfUnit1 never runs (lseg_net.py:176)
+            if (partial_pack_) continue;         // BN-folded packs are eval-only: refreshed lazily (eval_stale_)
             const std::string q = p + "resConfUnit" + std::to_string(u) + ".";
             Rcu& U = u == 1 ? R.u1 : R.u2;
             TRY(pack_conv3(q + "conv1.weight", q + "bn1", "", F, F, F, F, U.c1, st));
@@ -338,7 +350,7 @@ int Engine::finalize(hipStream_t st) {
         R.has_u1 = r != 4;
     }
     TRY(pack_linear("scratch.head1.weight", "scratch.head1.bias", c.out_c, F, img_dt_, head1_, st, true));
-    {   // commuted head: Wc = W_head1 . W_out_conv(refinenet1), bc = W_head1 . b_out_conv + b_head1  (fp32, then packed)
+    if (!partial_pack_) {   // commuted head: Wc = W_head1 . W_out_conv(refinenet1), bc = W_head1 . b_out_conv + b_head1  (fp32, then packed)
         BoundParam wh, bh, wo, bo;
         TRY(need("scratch.head1.weight", wh, {c.out_c, F})); TRY(need("scratch.head1.bias", bh, {c.out_c}));
         TRY(need("scratch.refinenet1.out_conv.weight", wo, {F, F})); TRY(need("scratch.refinenet1.out_conv.bias", bo, {F}));
@@ -358,6 +370,11 @@ int Engine::finalize(hipStream_t st) {
         TRY(pack_f32("scratch.head_block.depthwise.depthwise.weight", 9, hb_w_, st));
         TRY(pack_f32("scratch.head_block.depthwise.depthwise.bias", 1, hb_b_, st));
     }
+    if (partial_pack_) {                         // optimizer step: the text tower is frozen, nothing below changed
+        eval_stale_ = true;
+        return finalize_train(st);
+    }
+    eval_stale_ = false;
     // ---- CLIP text tower ([3P] clip/model.py) -----------------------------------------------------------
     const std::string cp = "clip_pretrained.";
     const int W = c.text_width;
@@ -574,6 +591,7 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
         if (argmax_out) return set_error(LSEG_ERR_UNSUPPORTED, "argmax output is an inference feature (train mode is on)");
         return forward_train(x_in, B, logits, st);
     }
+    if (eval_stale_) TRY(finalize(st));  // optimizer steps refresh only the train-mode packs: fold BatchNorm / the commuted head again
     const lseg_config& c = cfg;
     const int D = c.dim, H = c.heads, F = c.features, M = B * ntok_;
     last_B_ = B;

@@ -37,8 +37,9 @@ int launch_head_block(const float* in, float* out, const float* w9, const float*
 int launch_argmax_planes(const float* in, uint8_t* out, int B, int K, int HW, hipStream_t st);
 int launch_layernorm_backward(const void* dy, int dy_dtype, const float* x, const float* gamma, float* dx, float* dgamma,
                               float* dbeta, int M, int D, float eps, int accumulate, hipStream_t st, int accumulate_params = 0,
-                              float* partial_ws = nullptr);      // partial_ws: [LN_BWD_PARTIAL_BLOCKS, 2D] floats -> no atomics
-constexpr int LN_BWD_PARTIAL_BLOCKS = 256;
+                              float* partial_ws = nullptr,       // partial_ws: [LN_BWD_PARTIAL_BLOCKS, 2D] floats -> no atomics
+                              void* dx16 = nullptr);             // optional 16-bit copy (dy's type) of the updated dx
+constexpr int LN_BWD_PARTIAL_BLOCKS = 1024;
 int launch_transpose16(const void* in, void* out, int R, int C, int ldi, int ldo, hipStream_t st, int shift = 0, int relu = 0);
 int launch_attention_backward(const void* q, const void* k, const void* vt, const void* o, const void* d_o, const float* lse2,
                               float* dq, float* dk, float* dv, int B, int H, int ntok, int npad, int dtype, int causal, float scale,
@@ -60,7 +61,9 @@ int launch_conv_dgrad_pack(const void* wp, void* wd, int Co, int Ci, hipStream_t
 int launch_colsum16(const void* in, int dtype, float* out, int R, int C, int ld, hipStream_t st, int accumulate = 0);
 int launch_relu_backward_add(const void* dy, const void* x, const void* add, void* dx, size_t n, int dtype, hipStream_t st);
 int launch_seg_stats_ex(const float* scores, const int64_t* target, int B, int K, int HW, int ignore_index, unsigned long long* counts,
-                        double* nll, uint8_t* argmax_out, int up, int h, int w, hipStream_t st);
+                        double* nll, uint8_t* argmax_out, int up, int h, int w, hipStream_t st, float* lse_out = nullptr);
+int launch_upsample_ce_backward_rows(const float* low, const int64_t* target, const float* lse, const double* nll, void* rows, int B, int K,
+                                     int H, int W, int ldk, int ignore_index, int dtype, hipStream_t st);
 int launch_seg_stats(const float* scores, const int64_t* target, int B, int K, int HW, int ignore_index,
                      unsigned long long* counts, double* nll, hipStream_t st);
 
@@ -101,5 +104,18 @@ int launch_sum_partials(const float* part, float* dst, int nsplit, size_t n, siz
 int launch_convT_wgrad_unpack(const float* dw, float* dst, int C, int Cp, int s, int accumulate, hipStream_t st);
 int launch_fold_rows(const float* src, float* dst, int R, int C, int ld, int accumulate, hipStream_t st);
 int launch_sgd(float* w, const float* g, float* m, void* w16, size_t n, float lr, float mu, float wd, int first, int dtype, hipStream_t st);
+// table-driven launches of the optimizer step (tables live in device memory, sorted by blk0)
+struct SgdSeg {
+    float* w; const float* g; float* m;      // fp32 master, gradient, momentum
+    uint16_t* w16; float* w32;               // the engine's same-layout copies of the parameter (either may be NULL)
+    unsigned long long n;
+    unsigned blk0;                           // first block of this parameter (4096 elements per block)
+    int scratch;                             // learning-rate group: 0 = pretrained.*, 1 = scratch.*  (lsegmentation_module.py:119-127)
+    int vec;                                 // every pointer 16-byte aligned (w16: 8) -> float4 path
+};
+struct TransposeJob { const uint16_t* src; uint16_t* dst; int R, C; unsigned blk0; int tiles_r; };   // dst [C, R] = src [R, C]^T, R and C multiples of 8
+int launch_sgd_multi(const SgdSeg* dev_segs, int nseg, unsigned blocks, float lr_pre, float lr_scr, float mu, float wd, int first, int dtype,
+                     hipStream_t st);
+int launch_transpose16_multi(const TransposeJob* dev_jobs, int njobs, unsigned blocks, hipStream_t st);
 
 }  // namespace lseg

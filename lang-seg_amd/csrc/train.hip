@@ -71,12 +71,13 @@ int Engine::bind_grad(const char* key, float* p) {
     if (it == bound_.end()) return set_error(LSEG_ERR_MISSING_PARAM, "bind_grad: parameter '%s' was never bound", key);
     GradSlot& s = grads_[key];
     s.ptr = p; s.n = it->second.numel(); s.bound = true;
+    sgd_dirty_ = true;
     return 0;
 }
 
 float* Engine::grad(const std::string& key, size_t n) {
     GradSlot& s = grads_[key];
-    if (!s.ptr) { s.ptr = (float*)dalloc(n * sizeof(float)); s.n = n; }
+    if (!s.ptr) { s.ptr = (float*)dalloc(n * sizeof(float)); s.n = n; sgd_dirty_ = true; }
     if (s.n != n) { set_error(LSEG_ERR_INVALID, "gradient of '%s' has %zu elements, expected %zu", key.c_str(), s.n, n); return nullptr; }
     return s.ptr;
 }
@@ -159,7 +160,7 @@ int Engine::train_alloc() {
     TALLOC(g16_, uint16_t, M * D); TALLOC(dmlp_, uint16_t, M * 4 * D); TALLOC(dln_, uint16_t, M * D); TALLOC(datt_, uint16_t, M * D);
     TALLOC(dqkv_, uint16_t, M * 3 * D); TALLOC(dtok_, uint16_t, Mr * D);
     const size_t hw1 = (size_t)4 * lh_[0] * lw_[0], Kp = up64(c.max_labels);
-    TALLOC(logits_, float, B * c.max_labels * 4 * hw1); TALLOC(dlogits_, float, B * c.max_labels * 4 * hw1);
+    TALLOC(lse_px_, float, B * 4 * hw1);
     TALLOC(drows_, uint16_t, B * hw1 * Kp); TALLOC(da_, uint16_t, B * hw1 * c.out_c); TALLOC(df_, uint16_t, B * hw1 * c.out_c);
     TALLOC(tnT_, uint16_t, (size_t)c.out_c * Kp); TALLOC(tn16_, uint16_t, (size_t)c.max_labels * c.out_c);
     TALLOC(counts_, unsigned long long, 2 + 3 * (size_t)c.max_labels); TALLOC(nll_, double, 2);
@@ -172,22 +173,19 @@ int Engine::train_alloc() {
 int Engine::finalize_train(hipStream_t st) {
     const lseg_config& c = cfg;
     const int F = c.features;
-    auto make_wt = [&](Lin& L) -> int {          // wt [k, n] = w^T
-        if (!L.wt) TALLOC(L.wt, uint16_t, (size_t)L.n * L.k);
-        return launch_transpose16(L.w, L.wt, L.n, L.k, L.k, L.n, st);
-    };
+    std::vector<Lin*> wts;                       // every Linear whose dgrad needs wt [k, n] = w^T
     auto make_wd = [&](Lin& L, int co, int ci) -> int {   // w [co, 9, ci] -> wd [ci, 9, co] flipped
         if (!L.wd) TALLOC(L.wd, uint16_t, (size_t)co * 9 * ci);
         return launch_conv_dgrad_pack(L.w, L.wd, co, ci, st);
     };
-    for (auto& b : blocks_) { TRY(make_wt(b.qkv)); TRY(make_wt(b.proj)); TRY(make_wt(b.fc1)); TRY(make_wt(b.fc2)); }
+    for (auto& b : blocks_) { wts.push_back(&b.qkv); wts.push_back(&b.proj); wts.push_back(&b.fc1); wts.push_back(&b.fc2); }
     for (int l = 0; l < 4; ++l) {
-        TRY(make_wt(readout_[l])); TRY(make_wt(r1x1_[l]));
-        if (c.resample_kind[l] == LSEG_RS_CONVT) TRY(make_wt(rsmp_[l]));
+        wts.push_back(&readout_[l]); wts.push_back(&r1x1_[l]);
+        if (c.resample_kind[l] == LSEG_RS_CONVT) wts.push_back(&rsmp_[l]);
         else if (c.resample_kind[l] == LSEG_RS_CONV_S2) TRY(make_wd(rsmp_[l], cp_[l], cp_[l]));
         TRY(make_wd(layer_rn_[l], F, cp_[l]));
         Refine& R = refine_[l];
-        TRY(make_wt(R.out_conv));
+        wts.push_back(&R.out_conv);
         for (int u = 0; u < 2; ++u) {
             if (u == 0 && !R.has_u1) continue;
             Rcu& U = u == 0 ? R.u1 : R.u2;
@@ -201,8 +199,30 @@ int Engine::finalize_train(hipStream_t st) {
             TRY(pack_f32(U.key + "bn2.weight", F, U.g2, st)); TRY(pack_f32(U.key + "bn2.bias", F, U.be2, st));
         }
     }
-    TRY(make_wt(head1_));
-    LSEG_HIP_TRY(hipStreamSynchronize(st));
+    wts.push_back(&head1_);
+    // the transposes: one table-driven launch for every matrix with 16-byte rows on both sides, single launches for the rest
+    if (!wt_table_) {
+        std::vector<TransposeJob> jobs;
+        unsigned blk = 0;
+        for (Lin* L : wts) {
+            if (!L->wt) TALLOC(L->wt, uint16_t, (size_t)L->n * L->k);
+            if ((L->n & 7) || (L->k & 7)) continue;
+            TransposeJob j;
+            j.src = L->w; j.dst = L->wt; j.R = L->n; j.C = L->k; j.blk0 = blk; j.tiles_r = (L->n + 63) / 64;
+            blk += (unsigned)j.tiles_r * (unsigned)((L->k + 63) / 64);
+            jobs.push_back(j);
+        }
+        wt_n_ = (int)jobs.size(); wt_blocks_ = blk;
+        if (wt_n_) {
+            wt_table_ = (TransposeJob*)dalloc(jobs.size() * sizeof(TransposeJob));
+            if (!wt_table_) return set_error(LSEG_ERR_HIP, "out of device memory (transpose table)");
+            LSEG_HIP_TRY(hipMemcpy(wt_table_, jobs.data(), jobs.size() * sizeof(TransposeJob), hipMemcpyHostToDevice));
+        }
+    }
+    TRY(launch_transpose16_multi(wt_table_, wt_n_, wt_blocks_, st));
+    for (Lin* L : wts)
+        if ((L->n & 7) || (L->k & 7)) TRY(launch_transpose16(L->w, L->wt, L->n, L->k, L->k, L->n, st));
+    if (!partial_pack_) LSEG_HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }
 
@@ -237,6 +257,7 @@ int Engine::forward_train(const float* x_in, int B, float* logits, hipStream_t s
     if (!train_alloc_) return set_error(LSEG_ERR_STATE, "train mode was not enabled (lseg_set_train)");
     train_fwd_valid_ = false;
     last_B_ = B;
+    eval_stale_ = true;             // the BatchNorm running statistics move: the eval-mode (BN-folded) packs are refreshed by the next eval forward
     const bool run_text = !text_cache || !text_valid;
     if (run_text) {
         LSEG_HIP_TRY(hipEventRecord(ev_fork_, st));
@@ -340,9 +361,8 @@ int Engine::forward_train(const float* x_in, int B, float* logits, hipStream_t s
     const int Kp = (int)up64(K_);
     TRY(launch_convert(tnorm_, DT_F16, tn16_, DT_BF16, (size_t)K_ * c.out_c, st));
     TRY(launch_transpose16(tn16_, tnT_, K_, c.out_c, c.out_c, Kp, st));
-    float* out = logits ? logits : logits_;
-    TRY(launch_upsample2x_planes(low_, out, B * K_, h1, w1, st));
-    last_logits_ = out;
+    // output_conv (x2 bilinear) only when the caller wants the logits: the loss and its gradient are taken on the low-resolution ones
+    if (logits) TRY(launch_upsample2x_planes(low_, logits, B * K_, h1, w1, st));
     last_low_ = low_; last_kout_ = K_;
     train_B_ = B;
     train_fwd_valid_ = true;
@@ -525,6 +545,7 @@ int Engine::readout_backward(int l, int B, int acc, hipStream_t st) {
     TRY(launch_gelu_backward(v.dro, v.ropre, v.dro, (size_t)Mr * D, img_dt_, st));
     TRY(lin_bwd(v.dro, Mr, D, 2 * D, v.cat, readout_[l].wt, rowsA_, grad(a + "weight", (size_t)D * 2 * D), grad(a + "bias", D), acc, st));
     TRY(launch_readout_cat_bwd(rowsA_, gx_, B, ntok_, D, img_dt_, st));
+    g16_valid_ = false;
     return 0;
 }
 
@@ -540,17 +561,17 @@ int Engine::block_backward(int i, int B, int acc, hipStream_t st) {
     float *dg1 = G("norm1.weight", D), *db1 = G("norm1.bias", D), *dg2 = G("norm2.weight", D), *db2 = G("norm2.bias", D);
     if (!dg1 || !db1 || !dg2 || !db2) return LSEG_ERR_INVALID;
     // x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
-    TRY(launch_convert(gx_, DT_F32, g16_, img_dt_, (size_t)M * D, st));
+    if (!g16_valid_) TRY(launch_convert(gx_, DT_F32, g16_, img_dt_, (size_t)M * D, st));      // else: written by the previous LayerNorm backward
     TRY(lin_bwd(g16_, M, D, 4 * D, s.mlp, b.fc2.wt, dmlp_, G("mlp.fc2.weight", (size_t)D * 4 * D), G("mlp.fc2.bias", D), acc, st));
     TRY(launch_gelu_backward(dmlp_, s.pre, dmlp_, (size_t)M * 4 * D, img_dt_, st));
     TRY(lin_bwd(dmlp_, M, 4 * D, D, s.ln2, b.fc1.wt, dln_, G("mlp.fc1.weight", (size_t)4 * D * D), G("mlp.fc1.bias", 4 * D), acc, st));
-    TRY(launch_layernorm_backward(dln_, img_dt_, s.xmid, b.g2, gx_, dg2, db2, M, D, 1e-6f, 1, st, acc, ws_ln_));
+    TRY(launch_layernorm_backward(dln_, img_dt_, s.xmid, b.g2, gx_, dg2, db2, M, D, 1e-6f, 1, st, acc, ws_ln_, g16_));
     // x_mid = x_in + proj(attention(qkv(LN1(x_in))))
-    TRY(launch_convert(gx_, DT_F32, g16_, img_dt_, (size_t)M * D, st));
     TRY(lin_bwd(g16_, M, D, D, s.att, b.proj.wt, datt_, G("attn.proj.weight", (size_t)D * D), G("attn.proj.bias", D), acc, st));
     TRY(launch_attention_backward_qkv(s.q, s.k, s.vt, s.att, datt_, s.lse, dqkv_, attn_ws_, B, H, ntok_, npad_, img_dt_, 0.125f, st));
     TRY(lin_bwd(dqkv_, M, 3 * D, D, s.ln1, b.qkv.wt, dln_, G("attn.qkv.weight", (size_t)3 * D * D), G("attn.qkv.bias", 3 * D), acc, st));
-    TRY(launch_layernorm_backward(dln_, img_dt_, s.xin, b.g1, gx_, dg1, db1, M, D, 1e-6f, 1, st, acc, ws_ln_));
+    TRY(launch_layernorm_backward(dln_, img_dt_, s.xin, b.g1, gx_, dg1, db1, M, D, 1e-6f, 1, st, acc, ws_ln_, g16_));
+    g16_valid_ = true;          // g16_ = bf16(gx_) until something else adds into gx_ (a readout hook)
     return 0;
 }
 
@@ -564,15 +585,16 @@ int Engine::backward(const float* dlogits, const int64_t* target, int ignore_ind
     const int B = train_B_, D = c.dim, F = c.features, M = B * ntok_, Mr = B * np_;
     const int h1 = 2 * lh_[0], w1 = 2 * lw_[0], hw1 = h1 * w1, Mp1 = B * hw1, Kp = (int)up64(K_);
     const float logit_scale = expf(logf(1.0f / 0.07f));
-    if (!dlogits) {
-        TRY(launch_seg_stats(last_logits_, target, B, K_, 4 * hw1, ignore_index, counts_, nll_, st));
-        TRY(launch_softmax_ce_backward(last_logits_, target, dlogits_, B, K_, 4 * hw1, ignore_index, nll_, st));
+    // ---- loss + x2 upsample^T: the correlation's dY rows ---------------------------------------------------------------------
+    if (!dlogits) {      // CrossEntropyLoss(ignore_index) on output_conv(low): one pass for the loss and the per-pixel log-sum-exp, one for the rows
+        TRY(launch_seg_stats_ex(low_, target, B, K_, 4 * hw1, ignore_index, counts_, nll_, nullptr, 1, h1, w1, st, lse_px_));
+        TRY(launch_upsample_ce_backward_rows(low_, target, lse_px_, nll_, drows_, B, K_, h1, w1, Kp, ignore_index, img_dt_, st));
         if (dev_loss2) LSEG_HIP_TRY(hipMemcpyAsync(dev_loss2, nll_, 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
-        dlogits = dlogits_;
+    } else {             // autograd hand-over: d(logits) [B,K,2h,2w] given
+        LSEG_HIP_TRY(hipMemsetAsync(drows_, 0, (size_t)Mp1 * Kp * 2, st));
+        TRY(launch_upsample2x_planes_backward_rows(dlogits, drows_, B, K_, h1, w1, Kp, img_dt_, st));
     }
-    // ---- head: x2 upsample^T, correlation, L2-norm, head1 -----------------------------------------------------------------
-    LSEG_HIP_TRY(hipMemsetAsync(drows_, 0, (size_t)Mp1 * Kp * 2, st));
-    TRY(launch_upsample2x_planes_backward_rows(dlogits, drows_, B, K_, h1, w1, Kp, img_dt_, st));
+    // ---- head: correlation, L2-norm, head1 -------------------------------------------------------------------------------------
     GemmArgs g;
     gemm_args_init(g);
     g.A = drows_; g.W = tnT_; g.M = Mp1; g.N = c.out_c; g.K = Kp; g.lda = Kp; g.ldw = Kp;
@@ -587,6 +609,7 @@ int Engine::backward(const float* dlogits, const int64_t* target, int ignore_ind
     bucket_done(0, st);
     // ---- ViT blocks, readouts joining at their hooks --------------------------------------------------------------------------
     LSEG_HIP_TRY(hipMemsetAsync(gx_, 0, (size_t)M * D * sizeof(float), st));
+    g16_valid_ = false;
     for (int i = c.depth - 1; i >= 0; --i) {
         for (int l = 0; l < 4; ++l)
             if (c.hooks[l] == i) TRY(readout_backward(l, B, acc, st));
@@ -613,23 +636,68 @@ int Engine::backward(const float* dlogits, const int64_t* target, int ignore_ind
 }
 
 // ---- fused SGD (torch.optim.SGD semantics; two learning-rate groups, lsegmentation_module.py:119-127,165-171) ------------------
-int Engine::sgd_step(float lr_pre, float lr_scr, float mu, float wd, hipStream_t st) {
-    LSEG_HIP_TRY(hipSetDevice(device));
+// One table entry per trainable parameter: fp32 master (the caller's tensor), gradient, momentum (one flat allocation) and the
+// engine's same-layout copies of it (`direct_`, noted by finalize()).
+int Engine::build_sgd_table() {
+    std::vector<SgdSeg> segs;
+    size_t mom = 0;
     for (auto& kv : grads_) {
         const std::string& key = kv.first;
         auto it = bound_.find(key);
         if (it == bound_.end() || it->second.dtype != LSEG_F32 || !kv.second.ptr) continue;
-        float lr;
-        if (key.compare(0, 11, "pretrained.") == 0) lr = lr_pre;
-        else if (key.compare(0, 8, "scratch.") == 0) lr = lr_scr;
+        int scr;
+        if (key.compare(0, 11, "pretrained.") == 0) scr = 0;
+        else if (key.compare(0, 8, "scratch.") == 0) scr = 1;
         else continue;
-        float*& m = moms_[key];
-        if (!m) { m = (float*)dalloc(kv.second.n * sizeof(float)); if (!m) return set_error(LSEG_ERR_HIP, "out of device memory (momentum)"); }
-        TRY(launch_sgd((float*)it->second.ptr, kv.second.ptr, m, nullptr, kv.second.n, lr, mu, wd, sgd_first_ ? 1 : 0, 0, st));
+        if (kv.second.n != it->second.numel()) return set_error(LSEG_ERR_INVALID, "gradient of '%s' does not match the parameter", key.c_str());
+        SgdSeg s;
+        s.w = (float*)it->second.ptr; s.g = kv.second.ptr; s.m = nullptr; s.w16 = nullptr; s.w32 = nullptr;
+        s.n = kv.second.n; s.blk0 = 0; s.scratch = scr; s.vec = 0;
+        auto d = direct_.find(key);
+        if (d != direct_.end() && !d->second.conflict) { s.w16 = d->second.w16; s.w32 = d->second.w32; }
+        mom += (s.n + 3) / 4 * 4;
+        segs.push_back(s);
+        sgd_keys_[key] = 1;
     }
-    sgd_first_ = false;
-    TRY(finalize(st));                  // refresh the packed MFMA copies (and the train-mode packs) from the updated fp32 masters
+    if (mom > mom_flat_n_) {
+        if (!sgd_first_) return set_error(LSEG_ERR_STATE, "the set of trainable parameters grew after the first optimizer step");
+        mom_flat_ = (float*)dalloc(mom * sizeof(float));
+        if (!mom_flat_) return set_error(LSEG_ERR_HIP, "out of device memory (momentum)");
+        mom_flat_n_ = mom;
+    }
+    size_t off = 0;
+    unsigned blk = 0;
+    for (auto& s : segs) {
+        s.m = mom_flat_ + off;
+        off += (s.n + 3) / 4 * 4;
+        s.blk0 = blk;
+        blk += (unsigned)((s.n + 4095) / 4096);
+        const uintptr_t a = (uintptr_t)s.w | (uintptr_t)s.g | (uintptr_t)s.m | (uintptr_t)s.w32;
+        s.vec = !(a & 15) && !((uintptr_t)s.w16 & 7) && !(s.n & 3);
+    }
+    if (sgd_table_ && (int)segs.size() > sgd_nseg_) sgd_table_ = nullptr;      // (rebuilt after a re-bind; the old table stays in the arena)
+    if (!sgd_table_ && !segs.empty()) {
+        sgd_table_ = (SgdSeg*)dalloc(segs.size() * sizeof(SgdSeg));
+        if (!sgd_table_) return set_error(LSEG_ERR_HIP, "out of device memory (optimizer table)");
+    }
+    if (!segs.empty()) LSEG_HIP_TRY(hipMemcpy(sgd_table_, segs.data(), segs.size() * sizeof(SgdSeg), hipMemcpyHostToDevice));
+    sgd_nseg_ = (int)segs.size(); sgd_blocks_ = blk;
+    sgd_dirty_ = false;
     return 0;
+}
+
+int Engine::sgd_step(float lr_pre, float lr_scr, float mu, float wd, hipStream_t st) {
+    LSEG_HIP_TRY(hipSetDevice(device));
+    if (!finalized_) return set_error(LSEG_ERR_STATE, "parameters not finalised");
+    if (sgd_dirty_) TRY(build_sgd_table());
+    TRY(launch_sgd_multi(sgd_table_, sgd_nseg_, sgd_blocks_, lr_pre, lr_scr, mu, wd, sgd_first_ ? 1 : 0, img_dt_, st));
+    sgd_first_ = false;
+    // refresh the packs with a real re-layout (padded / tap-major / transposed / flipped copies) from the updated masters; the straight
+    // copies were written by the optimizer kernel, the frozen text tower and the eval-only packs are left alone
+    partial_pack_ = true;
+    const int r = finalize(st);
+    partial_pack_ = false;
+    return r;
 }
 
 }  // namespace lseg

@@ -237,3 +237,45 @@ def test_head_backward_through_the_bricks(B, h, w, K, Fd):
               "d_text": rel(d_t[:K], tr.grad)}
     print({k: round(v, 4) for k, v in report.items()})
     assert all(v < 3e-2 for v in report.values()), report
+
+
+@pytest.mark.parametrize("B,h,w,K", [(2, 12, 12, 7), (1, 10, 16, 150), (2, 32, 32, 5), (1, 120, 120, 19)])
+def test_fused_upsample_cross_entropy_backward(B, h, w, K):
+    """lseg_op_upsample_ce_backward_rows: loss and d(low-resolution logits) of CrossEntropyLoss(ignore_index)(x2 bilinear(low))
+    (lsegmentation_module.py:72 on lseg_net.py:203) without the full-resolution logits, vs torch autograd in fp32 and vs the
+    three-kernel path through the materialised logits (seg_stats, softmax_ce_backward, upsample2x_planes_backward_rows)."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11 + K)
+    low = (3.0 * torch.randn((B, K, h, w), generator=g)).cuda()
+    target = torch.randint(0, K, (B, 2 * h, 2 * w), generator=g)
+    target[torch.rand((B, 2 * h, 2 * w), generator=g) < 0.2] = -1
+    target = target.cuda()
+    Kp = ((K + 63) // 64) * 64
+    lr = low.clone().requires_grad_(True)
+    up = F.interpolate(lr, scale_factor=2, mode="bilinear", align_corners=True)
+    loss = F.cross_entropy(up, target, ignore_index=-1)
+    loss.backward()
+    want = lr.grad.permute(0, 2, 3, 1).reshape(B * h * w, K)
+    st = _st()
+    nll = torch.empty(2, dtype=torch.float64, device="cuda")
+    ws = torch.empty(B * 4 * h * w, dtype=torch.float32, device="cuda")
+    rows = torch.full((B * h * w, Kp), 7.0, dtype=BF, device="cuda")          # every column must be overwritten
+    _lib.check(lib.lseg_op_upsample_ce_backward_rows(P(low), P(target), B, K, h, w, -1, P(nll), P(ws), P(rows), Kp, _lib.LSEG_BF16, st))
+    # the unfused bricks on the materialised logits
+    upc = up.detach().contiguous()
+    counts = torch.empty(2 + 3 * K, dtype=torch.int64, device="cuda")
+    nll2 = torch.empty(2, dtype=torch.float64, device="cuda")
+    _lib.check(lib.lseg_op_seg_stats(P(upc), P(target), B, K, 2 * h, 2 * w, -1, P(counts), P(nll2), st))
+    dz = torch.empty_like(upc)
+    _lib.check(lib.lseg_op_softmax_ce_backward(P(upc), P(target), P(dz), B, K, 2 * h, 2 * w, -1, P(nll2), st))
+    rows2 = torch.zeros((B * h * w, Kp), dtype=BF, device="cuda")
+    _lib.check(lib.lseg_op_upsample2x_planes_backward_rows(P(dz), P(rows2), B, K, h, w, Kp, _lib.LSEG_BF16, st))
+    torch.cuda.synchronize()
+    assert nll[1].item() == (target >= 0).sum().item()
+    assert abs(nll[0].item() / nll[1].item() - loss.item()) < 1e-5 * abs(loss.item())
+    assert (rows[:, K:] == 0).all()
+    got = rows[:, :K].float()
+    err = (got - want).abs().max().item() / want.abs().max().item()
+    assert err < 6e-3, err                                                   # bf16 output rounding (2^-8 relative per element)
+    assert ((got - want).norm() / want.norm()).item() < 4e-3
+    assert ((got - rows2[:, :K].float()).norm() / want.norm()).item() < 4e-3

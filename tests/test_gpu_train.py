@@ -209,6 +209,21 @@ def test_fused_sgd_matches_torch_sgd():
             eng.forward(x.cuda())
             eng.backward(target=target.cuda())
             torch.cuda.synchronize()
+    # every packed copy the engine keeps (16-bit MFMA operands, transposed / flipped / tap-major / padded re-layouts, fp32 bias and
+    # affine copies) was refreshed by the step: the engine now computes exactly what a fresh engine loaded from the updated masters does
+    sd_new = {k: v.detach().clone().cpu() for k, v in eng.bound.items()}
+    out_a = eng.forward(x.cuda()).clone()
+    loss_a = eng.backward(target=target.cuda(), ignore_index=-1)
+    torch.cuda.synchronize()
+    grads_a = {k: v.clone() for k, v in eng.grads.items()}
+    eng_b, out_b, loss_b, _ = _engine_step(cfg, sd_new, x, target, tok)
+    assert torch.equal(out_a, out_b)
+    assert abs(float(loss_a) - float(loss_b)) <= 1e-6 * abs(float(loss_b))
+    for k in keys:                     # atomics in the BatchNorm / bias sums: run-to-run noise only
+        assert rel(grads_a[k], eng_b.grads[k]) < 2e-3, k
+    # ... and the eval-only packs (BatchNorm folded into the convs, the commuted head) catch up at the next eval forward
+    eng.set_train(False); eng_b.set_train(False)
+    assert torch.equal(eng.forward(x.cuda()), eng_b.forward(x.cuda()))
 
 
 def test_lsegnet_train_mode_backpropagates_through_the_engine():
