@@ -30,8 +30,9 @@ import torch  # noqa: E402
 GF_IMAGE = lambda K: 799.4 + 0.05898 * K        # image tower GF / image
 GF_TEXT = lambda K: 5.959 * K                   # CLIP text tower GF / forward call, the reference's 77-position schedule
 # executed by the engine: refinenet1.out_conv (7.55 GF) and head1 (15.10 GF) at 240x240 are replaced by ONE combined 1x1 conv on the
-# padded 122x122 map below the upsample (3.90 GF): DESIGN.md §3.4
-GF_IMAGE_EXEC = lambda K: GF_IMAGE(K) - 7.55 - 15.10 + 3.90
+# padded 122x122 map below the upsample (3.90 GF), and the pixel x text correlation runs on that map too (0.01524 GF per label
+# instead of 0.05898 at 240x240): DESIGN.md §3.4
+GF_IMAGE_EXEC = lambda K: GF_IMAGE(K) - 7.55 - 15.10 + 3.90 - (0.05898 - 0.01524) * K
 PEAK_BF16_TFLOPS = 2500.0                       # MI355X_MICROARCH.md dense bf16 MFMA peak
 
 
@@ -235,8 +236,8 @@ def main():
                        "parallelism": f"dp{world} (batch sharded, no collectives)"},
             "path_tflops": round(world * gf_step / (ms * 1e-3) / 1e3, 2),
             "path_frac_of_mfma_peak": round(gf_step / (ms * 1e-3) / 1e3 / PEAK_BF16_TFLOPS, 4),
-            "path_flops_convention": f"executed FLOPs: image tower {GF_IMAGE_EXEC(K):.1f} GF/image (head 1x1 convs commuted below the "
-                                     f"upsample: -18.75 GF) + text tower at {L_exec} of 77 positions ({gf_text_executed(K, L_exec):.1f} GF/call); "
+            "path_flops_convention": f"executed FLOPs: image tower {GF_IMAGE_EXEC(K):.1f} GF/image (head 1x1 convs and the correlation commuted below the "
+                                     f"x2 upsample: -18.75 GF - {(0.05898 - 0.01524) * K:.2f} GF) + text tower at {L_exec} of 77 positions ({gf_text_executed(K, L_exec):.1f} GF/call); "
                                      f"the reference's schedule on the same inputs = {GF_IMAGE(K):.1f} + {GF_TEXT(K):.1f}",
             "path_tflops_reference_algorithm": round(world * gf_step_ref / (ms * 1e-3) / 1e3, 2),
             "engine_forward_ms_hip_events": round(fwd["total_ms"] / max(1, fwd["launches"]), 4),

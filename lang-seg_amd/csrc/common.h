@@ -35,6 +35,23 @@ __device__ __forceinline__ uint16_t f32_to_f16(float f) {       // v_cvt_f16_f32
     return __builtin_bit_cast(uint16_t, h);
 }
 __device__ __forceinline__ float round_f16(float f) { return (float)((_Float16)f); }
+// (1-ly)*((1-lx)*a + lx*b) + ly*((1-lx)*c + lx*d) with the fused multiply-adds spelled out: every kernel that evaluates output_conv's
+// bilinear (materialised logits, masks / metrics read through it on the fly, the one-pass x4 upsample) gets the same bits whatever
+// the compiler would have contracted in its context
+// source taps of output index i under align_corners=True (r = (n_in - 1) / (n_out - 1)): i0 = floor(r i), i1 = min(i0 + 1, n - 1),
+// l = r i - i0 -- with the product ROUNDED before the subtraction in every kernel (no contraction into an fma here)
+__device__ __forceinline__ void src_tap(float r, int i, int n, int& i0, int& i1, float& l) {
+#pragma clang fp contract(off)
+    const float s = r * (float)i;
+    i0 = (int)s;
+    i1 = i0 + (i0 < n - 1);
+    l = s - (float)i0;
+}
+__device__ __forceinline__ float bilerp(float a, float b, float c, float d, float lx, float ly) {
+    const float wx = 1.f - lx, wy = 1.f - ly;
+    const float h0 = __builtin_fmaf(lx, b, wx * a), h1 = __builtin_fmaf(lx, d, wx * c);
+    return __builtin_fmaf(ly, h1, wy * h0);
+}
 
 template <typename T> __device__ __forceinline__ float to_f32(uint16_t v);
 template <> __device__ __forceinline__ float to_f32<BF16>(uint16_t v) { return bf16_to_f32(v); }

@@ -217,22 +217,21 @@ __global__ __launch_bounds__(128) void upsample2x_planes_kernel(const float* in,
     int yo = (int)ceilf((float)y0 / ry);
     while (yo > 0 && (int)(ry * (float)(yo - 1)) >= y0) --yo;
     while ((int)(ry * (float)yo) < y0) ++yo;
-    for (; yo < Ho && (int)(ry * (float)yo) == y0; ++yo) {
-        const float sy = ry * (float)yo;
-        const float ly = sy - (float)y0;
-        float* orow = out + ((size_t)pl * Ho + yo) * Wo;
-        for (int x4 = threadIdx.x; x4 < w4; x4 += 128) {
+    const int yo_first = yo;
+    for (int x4 = threadIdx.x; x4 < w4; x4 += 128) {          // column terms once per thread, then down the (up to 3) output rows
+        int x0[4], x1[4];
+        float lx[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) src_tap(rx, x4 * 4 + e, W, x0[e], x1[e], lx[e]);
+        for (yo = yo_first; yo < Ho && (int)(ry * (float)yo) == y0; ++yo) {
+            int ya_, yb_;
+            float ly;
+            src_tap(ry, yo, H, ya_, yb_, ly);
             float o[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int xo = x4 * 4 + e;
-                const float sx = rx * (float)xo;
-                const int x0 = (int)sx, x1 = x0 + (x0 < W - 1);
-                const float lx = sx - (float)x0;
-                o[e] = (1.f - ly) * ((1.f - lx) * rows[x0] + lx * rows[x1]) + ly * ((1.f - lx) * rows[W + x0] + lx * rows[W + x1]);
-            }
+            for (int e = 0; e < 4; ++e) o[e] = bilerp(rows[x0[e]], rows[x1[e]], rows[W + x0[e]], rows[W + x1[e]], lx[e], ly);
             const f32x4_t ov = {o[0], o[1], o[2], o[3]};     // written once, never re-read by the engine
-            __builtin_nontemporal_store(ov, reinterpret_cast<f32x4_t*>(orow) + x4);
+            __builtin_nontemporal_store(ov, reinterpret_cast<f32x4_t*>(out + ((size_t)pl * Ho + yo) * Wo) + x4);
         }
     }
 }
@@ -381,6 +380,211 @@ __global__ __launch_bounds__(256, NV == 1 ? 3 : 2) void upsample_norm_f16_kernel
                     }
                 }
             }
+        }
+    }
+}
+
+// ---- commuted correlation (engine.hip "commuted correlation"): the pixel x text product at the QUARTER resolution ------------------
+// logits_low[k, P] = t_k . a_P with a_P = s * u_P / ||u_P|| and u_P = the x2 bilinear of g at P is linear in u_P, so
+//   t_k . u_P = sum_taps w_tap (t_k . g_tap)   -> R = T g^T is one GEMM at (H, W) instead of (2H, 2W) (4x fewer pixels), up-sampled as planes;
+//   ||u_P||^2 = sum_{i,j} w_i w_j (g_i . g_j)  -> the 10 dot products of every 2x2 cell of g, 5 records per pixel (this kernel).
+// g: padded NHWC fp16 [B, H+2, W+2, C] (border = finite values, weight 0).  gram [B, H, W, 5] fp32 per pixel q = (y, x):
+//   {g_q.g_q, g_q.g_(y,x+1), g_q.g_(y+1,x), g_q.g_(y+1,x+1), g_(y,x+1).g_(y+1,x)}.  One wave per run of 4 pixels of a row.
+template <int NV>
+__global__ __launch_bounds__(256) void pixel_gram_kernel(const uint16_t* __restrict__ g, float* __restrict__ gram, int B, int H, int W, int C) {
+    const int lane = threadIdx.x & 63;
+    const int w4 = (W + 3) / 4;
+    const size_t nrun = (size_t)B * H * w4;
+    const size_t rowp = (size_t)(W + 2) * C;
+    for (size_t run = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6); run < nrun; run += (size_t)gridDim.x * 4) {
+        const int x0 = (int)(run % w4) * 4;
+        const int y = (int)((run / w4) % H);
+        const int b = (int)(run / ((size_t)w4 * H));
+        const uint16_t* r0 = g + ((size_t)b * (H + 2) + y + 1) * rowp + (size_t)(x0 + 1) * C;
+        const uint16_t* r1 = r0 + rowp;
+        float acc[4][5];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int d = 0; d < 5; ++d) acc[i][d] = 0.f;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const int c = (lane + 64 * v) * 8;
+            if (c >= C) continue;
+            float t[5][8], u[5][8];                       // rows y and y+1, columns x0 .. x0+4 (clamped to the padded row: x <= W)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int xj = x0 + j <= W ? j : W - x0;
+                const uint4 a = *reinterpret_cast<const uint4*>(r0 + (size_t)xj * C + c), bq = *reinterpret_cast<const uint4*>(r1 + (size_t)xj * C + c);
+                const uint16_t *ea = reinterpret_cast<const uint16_t*>(&a), *eb = reinterpret_cast<const uint16_t*>(&bq);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { t[j][e] = f16_to_f32(ea[e]); u[j][e] = f16_to_f32(eb[e]); }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    acc[i][0] += t[i][e] * t[i][e];
+                    acc[i][1] += t[i][e] * t[i + 1][e];
+                    acc[i][2] += t[i][e] * u[i][e];
+                    acc[i][3] += t[i][e] * u[i + 1][e];
+                    acc[i][4] += t[i + 1][e] * u[i][e];
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int d = 0; d < 5; ++d) {
+                float s = acc[i][d];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+                acc[i][d] = s;
+            }
+        if (lane < 20) {
+            const int i = lane / 5, d = lane - 5 * i;
+            float val = 0.f;
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int dd = 0; dd < 5; ++dd) if (ii == i && dd == d) val = acc[ii][dd];
+            if (x0 + i < W) gram[(((size_t)b * H + y) * W + x0 + i) * 5 + d] = val;
+        }
+    }
+}
+// scale[b, Y, X] = s / ||u_P||  on the (2H, 2W) grid, from the 2x2-cell dot products: ||u||^2 = sum_i w_i^2 (g_i.g_i) + 2 sum_{i<j} w_i w_j (g_i.g_j)
+__global__ void norm_scale_plane_kernel(const float* __restrict__ gram, float* __restrict__ scale, int B, int H, int W, float s) {
+    const int Ho = 2 * H, Wo = 2 * W;
+    const size_t n = (size_t)B * Ho * Wo;
+    const float ry = (float)(H - 1) / (float)(Ho - 1), rx = (float)(W - 1) / (float)(Wo - 1);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int xo = (int)(i % Wo), yo = (int)((i / Wo) % Ho), b = (int)(i / ((size_t)Wo * Ho));
+        const float sy = ry * (float)yo, sx = rx * (float)xo;
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        const float wa = (1.f - ly) * (1.f - lx), wb = (1.f - ly) * lx, wc = ly * (1.f - lx), wd = ly * lx;
+        const float* ra = gram + (((size_t)b * H + y0) * W + x0) * 5;          // a = (y0, x0): right -> a.b, down -> a.c, diag -> a.d, anti -> b.c
+        const float* rb = gram + (((size_t)b * H + y0) * W + x1) * 5;          // b = (y0, x1): down -> b.d
+        const float* rc = gram + (((size_t)b * H + y1) * W + x0) * 5;          // c = (y1, x0): right -> c.d
+        const float* rd = gram + (((size_t)b * H + y1) * W + x1) * 5;
+        // a clamped tap (x1 == x0 or y1 == y0) carries weight exactly 0, so the records it would mis-address never count
+        const float n2 = wa * wa * ra[0] + wb * wb * rb[0] + wc * wc * rc[0] + wd * wd * rd[0] +
+                         2.f * (wa * wb * ra[1] + wa * wc * ra[2] + wa * wd * ra[3] + wb * wc * ra[4] + wb * wd * rb[2] + wc * wd * rc[1]);
+        scale[i] = s * rsqrtf(n2);
+    }
+}
+// x2 bilinear (align_corners=True) of the label planes R (padded [P, H+2, W+2] fp32, interior read) with the per-pixel factor and the
+// reference's fp16 rounding of the logits: low[p, Y, X] = fp16( scale[p / K, Y, X] * bilinear(R[p])(Y, X) )  -> [P, 2H, 2W] fp32.
+// A block = one plane x a band of LB output rows: the R rows under the band are staged in LDS, the band's pixels are spread over
+// all threads (at W = 120 one output row is only 60 float4 stores).
+constexpr int UPS_LB = 8;
+__device__ __forceinline__ int ups_stage_r(const float* __restrict__ in, float* __restrict__ Rr, int pl, int H, int W, float ry, int ya, int yb) {
+    const int r_lo = (int)(ry * (float)ya);
+    int r_hi = (int)(ry * (float)yb) + 1;
+    if (r_hi > H - 1) r_hi = H - 1;
+    const int nR = r_hi - r_lo + 1;
+    for (int i = threadIdx.x; i < nR * W; i += blockDim.x) {
+        const int r = i / W, x = i - r * W;
+        Rr[i] = in[((size_t)pl * (H + 2) + r_lo + r + 1) * (W + 2) + 1 + x];
+    }
+    return r_lo;
+}
+// Thread layout of the banded kernels: a row of `n` items takes n threads, 256 / n rows are in flight per pass (n <= 256), so a thread
+// keeps ONE column: its source columns and weights are computed once, the row loop only adds the row terms.
+struct ColTerms { int x0[4], x1[4]; float lx[4]; };
+__device__ __forceinline__ ColTerms col_terms4(float rx, int x4, int Win) {
+    ColTerms t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) src_tap(rx, x4 * 4 + e, Win, t.x0[e], t.x1[e], t.lx[e]);
+    return t;
+}
+// four scaled low-resolution logits of row Y (the association of upsample_bilinear2d, then the fp16 rounding of `half @ half`)
+__device__ __forceinline__ void ups_low4(const float* __restrict__ Rr, const float* __restrict__ sc, int H, int W, float ry, int r_lo, int Y,
+                                         int x4, const ColTerms& t, float (&o)[4]) {
+    int y0, y1;
+    float ly;
+    src_tap(ry, Y, H, y0, y1, ly);
+    const float* q0 = Rr + (y0 - r_lo) * W;
+    const float* q1 = Rr + (y1 - r_lo) * W;
+    const float4 sv = *reinterpret_cast<const float4*>(sc + (size_t)Y * (2 * W) + x4 * 4);
+    const float se[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = round_f16(se[e] * bilerp(q0[t.x0[e]], q0[t.x1[e]], q1[t.x0[e]], q1[t.x1[e]], t.lx[e], ly));
+}
+__global__ __launch_bounds__(256) void upsample2x_planes_scaled_kernel(const float* __restrict__ in, const float* __restrict__ scale,
+                                                                       float* __restrict__ out, int P, int K, int H, int W) {
+    extern __shared__ float Rr[];             // [<= UPS_LB/2 + 4][W]
+    const int Ho = 2 * H, Wo = 2 * W, w4 = Wo / 4, bands = (Ho + UPS_LB - 1) / UPS_LB;
+    const int pl = blockIdx.x / bands, ya = (blockIdx.x - pl * bands) * UPS_LB;
+    const int yb = ya + UPS_LB - 1 < Ho - 1 ? ya + UPS_LB - 1 : Ho - 1;
+    const float ry = (float)(H - 1) / (float)(Ho - 1), rx = (float)(W - 1) / (float)(Wo - 1);
+    const int r_lo = ups_stage_r(in, Rr, pl, H, W, ry, ya, yb);
+    __syncthreads();
+    const float* sc = scale + (size_t)(pl / K) * Ho * Wo;
+    const int nsub = w4 < 256 ? 256 / w4 : 1;
+    for (int x4 = threadIdx.x % (w4 < 256 ? w4 : 256); x4 < w4; x4 += 256) {
+        const int sub = w4 < 256 ? threadIdx.x / w4 : 0;
+        if (sub >= nsub) break;
+        const ColTerms t = col_terms4(rx, x4, W);
+        for (int Y = ya + sub; Y <= yb; Y += nsub) {
+            float o[4];
+            ups_low4(Rr, sc, H, W, ry, r_lo, Y, x4, t, o);
+            *reinterpret_cast<float4*>(out + ((size_t)pl * Ho + Y) * Wo + x4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+// The same followed by scratch.output_conv's x2 bilinear (lseg_net.py:203) in one pass: R [P, H+2, W+2] -> logits [P, 4H, 4W], the
+// (2H, 2W) logits only ever exist as a band in LDS.  Bit-identical to upsample2x_planes_scaled + upsample2x_planes (bilerp).
+// A block = one plane x the output rows whose upper source row lies in a band of LB low rows.
+__global__ __launch_bounds__(256) void upsample4x_planes_scaled_kernel(const float* __restrict__ in, const float* __restrict__ scale,
+                                                                       float* __restrict__ out, int P, int K, int H, int W) {
+    extern __shared__ float sm[];             // Rr [<= UPS_LB/2 + 4][W] | Lr [UPS_LB + 1][2W]
+    const int Hl = 2 * H, Wl = 2 * W, Ho = 2 * Hl, Wo = 2 * Wl, w4 = Wo / 4, wl4 = Wl / 4, bands = (Hl + UPS_LB - 1) / UPS_LB;
+    const int pl = blockIdx.x / bands, ya = (blockIdx.x - pl * bands) * UPS_LB;
+    const int yb = ya + UPS_LB < Hl - 1 ? ya + UPS_LB : Hl - 1;        // last low row read (the band's rows + the next one)
+    float* Rr = sm;
+    float* Lr = sm + (UPS_LB / 2 + 4) * W;
+    const float ry1 = (float)(H - 1) / (float)(Hl - 1), rx1 = (float)(W - 1) / (float)(Wl - 1);
+    const int r_lo = ups_stage_r(in, Rr, pl, H, W, ry1, ya, yb);
+    __syncthreads();
+    const float* sc = scale + (size_t)(pl / K) * Hl * Wl;
+    {   // the band of (2H, 2W) logits into LDS
+        const int nsub = wl4 < 256 ? 256 / wl4 : 1;
+        for (int x4 = threadIdx.x % (wl4 < 256 ? wl4 : 256); x4 < wl4; x4 += 256) {
+            const int sub = wl4 < 256 ? threadIdx.x / wl4 : 0;
+            if (sub >= nsub) break;
+            const ColTerms t = col_terms4(rx1, x4, W);
+            for (int Y = ya + sub; Y <= yb; Y += nsub) {
+                float o[4];
+                ups_low4(Rr, sc, H, W, ry1, r_lo, Y, x4, t, o);
+                *reinterpret_cast<float4*>(Lr + (Y - ya) * Wl + x4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+        }
+    }
+    __syncthreads();
+    const float ry = (float)(Hl - 1) / (float)(Ho - 1), rx = (float)(Wl - 1) / (float)(Wo - 1);
+    // output rows of this band: y0(yo) = floor(ry * yo) in [ya, ya + LB)
+    int yo_first = (int)ceilf((float)ya / ry);
+    while (yo_first > 0 && (int)(ry * (float)(yo_first - 1)) >= ya) --yo_first;
+    while ((int)(ry * (float)yo_first) < ya) ++yo_first;
+    int yo_end = yo_first;
+    while (yo_end < Ho && (int)(ry * (float)yo_end) < ya + UPS_LB) ++yo_end;
+    const int nsub = w4 < 256 ? 256 / w4 : 1;
+    for (int x4 = threadIdx.x % (w4 < 256 ? w4 : 256); x4 < w4; x4 += 256) {
+        const int sub = w4 < 256 ? threadIdx.x / w4 : 0;
+        if (sub >= nsub) break;
+        const ColTerms t = col_terms4(rx, x4, Wl);
+        for (int yo = yo_first + sub; yo < yo_end; yo += nsub) {
+            int y0, y1;
+            float ly;
+            src_tap(ry, yo, Hl, y0, y1, ly);
+            const float* q0 = Lr + (y0 - ya) * Wl;
+            const float* q1 = Lr + (y1 - ya) * Wl;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = bilerp(q0[t.x0[e]], q0[t.x1[e]], q1[t.x0[e]], q1[t.x1[e]], t.lx[e], ly);
+            const f32x4_t ov = {o[0], o[1], o[2], o[3]};     // written once, never re-read by the engine
+            __builtin_nontemporal_store(ov, reinterpret_cast<f32x4_t*>(out + ((size_t)pl * Ho + yo) * Wo) + x4);
         }
     }
 }
@@ -1271,10 +1475,9 @@ __global__ __launch_bounds__(256) void seg_stats_kernel(const float* __restrict_
         float ly = 0.f, lx = 0.f;
         if (up) {
             const int yo = p / Wo, xo = p - yo * Wo;
-            const float sy = ry * (float)yo, sx = rx * (float)xo;
-            const int y0 = (int)sy, x0 = (int)sx;
-            const int y1 = y0 + (y0 < h - 1), x1 = x0 + (x0 < w - 1);
-            ly = sy - (float)y0; lx = sx - (float)x0;
+            int y0, y1, x0, x1;
+            src_tap(ry, yo, h, y0, y1, ly);
+            src_tap(rx, xo, w, x0, x1, lx);
             kstride = (size_t)h * w;
             col = scores + b * (size_t)K * kstride + (size_t)y0 * w + x0;
             o01 = x1 - x0; o10 = (y1 - y0) * w; o11 = o10 + o01;
@@ -1288,7 +1491,7 @@ __global__ __launch_bounds__(256) void seg_stats_kernel(const float* __restrict_
         for (int k = 0; k < K; ++k) {
             const float* c = col + (size_t)k * kstride;
             // same association as upsample_bilinear2d (and upsample2x_planes_kernel): bit-identical to the materialised logits
-            const float v = up ? (1.f - ly) * ((1.f - lx) * c[0] + lx * c[o01]) + ly * ((1.f - lx) * c[o10] + lx * c[o11]) : c[0];
+            const float v = up ? bilerp(c[0], c[o01], c[o10], c[o11], lx, ly) : c[0];
             if (v > m) {                                  // first maximum wins (torch.max / argmax tie rule)
                 ssum = ssum * __expf(m - v) + 1.f;        // online log-sum-exp (exp(-inf) = 0 on the first label)
                 m = v; arg = k;
@@ -2030,6 +2233,39 @@ int launch_sgd_multi(const SgdSeg* dev_segs, int nseg, unsigned blocks, float lr
 int launch_transpose16_multi(const TransposeJob* dev_jobs, int njobs, unsigned blocks, hipStream_t st) {
     if (njobs < 1 || blocks < 1) return 0;
     hipLaunchKernelGGL(transpose16_multi_kernel, dim3(blocks), dim3(256), 0, st, dev_jobs, njobs);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+// commuted correlation: cell dot products of g, the per-pixel scale plane, the scaled x2 upsample of the label planes
+int launch_pixel_gram(const void* g16, float* gram, int B, int H, int W, int C, hipStream_t st) {
+    if (C % 8 || C > 1024) return set_error(LSEG_ERR_UNSUPPORTED, "pixel gram: C=%d", C);
+    const size_t nrun = (size_t)B * H * ((W + 3) / 4);
+    const int blocks = (int)std::min<size_t>((nrun + 3) / 4, 256 * 32);
+    if (C <= 512) hipLaunchKernelGGL(pixel_gram_kernel<1>, dim3(blocks), dim3(256), 0, st, (const uint16_t*)g16, gram, B, H, W, C);
+    else hipLaunchKernelGGL(pixel_gram_kernel<2>, dim3(blocks), dim3(256), 0, st, (const uint16_t*)g16, gram, B, H, W, C);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_norm_scale_plane(const float* gram, float* scale, int B, int H, int W, float s, hipStream_t st) {
+    hipLaunchKernelGGL(norm_scale_plane_kernel, dim3(grid_for((size_t)B * 4 * H * W)), dim3(256), 0, st, gram, scale, B, H, W, s);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_upsample2x_planes_scaled(const float* in_padded, const float* scale, float* out, int P, int K, int H, int W, hipStream_t st) {
+    if (W % 2 != 0) return set_error(LSEG_ERR_UNSUPPORTED, "scaled upsample: W=%d must be even", W);
+    const int bands = (2 * H + UPS_LB - 1) / UPS_LB;
+    hipLaunchKernelGGL(upsample2x_planes_scaled_kernel, dim3((unsigned)P * bands), dim3(256), (size_t)(UPS_LB / 2 + 4) * W * sizeof(float), st,
+                       in_padded, scale, out, P, K, H, W);
+    CHECK_LAUNCH();
+    return 0;
+}
+// R planes -> the full-resolution logits in one pass (x2 with the per-pixel scale and fp16 rounding, then output_conv's x2)
+int launch_upsample4x_planes_scaled(const float* in_padded, const float* scale, float* out, int P, int K, int H, int W, hipStream_t st) {
+    if (W % 2 != 0) return set_error(LSEG_ERR_UNSUPPORTED, "scaled upsample: W=%d must be even", W);
+    const int bands = (2 * H + UPS_LB - 1) / UPS_LB;
+    const size_t lds = ((size_t)(UPS_LB / 2 + 4) * W + (size_t)(UPS_LB + 1) * 2 * W) * sizeof(float);
+    hipLaunchKernelGGL(upsample4x_planes_scaled_kernel, dim3((unsigned)P * bands), dim3(256), lds, st, in_padded, scale, out, P, K, H, W);
     CHECK_LAUNCH();
     return 0;
 }

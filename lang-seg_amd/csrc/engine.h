@@ -85,9 +85,11 @@ private:
     int pack_conv3(const std::string& wkey, const std::string& bn_prefix, const std::string& bias_key, int co, int ci,
                    int cop, int cip, Lin& out, hipStream_t st);
     int conv3x3(const void* in, const Lin& w, const void* res, const void* res2, void* out, int B, int H, int W,
-                int stride, int relu_in, int relu_out, hipStream_t st);
+                int stride, int relu_in, int relu_out, hipStream_t st, void* out_relu = nullptr, bool* relu_written = nullptr);
     int refine(int r, int B, hipStream_t st, bool stop_before_upsample = false);
     int flush_events();
+    int materialize_low(hipStream_t st);
+    bool low_pending_ = false; int low_planes_ = 0, low_k_ = 0;      // low_ = scaled x2 upsample of rpl_ not yet written (one-pass x4 upsample ran)
     // train.hip
     int train_alloc();
     int finalize_train(hipStream_t st);
@@ -135,6 +137,7 @@ private:
     Lin head1_;
     Lin headc_;                  // head1 o refinenet1.out_conv as ONE 1x1 conv (applied before the x2 upsample: engine.hip "commuted head")
     float *headc_w32_ = nullptr, *gpad_ = nullptr;
+    uint16_t* g16pad_ = nullptr; float *rpl_ = nullptr, *gram_ = nullptr, *nscale_ = nullptr;     // commuted correlation (engine.hip)
     float *hb_w_ = nullptr, *hb_b_ = nullptr;
     float *tok_emb_ = nullptr, *tpos_ = nullptr, *tlnf_g_ = nullptr, *tlnf_b_ = nullptr;
     std::vector<TextBlock> tblocks_;
@@ -146,6 +149,8 @@ private:
     uint16_t *patchA_ = nullptr, *catA_ = nullptr, *ro_ = nullptr, *r1_ = nullptr, *tmp_pad_ = nullptr;
     uint16_t* L_[4] = {};         // reassembled maps, padded NHWC
     uint16_t* rn_[4] = {};        // layerN_rn outputs, padded NHWC
+    uint16_t *rnr_[4] = {}, *sumr_[4] = {};   // ReLU(rn_) / ReLU(sum_) written by the producing conv's epilogue (refine())
+    bool rn_relu_ok_[4] = {};
     uint16_t *t1_[4] = {}, *sum_[4] = {}, *t2_[4] = {};   // refinenet temporaries per level
     uint16_t* up_[4] = {};        // upsampled (plain) per level
     uint16_t* path_[4] = {};      // path_r outputs: r=4..2 padded at next level's size, r=1 plain

@@ -125,6 +125,7 @@ int Engine::init() {
         const size_t pp = B * (lh_[l] + 2) * (lw_[l] + 2);
         ALLOC16(L_[l], pp * cp_[l]);
         ALLOC16(rn_[l], pp * F);
+        if (!strict_) { ALLOC(rnr_[l], uint16_t, pp * F); ALLOC(sumr_[l], uint16_t, pp * F); }      // ReLU copies (zero border like every padded map)
         ALLOC16(t1_[l], pp * F);
         ALLOC16(sum_[l], pp * F);
         ALLOC16(t2_[l], pp * F);
@@ -135,6 +136,11 @@ int Engine::init() {
     if (strict_) ALLOC16(relu_tmp_, B * (lh_[0] + 2) * (lw_[0] + 2) * F);
     const size_t hw1 = (size_t)4 * lh_[0] * lw_[0];
     ALLOC(gpad_, float, B * (lh_[0] + 2) * (lw_[0] + 2) * c.out_c);
+    // commuted correlation: g in fp16, the label planes R = T g^T at the quarter resolution, cell dot products, per-pixel scale
+    ALLOC(g16pad_, uint16_t, B * (lh_[0] + 2) * (lw_[0] + 2) * c.out_c);
+    ALLOC(rpl_, float, B * c.max_labels * (lh_[0] + 2) * (lw_[0] + 2));
+    ALLOC(gram_, float, B * lh_[0] * lw_[0] * 5);
+    ALLOC(nscale_, float, B * hw1);
     ALLOC(feat_, float, B * hw1 * c.out_c);
     ALLOC(a16_, uint16_t, B * hw1 * c.out_c);
     ALLOC(low_, float, B * c.max_labels * hw1);
@@ -489,7 +495,7 @@ int Engine::encode_text(hipStream_t st) {
 }
 
 int Engine::conv3x3(const void* in, const Lin& w, const void* res, const void* res2, void* out, int B, int H, int W,
-                    int stride, int relu_in, int relu_out, hipStream_t st) {
+                    int stride, int relu_in, int relu_out, hipStream_t st, void* out_relu, bool* relu_written) {
     // in: padded NHWC [B,H+2,W+2,Cin]; out: padded NHWC [B,Ho+2,Wo+2,Cout]
     GemmArgs g;
     gemm_args_init(g);
@@ -503,6 +509,11 @@ int Engine::conv3x3(const void* in, const Lin& w, const void* res, const void* r
     g.bias = w.b; g.act = relu_out ? ACT_RELU : ACT_NONE;
     if (res) { g.res_mode = RES_DEST; g.res = res; g.res_dtype = img_dt_; g.res2 = res2; }
     g.C = out; g.out_dtype = img_dt_; g.ldc = w.n; g.map_mode = MAP_PADDED;
+    if (relu_written) *relu_written = false;
+    if (out_relu && !strict_ && gemm_epilogue_is_pad16(g, img_dt_)) {       // also keep ReLU(out): the next unit's conv input
+        g.C_relu = out_relu;
+        if (relu_written) *relu_written = true;
+    }
     return igemm(g, st);
 }
 
@@ -510,16 +521,21 @@ int Engine::conv3x3(const void* in, const Lin& w, const void* res, const void* r
 int Engine::refine(int r, int B, hipStream_t st, bool stop_before_upsample) {
     const int l = r - 1, H = lh_[l], W = lw_[l], F = cfg.features;
     Refine& R = refine_[l];
+    // A residual unit reads ReLU(x) as its conv input and x as its skip (lseg_blocks.py:270-288).  Where the producer of x ran on the
+    // specialised epilogue it also left ReLU(x) (rnr_ / sumr_): the conv then runs without the per-fragment clamp in its K-loop.
     const uint16_t* rcu2_in;
+    bool rcu2_relu = rn_relu_ok_[l];
+    const uint16_t* rcu2_conv_in = rn_relu_ok_[l] ? rnr_[l] : rn_[l];
     if (R.has_u1) {
         // output = path_{r+1} + resConfUnit1(layer_r_rn)   (:345-347), RCU: lseg_blocks.py:265-288
-        TRY(conv3x3(rn_[l], R.u1.c1, nullptr, nullptr, t1_[l], B, H, W, 1, 1, 1, st));
-        TRY(conv3x3(t1_[l], R.u1.c2, rn_[l], path_[l + 1], sum_[l], B, H, W, 1, 0, 0, st));
+        TRY(conv3x3(rn_relu_ok_[l] ? rnr_[l] : rn_[l], R.u1.c1, nullptr, nullptr, t1_[l], B, H, W, 1, rn_relu_ok_[l] ? 0 : 1, 1, st));
+        TRY(conv3x3(t1_[l], R.u1.c2, rn_[l], path_[l + 1], sum_[l], B, H, W, 1, 0, 0, st, sumr_[l], &rcu2_relu));
         rcu2_in = sum_[l];
+        rcu2_conv_in = rcu2_relu ? sumr_[l] : sum_[l];
     } else {
         rcu2_in = rn_[l];
     }
-    TRY(conv3x3(rcu2_in, R.u2.c1, nullptr, nullptr, t1_[l], B, H, W, 1, 1, 1, st));
+    TRY(conv3x3(rcu2_conv_in, R.u2.c1, nullptr, nullptr, t1_[l], B, H, W, 1, rcu2_relu ? 0 : 1, 1, st));
     TRY(conv3x3(t1_[l], R.u2.c2, rcu2_in, nullptr, t2_[l], B, H, W, 1, 0, 0, st));
     if (stop_before_upsample) return 0;         // the commuted head takes it from here
     if (strict_) TRY(launch_upsample2x_nhwc_split(t2_[l], pl(t2_[l]), up_[l], pl(up_[l]), B, H, W, F, st));
@@ -595,6 +611,7 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
     const lseg_config& c = cfg;
     const int D = c.dim, H = c.heads, F = c.features, M = B * ntok_;
     last_B_ = B;
+    low_pending_ = false;
     hipEvent_t fwd0 = nullptr, fwd1 = nullptr;
     if (profiling) { fwd0 = get_event(); fwd1 = get_event(); if (fwd0) (void)hipEventRecord(fwd0, st); }
 
@@ -687,7 +704,7 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
                 TRY(conv3x3(tmp_pad_, rsmp_[l], nullptr, nullptr, L_[l], B, gh_, gw_, 2, 0, 0, st));
             }
             // scratch.layerN_rn (lseg_net.py:171-174)
-            TRY(conv3x3(L_[l], layer_rn_[l], nullptr, nullptr, rn_[l], B, lh_[l], lw_[l], 1, 0, 0, st));
+            TRY(conv3x3(L_[l], layer_rn_[l], nullptr, nullptr, rn_[l], B, lh_[l], lw_[l], 1, 0, 0, st, rnr_[l], &rn_relu_ok_[l]));
         }
     }
 
@@ -705,7 +722,50 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
     gemm_args_init(g);
     g.A = path_[0]; g.W = head1_.w; g.M = Mp; g.N = c.out_c; g.K = F; g.lda = F; g.ldw = F;
     g.bias = head1_.b;
-    if (commuted) {
+    // ... and so does the correlation: t_k . up(g)_P = up(t_k . g)_P, with ||up(g)_P|| from the dot products of g's 2x2 cells
+    // (elementwise.hip "commuted correlation"): the pixel x text GEMM runs on 4x fewer pixels and the 240x240x512 feature map never exists
+    static const bool corr_full = getenv("LSEG_CORR_FULLRES") != nullptr;           // A/B switch (tools): the correlation at (2h, 2w)
+    const bool corr_low = commuted && !corr_full && (lw_[0] % 2) == 0;
+    if (corr_low && group_k > 0) {
+        if (K_ != B * group_k)
+            return set_error(LSEG_ERR_INVALID, "grouped labels: %d token rows != B=%d x %d labels per image", K_, B, group_k);
+        if (c.arch_option != 0) return set_error(LSEG_ERR_UNSUPPORTED, "per-image label sets have no head blocks (lseg_net_zs.py:177-214)");
+    }
+    if (corr_low) {
+        const int hp = lh_[0] + 2, wp = lw_[0] + 2;
+        g.A = t2_[0]; g.W = headc_.w; g.bias = headc_.b; g.M = B * hp * wp;
+        g.C = g16pad_; g.out_dtype = DT_F16; g.ldc = c.out_c; g.map_mode = MAP_LINEAR;
+        TRY(igemm(g, st));
+        TRY(launch_pixel_gram(g16pad_, gram_, B, lh_[0], lw_[0], c.out_c, st));
+        TRY(launch_norm_scale_plane(gram_, nscale_, B, lh_[0], lw_[0], logit_scale, st));
+        if (group_k > 0) {
+            // lseg_net_zs.py:198-208: image b against its own k text rows -- B small GEMMs [k, out_c] x [out_c, hp*wp]
+            for (int b = 0; b < B; ++b) {
+                gemm_args_init(g);
+                g.A = tnorm_ + (size_t)b * group_k * c.out_c; g.W = g16pad_ + (size_t)b * hp * wp * c.out_c;
+                g.M = group_k; g.N = hp * wp; g.K = c.out_c; g.lda = c.out_c; g.ldw = c.out_c;
+                g.C = rpl_ + (size_t)b * group_k * hp * wp; g.out_dtype = DT_F32; g.map_mode = MAP_LABELPLANES; g.p_div = hp * wp;
+                TRY(launch_gemm(g, DT_F16, st));
+            }
+        } else {
+            gemm_args_init(g);
+            g.A = tnorm_; g.W = g16pad_; g.M = K_; g.N = B * hp * wp; g.K = c.out_c; g.lda = c.out_c; g.ldw = c.out_c;
+            g.C = rpl_; g.out_dtype = DT_F32; g.map_mode = MAP_LABELPLANES; g.p_div = hp * wp;
+            TRY(launch_gemm(g, DT_F16, st));
+        }
+        // R -> logits.  When only the full-resolution logits are wanted the two x2 upsamples run as one pass and the (2h, 2w) logits
+        // stay in LDS; masks, head blocks, the "lowres" tap and lseg_forward_stats need them in memory (made on demand below).
+        const int kk = group_k > 0 ? group_k : K_;
+        low_pending_ = true; low_planes_ = B * kk; low_k_ = kk;
+        static const bool no_4x = getenv("LSEG_NO_UPSAMPLE4X") != nullptr;          // A/B switch (tools)
+        if (logits && !argmax_out && c.arch_option == 0 && !no_4x) {
+            TRY(launch_upsample4x_planes_scaled(rpl_, nscale_, logits, B * kk, kk, lh_[0], lw_[0], st));
+            last_low_ = low_; last_kout_ = kk;
+            if (profiling && fwd0 && fwd1) { (void)hipEventRecord(fwd1, st); ev_fwd_.push_back({fwd0, fwd1}); }
+            return 0;
+        }
+        TRY(materialize_low(st));
+    } else if (commuted) {
         // g = Wc t2 + bc on every row of the padded map (border rows are never read), fp32; then x2 bilinear + L2-norm + fp16 casts
         g.A = t2_[0]; g.W = headc_.w; g.bias = headc_.b; g.M = B * (lh_[0] + 2) * (lw_[0] + 2);
         g.C = gpad_; g.out_dtype = DT_F32; g.ldc = c.out_c; g.map_mode = MAP_LINEAR;
@@ -722,7 +782,9 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
         TRY(launch_l2norm_scale_f16(feat_, a16_, Mp, c.out_c, logit_scale, st));
     }
     const int Kout = group_k > 0 ? group_k : K_;            // label planes per image
-    if (group_k > 0) {
+    if (corr_low) {
+        // low_ already holds the (2h, 2w) logits
+    } else if (group_k > 0) {
         // lseg_net_zs.py:198-208: image b against its own k text rows -- B small GEMMs [hw1,out_c] x [out_c,k]
         if (K_ != B * group_k)
             return set_error(LSEG_ERR_INVALID, "grouped labels: %d token rows != B=%d x %d labels per image", K_, B, group_k);
@@ -764,12 +826,20 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
     return 0;
 }
 
+// the (2h, 2w) logits of the last forward in memory (the one-pass x4 upsample skipped them)
+int Engine::materialize_low(hipStream_t st) {
+    if (!low_pending_) return 0;
+    low_pending_ = false;
+    return launch_upsample2x_planes_scaled(rpl_, nscale_, low_, low_planes_, low_k_, lh_[0], lw_[0], st);
+}
+
 // pixAcc / IoU counts and the cross-entropy sum of the LAST forward's output against a target mask, from the low-resolution logits
 // through the x2 bilinear on the fly (lsegmentation_module.py:49-50,59-60,72: the metric / loss step after the path)
 int Engine::forward_stats(const int64_t* target, int ignore_index, int64_t* counts, double* nll, hipStream_t st) {
     if (!last_low_ || last_B_ < 1) return set_error(LSEG_ERR_STATE, "no forward has run");
     if (!target || !counts || !nll) return set_error(LSEG_ERR_INVALID, "forward_stats: NULL pointer");
     LSEG_HIP_TRY(hipSetDevice(device));
+    TRY(materialize_low(st));
     const int h1 = 2 * lh_[0], w1 = 2 * lw_[0];
     return launch_seg_stats_ex(last_low_, target, last_B_, last_kout_, 4 * h1 * w1, ignore_index, reinterpret_cast<unsigned long long*>(counts),
                                nll, nullptr, 1, h1, w1, st);
@@ -813,6 +883,7 @@ int Engine::get_intermediate(const char* name, float* out, size_t cap, size_t* n
         if (cap < need_n) return set_error(LSEG_ERR_INVALID, "buffer too small: %zu < %zu", cap, need_n);
         TRY(launch_rows_to_nchw_f32(feat_, out, B, hw1, cfg.out_c, st));
     } else if (!strcmp(name, "lowres")) {
+        TRY(materialize_low(st));
         const int hw1 = 4 * lh_[0] * lw_[0];
         need_n = (size_t)B * (group_k > 0 ? group_k : K_) * hw1;
         if (cap < need_n) return set_error(LSEG_ERR_INVALID, "buffer too small: %zu < %zu", cap, need_n);

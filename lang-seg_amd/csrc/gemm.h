@@ -43,6 +43,9 @@ struct GemmArgs {
     const void* res;  int res_dtype; int ldr;   // residual tensor
     const void* res2;                            // optional second residual (RES_DEST, same dtype/geometry)
     void* C;  int out_dtype; int ldc;
+    void* C_relu;               // MAP_PADDED on the specialised epilogue only (gemm_epilogue_is_pad16): a second copy ReLU(C), same geometry --
+                                // the DPT residual units read ReLU(x) as conv input and x as skip (lseg_blocks.py:270-288): clamping the
+                                // A fragments in the K-loop instead costs the 3x3 convs a third of their MFMA rate
     int map_mode;
     int p_div, p_mul, p_off;    // MAP_PERIODIC / RES_PERIODIC / MAP_NCHW(P)
     int ps_s, ps_C;             // MAP_PIXSHUF
@@ -71,5 +74,7 @@ void gemm_args_init(GemmArgs& g);
 int device_cu_count(int dev);
 // ab_dtype: DT_BF16 | DT_F16.  Returns 0 or a negative lseg_status.
 int launch_gemm(const GemmArgs& g, int ab_dtype, hipStream_t stream);
+// true when launch_gemm would run this problem on the specialised padded-NHWC epilogue (the one that honours C_relu)
+bool gemm_epilogue_is_pad16(const GemmArgs& g, int ab_dtype);
 
 }  // namespace lseg

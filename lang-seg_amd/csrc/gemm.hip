@@ -379,6 +379,7 @@ enum Epi {
     EPI_RES32 = 3,        // C[m*ldc+n] = res[m*ldc+n] + acc + bias, fp32    (attention proj / MLP fc2 on the residual stream)
     EPI_QKV16 = 4,        // MAP_QKV, q,k -> [b,head,t,d], v -> [b,head,d,t]
     EPI_PAD16 = 5,        // MAP_PADDED NHWC (1-pixel zero border), T(act(acc + bias) [+ res [+ res2]]): the DPT head's 3x3 convs
+    EPI_LIN16_F16 = 6,    // MAP_LINEAR, C = fp16(acc + bias) from bf16 operands: the commuted head's g (the fp16 operand of the correlation)
 };
 
 // two adjacent 16-column sub-tiles (4 columns per lane each) -> 8 contiguous columns (16 bytes) per lane
@@ -403,7 +404,8 @@ __device__ __forceinline__ void fast_epilogue(const GemmArgs& g, f32x4_t (&acc)[
         v[0] = acc[i][j][0] + bias[i].x; v[1] = acc[i][j][1] + bias[i].y;
         v[2] = acc[i][j][2] + bias[i].z; v[3] = acc[i][j][3] + bias[i].w;
     };
-    if constexpr (EPI == EPI_LIN16 || EPI == EPI_LIN16_GELU) {
+    if constexpr (EPI == EPI_LIN16 || EPI == EPI_LIN16_GELU || EPI == EPI_LIN16_F16) {
+        using OT = typename std::conditional<EPI == EPI_LIN16_F16, F16, T>::type;
         uint16_t* cbase = (uint16_t*)g.C + ncol0 + cw;
         static_for<0, MI>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
@@ -420,7 +422,7 @@ __device__ __forceinline__ void fast_epilogue(const GemmArgs& g, f32x4_t (&acc)[
                     x[0] = a[0]; x[1] = a[1]; x[2] = b[0]; x[3] = b[1];
                     y[0] = c[0]; y[1] = c[1]; y[2] = d[0]; y[3] = d[1];
                 }
-                const uint4 o = widen16<T>(x, y);
+                const uint4 o = widen16<OT>(x, y);
                 if (m < g.M) *reinterpret_cast<uint4*>(p + i * 16) = o;
             });
         });
@@ -499,7 +501,13 @@ __device__ __forceinline__ void fast_epilogue(const GemmArgs& g, f32x4_t (&acc)[
                     }
                 }
                 const uint4 o = widen16<T>(x4[0], x4[1]);
-                if (m < g.M) *reinterpret_cast<uint4*>(prow + i * 16) = o;
+                if (m < g.M) {
+                    *reinterpret_cast<uint4*>(prow + i * 16) = o;
+                    if (g.C_relu) {          // second copy with the negative halves cleared (sign bit of a bf16 / fp16 half)
+                        auto rl = [](uint32_t w) { return ((w & 0x8000u) ? 0u : (w & 0xffffu)) | ((w & 0x80000000u) ? 0u : (w & 0xffff0000u)); };
+                        *reinterpret_cast<uint4*>((uint16_t*)g.C_relu + r0 + cw + i * 16) = make_uint4(rl(o.x), rl(o.y), rl(o.z), rl(o.w));
+                    }
+                }
             });
         });
     } else if constexpr (EPI == EPI_QKV16) {
@@ -1053,6 +1061,8 @@ int select_epi(const GemmArgs& g) {
         if (g.act == ACT_GELU) return EPI_LIN16_GELU;
         return EPI_GENERIC;
     }
+    if (g.map_mode == MAP_LINEAR && g.res_mode == RES_NONE && dt == DT_BF16 && g.out_dtype == DT_F16 && (g.ldc % 8) == 0 && g.act == ACT_NONE)
+        return EPI_LIN16_F16;
     if (g.map_mode == MAP_LINEAR && g.res_mode == RES_DEST && g.out_dtype == DT_F32 && g.res_dtype == DT_F32 &&
         g.act == ACT_NONE && (g.ldc % 4) == 0 && !(reinterpret_cast<uintptr_t>(g.res) & 15))
         return EPI_RES32;
@@ -1089,12 +1099,19 @@ int dispatch(const GemmArgs& g, hipStream_t stream) {
             if (g.tag == 1) return pick_tile<T, false, false, EPI_LIN16_GELU, 1>(g, stream);
             return pick_tile<T, false, false, EPI_LIN16_GELU, 0>(g, stream);
         case EPI_RES32: return pick_tile<T, false, false, EPI_RES32, 0>(g, stream);
+        case EPI_LIN16_F16: return pick_tile<T, false, false, EPI_LIN16_F16, 0>(g, stream);
         case EPI_QKV16: return pick_tile<T, false, false, EPI_QKV16, 0>(g, stream);
         default: return pick_tile<T, false, false, EPI_GENERIC, 0>(g, stream);
     }
 }
 
 }  // namespace
+
+bool gemm_epilogue_is_pad16(const GemmArgs& g, int ab_dtype) {
+    if (ab_dtype == DT_BF16) return select_epi<BF16>(g) == EPI_PAD16;
+    if (ab_dtype == DT_F16) return select_epi<F16>(g) == EPI_PAD16;
+    return false;
+}
 
 int launch_gemm(const GemmArgs& g_in, int ab_dtype, hipStream_t stream) {
     GemmArgs g = g_in;
@@ -1103,6 +1120,7 @@ int launch_gemm(const GemmArgs& g_in, int ab_dtype, hipStream_t stream) {
     static const int group_m = getenv("LSEG_GEMM_GROUP_M") ? atoi(getenv("LSEG_GEMM_GROUP_M")) : 8;   // tools: L2 locality sweeps
     g.group_m = group_m > 0 ? group_m : 8;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return set_error(LSEG_ERR_INVALID, "gemm: empty problem %dx%dx%d", g.M, g.N, g.K);
+    if (g.C_relu && !gemm_epilogue_is_pad16(g, ab_dtype)) return set_error(LSEG_ERR_UNSUPPORTED, "gemm: C_relu needs the padded-NHWC specialised epilogue");
     if (g.K % 64 != 0) return set_error(LSEG_ERR_UNSUPPORTED, "gemm: K=%d must be a multiple of 64", g.K);
     if (g.conv && (g.cin % 64 != 0)) return set_error(LSEG_ERR_UNSUPPORTED, "conv: Cin=%d must be a multiple of 64", g.cin);
     if (g.nsplit > 1 && (g.bias || g.res_mode != RES_NONE || g.map_mode != MAP_LINEAR || g.split || g.split_steps < 1 ||

@@ -257,6 +257,7 @@ int Engine::forward_train(const float* x_in, int B, float* logits, hipStream_t s
     if (!train_alloc_) return set_error(LSEG_ERR_STATE, "train mode was not enabled (lseg_set_train)");
     train_fwd_valid_ = false;
     last_B_ = B;
+    low_pending_ = false;
     eval_stale_ = true;             // the BatchNorm running statistics move: the eval-mode (BN-folded) packs are refreshed by the next eval forward
     const bool run_text = !text_cache || !text_valid;
     if (run_text) {

@@ -55,7 +55,8 @@ def run_engine(spec, image_dtype="bf16", debug=True):
     eng.load_state_dict(sd)
     eng.set_tokens(tok)
     eng.set_debug(debug)
-    logits, amax = eng.forward(x.cuda(), want_logits=True, want_argmax=True)
+    logits = eng.forward(x.cuda())                                              # logits only: the call every caller of the class makes
+    amax = eng.forward(x.cuda(), want_logits=False, want_argmax=True)           # masks only
     torch.cuda.synchronize()
     return cfg, sd, tok, x, eng, logits, amax
 
@@ -453,6 +454,23 @@ def test_masks_and_metrics_without_the_full_resolution_logits():
     # counts may differ only through pixels with an exact fp32 tie between the two best labels (none on this input)
     assert (res[0][0] - res[1][0]).abs().max().item() <= int((~decisive).sum().item())
     assert abs(res[0][1][0] - res[1][1][0]).item() <= 1e-6 * abs(res[0][1][0]).item() and res[0][1][1] == res[1][1][1]
+
+
+def test_one_pass_x4_upsample_equals_its_two_stages():
+    """Production schedule: the logits come out of ONE pass over the quarter-resolution label planes (x2 bilinear * per-pixel 1/||.||,
+    fp16 rounding, then output_conv's x2 bilinear, lseg_net.py:191-203) and the (h/2, w/2) logits stay in LDS.  They must equal
+    output_conv applied to the low-resolution logits the engine writes on demand (the "lowres" tap / masks / metrics path), and the
+    two ways of asking for the masks must agree."""
+    import torch.nn.functional as F
+    cfg, sd, tok, x, eng, logits, amax = run_engine(MG.CASES["tiny16_96x64_k7"], debug=False)
+    B, K, H, W = logits.shape
+    only_logits = eng.forward(x.cuda())                                     # one-pass x4 upsample
+    low = eng.intermediate("lowres", (B, K, H // 2, W // 2))                # written on demand from the same label planes
+    two_stage = F.interpolate(low, scale_factor=2, mode="bilinear", align_corners=True)
+    assert (only_logits - two_stage).abs().max().item() <= 2e-6 * max(1.0, two_stage.abs().max().item())
+    both, amax2 = eng.forward(x.cuda(), want_logits=True, want_argmax=True)  # logits AND masks: the two x2 kernels
+    assert torch.equal(both, only_logits) and torch.equal(amax2, amax)       # same arithmetic, spelled out (bilerp / src_tap)
+    assert torch.equal(low, low.half().float())                             # the reference's fp16 logits before output_conv
 
 
 def test_module_metrics_path_needs_no_logits():

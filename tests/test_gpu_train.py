@@ -219,8 +219,15 @@ def test_fused_sgd_matches_torch_sgd():
     eng_b, out_b, loss_b, _ = _engine_step(cfg, sd_new, x, target, tok)
     assert torch.equal(out_a, out_b)
     assert abs(float(loss_a) - float(loss_b)) <= 1e-6 * abs(float(loss_b))
-    for k in keys:                     # atomics in the BatchNorm / bias sums: run-to-run noise only
-        assert rel(grads_a[k], eng_b.grads[k]) < 2e-3, k
+    # gradients: equal up to the run-to-run noise of the fp32 atomics in the BatchNorm / bias sums, measured by repeating the step on
+    # the fresh engine (a stale W^T / flipped-conv pack would show up here: only the backward reads those)
+    grads_b = {k: v.clone() for k, v in eng_b.grads.items()}
+    eng_b.forward(x.cuda())
+    eng_b.backward(target=target.cuda(), ignore_index=-1)
+    torch.cuda.synchronize()
+    report = {k: (rel(grads_a[k], grads_b[k]), rel(eng_b.grads[k], grads_b[k])) for k in keys}
+    bad = {k: v for k, v in report.items() if v[0] > max(1e-4, 20 * v[1])}
+    assert not bad, bad
     # ... and the eval-only packs (BatchNorm folded into the convs, the commuted head) catch up at the next eval forward
     eng.set_train(False); eng_b.set_train(False)
     assert torch.equal(eng.forward(x.cuda()), eng_b.forward(x.cuda()))
