@@ -215,6 +215,22 @@ int lseg_op_seg_stats(const float* d_scores, const int64_t* d_target, int B, int
 int lseg_op_seg_stats_lowres(const float* d_low, const int64_t* d_target, int B, int K, int h, int w, int ignore_index,
                              int64_t* d_counts, double* d_nll, uint8_t* d_argmax, void* stream);
 
+/* Device side of the multi-scale / flip sliding-window evaluator that calls the forward (additional_utils/encoding_models.py:54-155
+ * MultiEvalModule.forward, module_inference, pad_image, crop_image, flip_image; additional_utils/models.py:55-140).  Per scale:
+ *   lseg_op_eval_make_crops  d_img fp32 [C,height,width] (the resized image, C <= 3) -> d_crops fp32 [(1+flip)*n, C, crop, crop], n =
+ *                            h_grids*w_grids: crop (idh,idw) starts at (idh*stride, idw*stride), pixels beyond the image take pad[c]
+ *                            (= -mean/std, :144-155); with flip the second half holds the mirrored twins (:135-137)
+ *   lseg_op_eval_accumulate  d_outs fp32 [(1+flip)*n, K, crop, crop] (the engine's logits for that stack) -> d_map fp32 [K,height,width]:
+ *                            out + flip(out_twin) summed over the covering boxes in (idh,idw) order, divided by their count, cropped
+ *                            to the un-padded size (:100-121); ph, pw = size of the padded image the boxes are clipped to
+ *   lseg_op_eval_resize      d_dst [P,Ho,Wo] (+)= bilinear(d_src [P,Hi,Wi]), align_corners=True (:78, :123: the image resize and
+ *                            `scores += resize_image(outputs, h, w)`) */
+int lseg_op_eval_make_crops(const float* d_img, float* d_crops, int C, int height, int width, int crop, int stride, int h_grids, int w_grids,
+                            int flip, const float* host_pad3, void* stream);
+int lseg_op_eval_accumulate(const float* d_outs, float* d_map, int K, int height, int width, int ph, int pw, int crop, int stride,
+                            int h_grids, int w_grids, int flip, void* stream);
+int lseg_op_eval_resize(const float* d_src, float* d_dst, int P, int Hi, int Wi, int Ho, int Wo, int accumulate, void* stream);
+
 /* Backward of one Linear layer y = x W^T + b -- first brick of the training step (the reference gets
  * it from torch autograd under LSegmentationModule.training_step, lsegmentation_module.py:66-81).  bf16/fp16 operands,
  * fp32 accumulate, both GEMMs on the forward MFMA kernel with the contraction dimension transposed onto the fast axis:

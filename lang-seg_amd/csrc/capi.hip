@@ -274,6 +274,30 @@ int lseg_op_upsample_ce_backward_rows(const float* d_low, const int64_t* d_targe
     return r;
 }
 
+int lseg_op_eval_make_crops(const float* d_img, float* d_crops, int C, int height, int width, int crop, int stride, int h_grids, int w_grids,
+                            int flip, const float* host_pad3, void* stream) {
+    int r = require_device(); if (r) return r;
+    if (!d_img || !d_crops || !host_pad3) return set_error(LSEG_ERR_INVALID, "eval_make_crops: NULL pointer");
+    if (C < 1 || C > 3 || height < 1 || width < 1 || crop < 1 || stride < 1 || h_grids < 1 || w_grids < 1)
+        return set_error(LSEG_ERR_INVALID, "eval_make_crops: bad geometry");
+    return launch_eval_make_crops(d_img, d_crops, C, height, width, crop, stride, h_grids, w_grids, flip ? 1 : 0, host_pad3, (hipStream_t)stream);
+}
+int lseg_op_eval_accumulate(const float* d_outs, float* d_map, int K, int height, int width, int ph, int pw, int crop, int stride,
+                            int h_grids, int w_grids, int flip, void* stream) {
+    int r = require_device(); if (r) return r;
+    if (!d_outs || !d_map) return set_error(LSEG_ERR_INVALID, "eval_accumulate: NULL pointer");
+    if (K < 1 || height < 1 || width < 1 || height > ph || width > pw || crop < 1 || stride < 1 || h_grids < 1 || w_grids < 1 ||
+        (h_grids - 1) * stride + crop < ph || (w_grids - 1) * stride + crop < pw)
+        return set_error(LSEG_ERR_INVALID, "eval_accumulate: the boxes do not cover the %dx%d map", ph, pw);
+    return launch_eval_accumulate(d_outs, d_map, K, height, width, ph, pw, crop, stride, h_grids, w_grids, flip ? 1 : 0, (hipStream_t)stream);
+}
+int lseg_op_eval_resize(const float* d_src, float* d_dst, int P, int Hi, int Wi, int Ho, int Wo, int accumulate, void* stream) {
+    int r = require_device(); if (r) return r;
+    if (!d_src || !d_dst) return set_error(LSEG_ERR_INVALID, "eval_resize: NULL pointer");
+    if (P < 1 || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1) return set_error(LSEG_ERR_INVALID, "eval_resize: bad shape");
+    return launch_eval_resize(d_src, d_dst, P, Hi, Wi, Ho, Wo, accumulate ? 1 : 0, (hipStream_t)stream);
+}
+
 int lseg_op_linear_backward(const void* d_dy, const void* d_x, const void* d_w, int ab_dtype, void* d_dx, float* d_dw,
                             float* d_db, int M, int N, int K, void* stream) {
     int r = require_device(); if (r) return r;

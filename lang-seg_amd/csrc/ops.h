@@ -122,4 +122,11 @@ int launch_sgd_multi(const SgdSeg* dev_segs, int nseg, unsigned blocks, float lr
                      hipStream_t st);
 int launch_transpose16_multi(const TransposeJob* dev_jobs, int njobs, unsigned blocks, hipStream_t st);
 
+// ---- multi-scale / flip evaluator data movement (evaluator.hip) ---------------------------------------------------------------
+int launch_eval_make_crops(const float* img, float* crops, int C, int height, int width, int crop, int stride, int h_grids, int w_grids,
+                           int flip, const float* pad3, hipStream_t st);
+int launch_eval_accumulate(const float* outs, float* outputs, int K, int height, int width, int ph, int pw, int crop, int stride, int h_grids,
+                           int w_grids, int flip, hipStream_t st);
+int launch_eval_resize(const float* src, float* dst, int P, int Hi, int Wi, int Ho, int Wo, int accumulate, hipStream_t st);
+
 }  // namespace lseg

@@ -91,6 +91,9 @@ SIGNATURES = {
     "lseg_op_relu_backward": (_i, [_vp, _vp, _vp, C.c_int64, _vp]),
     "lseg_op_upsample2x_planes_backward_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "lseg_op_upsample_ce_backward_rows": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp]),
+    "lseg_op_eval_make_crops": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "lseg_op_eval_accumulate": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "lseg_op_eval_resize": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "lseg_op_l2norm_scale_backward": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _f, _vp]),
     "lseg_op_qkv_grad_pack": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "lseg_op_gelu_backward": (_i, [_vp, _vp, _vp, C.c_int64, _i, _vp]),

@@ -6,8 +6,12 @@ Same algorithm, same arithmetic order per pixel, but every crop of a scale and i
 go through the engine as ONE batch instead of 2 x n_crops separate B=1 forwards (a 4:3 ADE image
 costs the reference 36 B=1 forwards, each re-encoding the 150 labels; here 6 batched forwards).
 Images of a batch are independent in the engine, so the result is identical to the sequential
-schedule.  Only data movement (resize / pad / crop / flip / accumulate) happens here, in torch.
+schedule.  The data movement around the forwards -- resize / pad / crop / flip / overlap-add / count-normalise -- runs on
+the device in three kernels per scale (csrc/evaluator.hip through the C ABI: lseg_op_eval_make_crops / _accumulate /
+_resize) when the image lives on the GPU; the torch statement of the same steps below is the definition they are tested
+against and what runs for host tensors (tests/test_evaluator_ref_golden.py drives it with a toy module on the CPU).
 """
+import ctypes as C
 import math
 from typing import List, Optional, Sequence
 
@@ -63,8 +67,59 @@ class BatchedMultiEval(torch.nn.Module):
         """list of [3,h,w] images in, list of [1,nclass,h,w] score maps out (encoding_models.py:35-52)."""
         return [self.forward(img.unsqueeze(0).cuda(), label_set) for img in inputs]
 
+    def _module_eval(self, xs: torch.Tensor, label_set) -> torch.Tensor:
+        outs = []
+        for i in range(0, xs.shape[0], self.max_batch):
+            chunk = xs[i:i + self.max_batch]
+            outs.append(self.module.evaluate(chunk) if label_set is None else self.module.evaluate_random(chunk, label_set))
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=0)
+
+    @torch.no_grad()
+    def _forward_device(self, image: torch.Tensor, label_set=None) -> torch.Tensor:
+        """The same schedule with the data movement in csrc/evaluator.hip (image on the GPU)."""
+        from . import _lib
+        lib = _lib.load()
+        P = lambda t: C.c_void_p(t.data_ptr())
+        st = C.c_void_p(torch.cuda.current_stream(image.device).cuda_stream)
+        batch, ch, h, w = image.shape
+        assert batch == 1 and image.dtype == torch.float32
+        nclass = self.nclass if label_set is None else len(label_set)
+        crop = self.crop_size
+        stride = int(crop * 2.0 / 3.0)
+        if self.module._up_kwargs != {"mode": "bilinear", "align_corners": True}:
+            raise ValueError("the device evaluator implements the reference's bilinear / align_corners=True resize")
+        pad = (C.c_float * 3)(*[float(v) for v in (-np.array(self.module.mean) / np.array(self.module.std))])
+        image = image.contiguous()
+        scores = image.new_zeros((1, nclass, h, w))
+        for scale in self.scales:
+            long_size = int(math.ceil(self.base_size * scale))
+            if h > w:
+                height, width = long_size, int(1.0 * w * long_size / h + 0.5)
+            else:
+                width, height = long_size, int(1.0 * h * long_size / w + 0.5)
+            cur = image.new_empty((ch, height, width))
+            _lib.check(lib.lseg_op_eval_resize(P(image), P(cur), ch, h, w, height, width, 0, st))
+            ph, pw = max(height, crop), max(width, crop)                       # pad_image: up to the crop size, never beyond
+            if long_size <= crop:
+                h_grids = w_grids = 1
+            else:
+                h_grids = int(math.ceil(1.0 * (ph - crop) / stride)) + 1
+                w_grids = int(math.ceil(1.0 * (pw - crop) / stride)) + 1
+            n = h_grids * w_grids
+            crops = image.new_empty(((2 if self.flip else 1) * n, ch, crop, crop))
+            _lib.check(lib.lseg_op_eval_make_crops(P(cur), P(crops), ch, height, width, crop, stride, h_grids, w_grids, int(self.flip), pad, st))
+            outs = self._module_eval(crops, label_set).contiguous()              # one batched pass per scale (chunks of max_batch)
+            assert outs.shape == (crops.shape[0], nclass, crop, crop) and outs.dtype == torch.float32
+            smap = image.new_empty((nclass, height, width))
+            _lib.check(lib.lseg_op_eval_accumulate(P(outs), P(smap), nclass, height, width, ph, pw, crop, stride, h_grids, w_grids,
+                                                   int(self.flip), st))
+            _lib.check(lib.lseg_op_eval_resize(P(smap), P(scores), nclass, height, width, h, w, 1, st))
+        return scores
+
     @torch.no_grad()
     def forward(self, image: torch.Tensor, label_set=None) -> torch.Tensor:
+        if image.is_cuda:
+            return self._forward_device(image, label_set)
         batch, _, h, w = image.shape
         assert batch == 1
         nclass = self.nclass if label_set is None else len(label_set)

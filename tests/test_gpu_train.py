@@ -229,6 +229,7 @@ def test_fused_sgd_matches_torch_sgd():
     bad = {k: v for k, v in report.items() if v[0] > max(1e-4, 20 * v[1])}
     assert not bad, bad
     # ... and the eval-only packs (BatchNorm folded into the convs, the commuted head) catch up at the next eval forward
+    eng.forward(x.cuda())              # the fresh engine ran one more train-mode forward: keep the running statistics in step
     eng.set_train(False); eng_b.set_train(False)
     assert torch.equal(eng.forward(x.cuda()), eng_b.forward(x.cuda()))
 
