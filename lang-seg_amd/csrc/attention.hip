@@ -104,15 +104,11 @@ __global__ __launch_bounds__(256, 3) void lseg_attention_kernel(const AttnArgs a
         const char* sv = sk + TILE;
 
         // ---- S^T[key][q] for 64 keys: 2 sub-tiles x 4 k-steps ---------------------------------
-        // the last tile of a 901-token sequence holds 5 keys: when its upper 32 keys are all padding (wave-uniform) that half of both
-        // products is skipped -- its scores would be masked to -inf and its probabilities are exactly 0
-        const bool half_tile = !a.causal && t * 64 + 32 >= a.ntok;
         f32x16_t s[2];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
-            if (sub == 1 && half_tile) continue;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const i32x4_t kf = *reinterpret_cast<const i32x4_t*>(sk + tile_off(sub * 32 + ql, ks * 2 + hi));
@@ -186,14 +182,12 @@ __global__ __launch_bounds__(256, 3) void lseg_attention_kernel(const AttnArgs a
         for (int d = 0; d < 2; ++d) {
             const int row = d * 32 + ql;
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-                if (sub == 1 && half_tile) continue;          // P = 0 on the padding keys: nothing to add
+            for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const i32x4_t vf = *reinterpret_cast<const i32x4_t*>(sv + tile_off(row, sub * 4 + s2 * 2 + hi));
                     o[d] = mfma32<T>(vf, pf[sub][s2], o[d]);
                 }
-            }
         }
     }
 
