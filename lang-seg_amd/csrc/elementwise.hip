@@ -1145,8 +1145,30 @@ __global__ void bn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __rest
                                 float eps, int dtype, float inv_n, const uint16_t* __restrict__ res1, const uint16_t* __restrict__ res2) {
     const int c8n = C >> 3;
     const size_t n = (size_t)B * H * W * c8n;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    // the grid stride is a multiple of C/8 for the power-of-two widths of the DPT head: a thread keeps ONE group of 8 channels, whose
+    // mean / rstd / affine parameters are loaded (two float4 per array) and computed once, outside the pixel loop
+    const bool fixed_c = ((size_t)gridDim.x * blockDim.x) % c8n == 0;
+    float mean[8], rs[8], ga[8], be[8];
+    auto load_c = [&](int c0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 s1 = *reinterpret_cast<const float4*>(stats + c0 + 4 * h), s2 = *reinterpret_cast<const float4*>(stats + C + c0 + 4 * h);
+            const float4 g4 = *reinterpret_cast<const float4*>(gamma + c0 + 4 * h), b4 = *reinterpret_cast<const float4*>(beta + c0 + 4 * h);
+            const float a1[4] = {s1.x, s1.y, s1.z, s1.w}, a2[4] = {s2.x, s2.y, s2.z, s2.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float m = a1[k] * inv_n;
+                mean[4 * h + k] = m;
+                rs[4 * h + k] = rsqrtf(fmaxf(a2[k] * inv_n - m * m, 0.f) + eps);
+                ga[4 * h + k] = gg[k]; be[4 * h + k] = bb[k];
+            }
+        }
+    };
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (fixed_c && i < n) load_c((int)(i % c8n) * 8);
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int c0 = (int)(i % c8n) * 8;
+        if (!fixed_c) load_c(c0);
         size_t p = i / c8n;
         const int xx = (int)(p % W); p /= W;
         const int yy = (int)(p % H);
@@ -1160,10 +1182,7 @@ __global__ void bn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __rest
         float v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int c = c0 + k;
-            const float mean = stats[c] * inv_n;
-            const float var = fmaxf(stats[C + c] * inv_n - mean * mean, 0.f);
-            v[k] = gamma[c] * (load_as_f32(ex, k, dtype) - mean) * rsqrtf(var + eps) + beta[c];
+            v[k] = ga[k] * (load_as_f32(ex, k, dtype) - mean[k]) * rs[k] + be[k];
             if (res1) v[k] += load_as_f32(e1, k, dtype);
             if (res2) v[k] += load_as_f32(e2, k, dtype);
         }
@@ -1177,8 +1196,30 @@ __global__ void bn_bwd_apply_kernel(const uint16_t* __restrict__ dy, const uint1
                                     int B, int H, int W, int C, float eps, int dtype, float inv_n) {
     const int c8n = C >> 3;
     const size_t n = (size_t)B * H * W * c8n;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const bool fixed_c = ((size_t)gridDim.x * blockDim.x) % c8n == 0;      // see bn_apply_kernel
+    float mean[8], rs[8], gr[8], mg[8], mq[8];
+    auto load_c = [&](int c0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 s1 = *reinterpret_cast<const float4*>(stats + c0 + 4 * h), s2 = *reinterpret_cast<const float4*>(stats + C + c0 + 4 * h);
+            const float4 t1 = *reinterpret_cast<const float4*>(bstats + c0 + 4 * h), t2 = *reinterpret_cast<const float4*>(bstats + C + c0 + 4 * h);
+            const float4 g4 = *reinterpret_cast<const float4*>(gamma + c0 + 4 * h);
+            const float a1[4] = {s1.x, s1.y, s1.z, s1.w}, a2[4] = {s2.x, s2.y, s2.z, s2.w}, b1[4] = {t1.x, t1.y, t1.z, t1.w},
+                        b2[4] = {t2.x, t2.y, t2.z, t2.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float m = a1[k] * inv_n;
+                const float r = rsqrtf(fmaxf(a2[k] * inv_n - m * m, 0.f) + eps);
+                mean[4 * h + k] = m; rs[4 * h + k] = r; gr[4 * h + k] = gg[k] * r;
+                mg[4 * h + k] = b1[k] * inv_n; mq[4 * h + k] = b2[k] * inv_n;
+            }
+        }
+    };
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    if (fixed_c && i < n) load_c((int)(i % c8n) * 8);
+    for (; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int c0 = (int)(i % c8n) * 8;
+        if (!fixed_c) load_c(c0);
         size_t p = i / c8n;
         const int xx = (int)(p % W); p /= W;
         const int yy = (int)(p % H);
@@ -1189,11 +1230,8 @@ __global__ void bn_bwd_apply_kernel(const uint16_t* __restrict__ dy, const uint1
         float v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int c = c0 + k;
-            const float mean = stats[c] * inv_n;
-            const float rstd = rsqrtf(fmaxf(stats[C + c] * inv_n - mean * mean, 0.f) + eps);
-            const float xh = (load_as_f32(ex, k, dtype) - mean) * rstd;
-            v[k] = gamma[c] * rstd * (load_as_f32(eg, k, dtype) - bstats[c] * inv_n - xh * bstats[C + c] * inv_n);
+            const float xh = (load_as_f32(ex, k, dtype) - mean[k]) * rs[k];
+            v[k] = gr[k] * (load_as_f32(eg, k, dtype) - mg[k] - xh * mq[k]);
         }
         *reinterpret_cast<uint4*>(dx + off) = make_uint4(pack2_dt(v[0], v[1], dtype), pack2_dt(v[2], v[3], dtype),
                                                          pack2_dt(v[4], v[5], dtype), pack2_dt(v[6], v[7], dtype));
@@ -1788,6 +1826,12 @@ __global__ __launch_bounds__(256) void sgd_multi_kernel(const SgdSeg* __restrict
     }
 }
 
+// many small buffers zeroed in one launch (the atomically accumulated sums of a step: bias gradients, BatchNorm batch sums)
+__global__ __launch_bounds__(256) void zero_multi_kernel(const ZeroJob* __restrict__ jobs, int njobs) {
+    const ZeroJob j = jobs[blockIdx.x];
+    for (unsigned i = threadIdx.x; i < j.n; i += 256) j.p[i] = 0.f;
+}
+
 inline int grid_for(size_t total, int block = 256) {
     size_t g = (total + block - 1) / block;
     if (g > 256 * 16) g = 256 * 16;      // cap + grid-stride (cdna guide G11)
@@ -2016,9 +2060,9 @@ static int colstats_rows(int R, int C) {
     rpb = (rpb + 7) / 8 * 8;
     return rpb < 32 ? 32 : rpb;
 }
-int launch_bn_stats(const void* x, float* stats, int B, int H, int W, int C, int dtype, hipStream_t st) {
+int launch_bn_stats(const void* x, float* stats, int B, int H, int W, int C, int dtype, hipStream_t st, int pre_zeroed) {
     const int Mp = B * (H + 2) * (W + 2), rpb = colstats_rows(Mp, C);
-    LSEG_HIP_TRY(hipMemsetAsync(stats, 0, (size_t)2 * C * sizeof(float), st));
+    if (!pre_zeroed) LSEG_HIP_TRY(hipMemsetAsync(stats, 0, (size_t)2 * C * sizeof(float), st));
     hipLaunchKernelGGL(colstats16_kernel<1>, dim3((C + 255) / 256, (Mp + rpb - 1) / rpb), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)nullptr,
                        (const float*)nullptr, 0.f, 0.f, dtype, stats, Mp, C, C, rpb);
     CHECK_LAUNCH();
@@ -2266,6 +2310,13 @@ int launch_upsample4x_planes_scaled(const float* in_padded, const float* scale, 
     const int bands = (2 * H + UPS_LB - 1) / UPS_LB;
     const size_t lds = ((size_t)(UPS_LB / 2 + 4) * W + (size_t)(UPS_LB + 1) * 2 * W) * sizeof(float);
     hipLaunchKernelGGL(upsample4x_planes_scaled_kernel, dim3((unsigned)P * bands), dim3(256), lds, st, in_padded, scale, out, P, K, H, W);
+    CHECK_LAUNCH();
+    return 0;
+}
+
+int launch_zero_multi(const ZeroJob* dev_jobs, int njobs, hipStream_t st) {
+    if (njobs < 1) return 0;
+    hipLaunchKernelGGL(zero_multi_kernel, dim3(njobs), dim3(256), 0, st, dev_jobs, njobs);
     CHECK_LAUNCH();
     return 0;
 }

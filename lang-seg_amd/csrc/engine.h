@@ -206,6 +206,14 @@ private:
     float* mom_flat_ = nullptr; size_t mom_flat_n_ = 0;
     TransposeJob* wt_table_ = nullptr; int wt_n_ = 0; unsigned wt_blocks_ = 0;
     int build_sgd_table();
+    // small buffers that are accumulated into with atomics, zeroed by ONE launch per pass once their list is known (recorded during the
+    // first pass, which still uses one memset each): [0] the forward's BatchNorm batch sums, [1] the backward's bias gradients
+    struct ZeroSet { std::vector<ZeroJob> host; ZeroJob* dev = nullptr; int n = 0; bool ready = false; };
+    ZeroSet zero_fwd_, zero_bwd_;
+    bool zero_note(ZeroSet& z, float* p, size_t n);       // true: the buffer was zeroed by this pass's launch_zero_multi
+    int zero_begin(ZeroSet& z, hipStream_t st);
+    int zero_end(ZeroSet& z);
+    int bias_sum(const uint16_t* dy, float* db, int R, int C, int ld, int acc, hipStream_t st);
 
     // ---- side stream: the (small, latency-bound) text tower overlaps the image tower ----------------
     hipStream_t text_stream_ = nullptr;

@@ -88,7 +88,7 @@ int launch_attention_backward_qkv(const void* q, const void* k, const void* vt, 
 // ---- engine-level training step (train.hip) --------------------------------------------------------------------------------
 int launch_attention_lse(const void* q, const void* k, const void* vt, void* out, float* lse2, int B, int H, int ntok, int npad, int dtype,
                          int causal, float scale, hipStream_t stream);
-int launch_bn_stats(const void* x, float* stats, int B, int H, int W, int C, int dtype, hipStream_t st);
+int launch_bn_stats(const void* x, float* stats, int B, int H, int W, int C, int dtype, hipStream_t st, int pre_zeroed = 0);
 int launch_bn_apply(const void* x, void* y, const float* stats, const float* gamma, const float* beta, const void* res1, const void* res2,
                     int B, int H, int W, int C, float eps, double count, int dtype, hipStream_t st);
 int launch_bn_bwd_stats(const void* dy, const void* x, const float* stats, float* bstats, int B, int H, int W, int C, float eps,
@@ -117,6 +117,8 @@ struct SgdSeg {
     int scratch;                             // learning-rate group: 0 = pretrained.*, 1 = scratch.*  (lsegmentation_module.py:119-127)
     int vec;                                 // every pointer 16-byte aligned (w16: 8) -> float4 path
 };
+struct ZeroJob { float* p; unsigned n; };      // one block per job
+int launch_zero_multi(const ZeroJob* dev_jobs, int njobs, hipStream_t st);
 struct TransposeJob { const uint16_t* src; uint16_t* dst; int R, C; unsigned blk0; int tiles_r; };   // dst [C, R] = src [R, C]^T, R and C multiples of 8
 int launch_sgd_multi(const SgdSeg* dev_segs, int nseg, unsigned blocks, float lr_pre, float lr_scr, float mu, float wd, int first, int dtype,
                      hipStream_t st);

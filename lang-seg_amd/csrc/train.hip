@@ -72,6 +72,7 @@ int Engine::bind_grad(const char* key, float* p) {
     GradSlot& s = grads_[key];
     s.ptr = p; s.n = it->second.numel(); s.bound = true;
     sgd_dirty_ = true;
+    zero_bwd_.ready = false; zero_bwd_.host.clear();
     return 0;
 }
 
@@ -88,6 +89,32 @@ int Engine::grad_ptr(const char* key, float** out, size_t* n) {
     if (out) *out = it->second.ptr;
     if (n) *n = it->second.n;
     return 0;
+}
+
+// ---- one-launch zeroing of the atomically accumulated buffers ---------------------------------------------------------------------
+bool Engine::zero_note(ZeroSet& z, float* p, size_t n) {
+    if (z.ready) return true;
+    ZeroJob j; j.p = p; j.n = (unsigned)n;
+    z.host.push_back(j);
+    return false;
+}
+int Engine::zero_begin(ZeroSet& z, hipStream_t st) {
+    if (!z.ready) { z.host.clear(); return 0; }
+    return launch_zero_multi(z.dev, z.n, st);
+}
+int Engine::zero_end(ZeroSet& z) {
+    if (z.ready || z.host.empty()) return 0;
+    z.dev = (ZeroJob*)dalloc(z.host.size() * sizeof(ZeroJob));
+    if (!z.dev) return set_error(LSEG_ERR_HIP, "out of device memory (zero table)");
+    LSEG_HIP_TRY(hipMemcpy(z.dev, z.host.data(), z.host.size() * sizeof(ZeroJob), hipMemcpyHostToDevice));
+    z.n = (int)z.host.size();
+    z.ready = true;
+    return 0;
+}
+// db[c] (+)= column sums of dy: the bias gradient of a Linear / 1x1 conv
+int Engine::bias_sum(const uint16_t* dy, float* db, int R, int C, int ld, int acc, hipStream_t st) {
+    if (acc) return launch_colsum16(dy, img_dt_, db, R, C, ld, st, 1);
+    return launch_colsum16(dy, img_dt_, db, R, C, ld, st, zero_note(zero_bwd_, db, (size_t)C) ? 1 : 0);
 }
 
 // ---- workspace of the training step (sized for cfg.max_batch images) -------------------------------------------------------
@@ -234,11 +261,11 @@ int Engine::rcu_train(const uint16_t* in, Rcu& U, const uint16_t* res2, uint16_t
     Lin c1 = U.r1; c1.b = zeros_;
     Lin c2 = U.r2; c2.b = zeros_;
     TRY(conv3x3(in, c1, nullptr, nullptr, U.cv1, B, H, W, 1, 1, 0, st));
-    TRY(launch_bn_stats(U.cv1, U.st1, B, H, W, F, img_dt_, st));
+    TRY(launch_bn_stats(U.cv1, U.st1, B, H, W, F, img_dt_, st, zero_note(zero_fwd_, U.st1, (size_t)2 * F) ? 1 : 0));
     TRY(bn_sync(U.st1, 2 * F, st));
     TRY(launch_bn_apply(U.cv1, U.n1, U.st1, U.g1, U.be1, nullptr, nullptr, B, H, W, F, 1e-5f, cnt, img_dt_, st));
     TRY(conv3x3(U.n1, c2, nullptr, nullptr, U.cv2, B, H, W, 1, 1, 0, st));
-    TRY(launch_bn_stats(U.cv2, U.st2, B, H, W, F, img_dt_, st));
+    TRY(launch_bn_stats(U.cv2, U.st2, B, H, W, F, img_dt_, st, zero_note(zero_fwd_, U.st2, (size_t)2 * F) ? 1 : 0));
     TRY(bn_sync(U.st2, 2 * F, st));
     TRY(launch_bn_apply(U.cv2, out, U.st2, U.g2, U.be2, in, res2, B, H, W, F, 1e-5f, cnt, img_dt_, st));
     // running statistics live in the caller's tensors (momentum 0.1, unbiased variance: nn.BatchNorm2d / SyncBatchNorm)
@@ -266,6 +293,7 @@ int Engine::forward_train(const float* x_in, int B, float* logits, hipStream_t s
         TRY(encode_text(text_stream_));
         LSEG_HIP_TRY(hipEventRecord(ev_join_, text_stream_));
     }
+    TRY(zero_begin(zero_fwd_, st));
     TRY(launch_im2col_patch(x_in, patchA_, B, c.img_h, c.img_w, c.patch, img_dt_, st));
     GemmArgs g;
     gemm_args_init(g);
@@ -367,6 +395,7 @@ int Engine::forward_train(const float* x_in, int B, float* logits, hipStream_t s
     last_low_ = low_; last_kout_ = K_;
     train_B_ = B;
     train_fwd_valid_ = true;
+    TRY(zero_end(zero_fwd_));
     return 0;
 }
 
@@ -416,7 +445,7 @@ int Engine::lin_bwd(const uint16_t* dy, int M, int N, int K, const uint16_t* x, 
             TRY(launch_gemm(g, img_dt_, st));
         }
     }
-    if (db) TRY(launch_colsum16(dy, img_dt_, db, M, dw_rows > 0 ? dw_rows : N, N, st, acc));
+    if (db) TRY(bias_sum(dy, db, M, dw_rows > 0 ? dw_rows : N, N, acc, st));
     return 0;
 }
 
@@ -524,7 +553,7 @@ int Engine::reassemble_backward(int l, int B, int acc, hipStream_t st) {
         const int Ho = lh_[l], Wo = lw_[l];
         TRY(launch_dilate2(dL_[l], ddil_, B, Ho, Wo, gh_, gw_, Cp, st));
         TRY(conv_bwd(ddil_, v.tmp, 0, rsmp_[l], dtmp_, grad(a + "4.weight", (size_t)C * C * 9), B, gh_, gw_, Cp, Cp, C, C, acc, st));
-        TRY(launch_colsum16(dL_[l], img_dt_, grad(a + "4.bias", C), B * (Ho + 2) * (Wo + 2), C, Cp, st, acc));
+        TRY(bias_sum(dL_[l], grad(a + "4.bias", C), B * (Ho + 2) * (Wo + 2), C, Cp, acc, st));
         TRY(launch_unpad_rows(dtmp_, rowsB_, B, gh_, gw_, Cp, st));
         d_r1 = rowsB_;
     } else {
@@ -586,6 +615,7 @@ int Engine::backward(const float* dlogits, const int64_t* target, int ignore_ind
     const int B = train_B_, D = c.dim, F = c.features, M = B * ntok_, Mr = B * np_;
     const int h1 = 2 * lh_[0], w1 = 2 * lw_[0], hw1 = h1 * w1, Mp1 = B * hw1, Kp = (int)up64(K_);
     const float logit_scale = expf(logf(1.0f / 0.07f));
+    if (!acc) TRY(zero_begin(zero_bwd_, st));
     // ---- loss + x2 upsample^T: the correlation's dY rows ---------------------------------------------------------------------
     if (!dlogits) {      // CrossEntropyLoss(ignore_index) on output_conv(low): one pass for the loss and the per-pixel log-sum-exp, one for the rows
         TRY(launch_seg_stats_ex(low_, target, B, K_, 4 * hw1, ignore_index, counts_, nll_, nullptr, 1, h1, w1, st, lse_px_));
@@ -633,6 +663,7 @@ int Engine::backward(const float* dlogits, const int64_t* target, int ignore_ind
     }
     TRY(launch_pos_resize_bwd(dpos_, gpos, gcls, c.pos_grid, gh_, gw_, D, st));
     bucket_done(c.depth, st);
+    if (!acc) TRY(zero_end(zero_bwd_));
     return 0;
 }
 
