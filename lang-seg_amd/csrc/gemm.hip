@@ -380,6 +380,7 @@ enum Epi {
     EPI_QKV16 = 4,        // MAP_QKV, q,k -> [b,head,t,d], v -> [b,head,d,t]
     EPI_PAD16 = 5,        // MAP_PADDED NHWC (1-pixel zero border), T(act(acc + bias) [+ res [+ res2]]): the DPT head's 3x3 convs
     EPI_LIN16_F16 = 6,    // MAP_LINEAR, C = fp16(acc + bias) from bf16 operands: the commuted head's g (the fp16 operand of the correlation)
+    EPI_PIX16 = 7,        // MAP_PIXSHUF, T(acc + bias[n % C]): ConvTranspose2d(k = s) as a GEMM whose columns scatter to the s x s sub-pixels
 };
 
 // two adjacent 16-column sub-tiles (4 columns per lane each) -> 8 contiguous columns (16 bytes) per lane
@@ -508,6 +509,29 @@ __device__ __forceinline__ void fast_epilogue(const GemmArgs& g, f32x4_t (&acc)[
                         *reinterpret_cast<uint4*>((uint16_t*)g.C_relu + r0 + cw + i * 16) = make_uint4(rl(o.x), rl(o.y), rl(o.z), rl(o.w));
                     }
                 }
+            });
+        });
+    } else if constexpr (EPI == EPI_PIX16) {
+        // m = (b, y, x) on the (ho, wo) grid -> pixel (y*s + i, x*s + j) of the padded [B, ho*s + 2, wo*s + 2, C] map for column
+        // n = (i*s + j)*C + co; a 32-column pair lies inside one (i, j) group (C % 32 == 0): 16-byte stores of 8 channels
+        const int hw = g.ho * g.wo, Hd = g.ho * g.ps_s + 2, Wd = g.wo * g.ps_s + 2;
+        static_for<0, MI>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int m = mrow0 + j * 16 + ml;
+            const int mm = m < g.M ? m : g.M - 1;
+            const int b = mm / hw, p = mm - b * hw;
+            const int y = p / g.wo, x = p - y * g.wo;
+            const size_t r0 = ((size_t)(b * Hd + y * g.ps_s + 1) * Wd + x * g.ps_s + 1) * g.ps_C;
+            static_for<0, NI / 2>([&](auto pc) {
+                constexpr int i = 2 * decltype(pc)::value;
+                const int c0 = ncol0 + i * 16;
+                const int ij = c0 / g.ps_C, co = c0 - ij * g.ps_C;
+                const int si = ij / g.ps_s, sj = ij - si * g.ps_s;
+                float xx[4], yy[4];
+                biased(std::integral_constant<int, i>{}, jc, xx);
+                biased(std::integral_constant<int, i + 1>{}, jc, yy);
+                const uint4 o = widen16<T>(xx, yy);
+                if (m < g.M) *reinterpret_cast<uint4*>((uint16_t*)g.C + r0 + ((size_t)si * Wd + sj) * g.ps_C + co + cw) = o;
             });
         });
     } else if constexpr (EPI == EPI_QKV16) {
@@ -881,7 +905,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
             if constexpr (EPI != EPI_GENERIC && BIAS_PREFETCH) {
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
-                    biasv[i] = *reinterpret_cast<const float4*>(g.bias + pn0 + wn * WN + i * 16 + (lane >> 4) * 4);
+                    biasv[i] = *reinterpret_cast<const float4*>(g.bias + (EPI == EPI_PIX16 ? (pn0 + wn * WN + i * 16) % g.ps_C : pn0 + wn * WN + i * 16) + (lane >> 4) * 4);
             }
         }
 #pragma unroll
@@ -949,7 +973,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
             if constexpr (!BIAS_PREFETCH) {       // 128-accumulator tiles have no registers to spare across the K-loop
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
-                    biasv[i] = *reinterpret_cast<const float4*>(g.bias + n0c + wn * WN + i * 16 + (lane >> 4) * 4);
+                    biasv[i] = *reinterpret_cast<const float4*>(g.bias + (EPI == EPI_PIX16 ? (n0c + wn * WN + i * 16) % g.ps_C : n0c + wn * WN + i * 16) + (lane >> 4) * 4);
             }
             fast_epilogue<T, EPI, MI, NI>(g, acc, m0c + wm * WM, n0c + wn * WN, lane, biasv);
         } else {
@@ -1048,7 +1072,11 @@ template <typename T>
 int select_epi(const GemmArgs& g) {
     constexpr int dt = std::is_same<T, BF16>::value ? DT_BF16 : DT_F16;
     static const bool off = getenv("LSEG_GEMM_GENERIC_EPI") != nullptr;       // A/B switch (tools)
-    if (off || g.split || g.nsplit > 1 || (g.dbg & 3) || !g.bias || g.bias_mod || g.round_mid || (g.N % 128) != 0) return EPI_GENERIC;
+    if (off || g.split || g.nsplit > 1 || (g.dbg & 3) || !g.bias || g.round_mid || (g.N % 128) != 0) return EPI_GENERIC;
+    if (g.map_mode == MAP_PIXSHUF && !g.conv && g.bias_mod == g.ps_C && (g.ps_C % 32) == 0 && g.N == g.ps_s * g.ps_s * g.ps_C && g.out_dtype == dt &&
+        g.res_mode == RES_NONE && g.act == ACT_NONE && !(reinterpret_cast<uintptr_t>(g.C) & 15) && !(reinterpret_cast<uintptr_t>(g.bias) & 15))
+        return EPI_PIX16;
+    if (g.bias_mod) return EPI_GENERIC;
     if (g.res2 && !(g.dbg & 4) && g.map_mode != MAP_PADDED) return EPI_GENERIC;
     if ((reinterpret_cast<uintptr_t>(g.C) & 15) || (reinterpret_cast<uintptr_t>(g.bias) & 15)) return EPI_GENERIC;
     if (g.map_mode == MAP_PADDED && g.out_dtype == dt && (g.ldc % 8) == 0 && (g.act == ACT_NONE || g.act == ACT_RELU) &&
@@ -1100,6 +1128,7 @@ int dispatch(const GemmArgs& g, hipStream_t stream) {
             return pick_tile<T, false, false, EPI_LIN16_GELU, 0>(g, stream);
         case EPI_RES32: return pick_tile<T, false, false, EPI_RES32, 0>(g, stream);
         case EPI_LIN16_F16: return pick_tile<T, false, false, EPI_LIN16_F16, 0>(g, stream);
+        case EPI_PIX16: return pick_tile<T, false, false, EPI_PIX16, 0>(g, stream);
         case EPI_QKV16: return pick_tile<T, false, false, EPI_QKV16, 0>(g, stream);
         default: return pick_tile<T, false, false, EPI_GENERIC, 0>(g, stream);
     }
