@@ -20,6 +20,24 @@ import torch
 import torch.nn.functional as F
 
 
+def scale_geometry(h: int, w: int, scale: float, base_size: int, crop_size: int):
+    """Sizes of one scale of MultiEvalModule.forward (encoding_models.py:66-99): the resized image (height, width), the padded image
+    the sliding window runs over (ph, pw), the crop grid (h_grids, w_grids) and the stride.  One crop when the long side fits."""
+    stride = int(crop_size * 2.0 / 3.0)
+    long_size = int(math.ceil(base_size * scale))
+    if h > w:
+        height, width = long_size, int(1.0 * w * long_size / h + 0.5)
+    else:
+        width, height = long_size, int(1.0 * h * long_size / w + 0.5)
+    ph, pw = max(height, crop_size), max(width, crop_size)            # pad_image pads up to the crop size, never beyond
+    if long_size <= crop_size:
+        h_grids = w_grids = 1
+    else:
+        h_grids = int(math.ceil(1.0 * (ph - crop_size) / stride)) + 1
+        w_grids = int(math.ceil(1.0 * (pw - crop_size) / stride)) + 1
+    return height, width, ph, pw, h_grids, w_grids, stride
+
+
 def _pad_image(img, mean, std, crop_size):          # encoding_models.py:144-155
     b, c, h, w = img.shape
     padh = crop_size - h if h < crop_size else 0
@@ -85,26 +103,15 @@ class BatchedMultiEval(torch.nn.Module):
         assert batch == 1 and image.dtype == torch.float32
         nclass = self.nclass if label_set is None else len(label_set)
         crop = self.crop_size
-        stride = int(crop * 2.0 / 3.0)
         if self.module._up_kwargs != {"mode": "bilinear", "align_corners": True}:
             raise ValueError("the device evaluator implements the reference's bilinear / align_corners=True resize")
         pad = (C.c_float * 3)(*[float(v) for v in (-np.array(self.module.mean) / np.array(self.module.std))])
         image = image.contiguous()
         scores = image.new_zeros((1, nclass, h, w))
         for scale in self.scales:
-            long_size = int(math.ceil(self.base_size * scale))
-            if h > w:
-                height, width = long_size, int(1.0 * w * long_size / h + 0.5)
-            else:
-                width, height = long_size, int(1.0 * h * long_size / w + 0.5)
+            height, width, ph, pw, h_grids, w_grids, stride = scale_geometry(h, w, scale, self.base_size, crop)
             cur = image.new_empty((ch, height, width))
             _lib.check(lib.lseg_op_eval_resize(P(image), P(cur), ch, h, w, height, width, 0, st))
-            ph, pw = max(height, crop), max(width, crop)                       # pad_image: up to the crop size, never beyond
-            if long_size <= crop:
-                h_grids = w_grids = 1
-            else:
-                h_grids = int(math.ceil(1.0 * (ph - crop) / stride)) + 1
-                w_grids = int(math.ceil(1.0 * (pw - crop) / stride)) + 1
             n = h_grids * w_grids
             crops = image.new_empty(((2 if self.flip else 1) * n, ch, crop, crop))
             _lib.check(lib.lseg_op_eval_make_crops(P(cur), P(crops), ch, height, width, crop, stride, h_grids, w_grids, int(self.flip), pad, st))
@@ -124,19 +131,11 @@ class BatchedMultiEval(torch.nn.Module):
         assert batch == 1
         nclass = self.nclass if label_set is None else len(label_set)
         crop_size = self.crop_size
-        stride = int(crop_size * 2.0 / 3.0)
         up = self.module._up_kwargs
         scores = image.new_zeros((batch, nclass, h, w))
         for scale in self.scales:
-            long_size = int(math.ceil(self.base_size * scale))
-            if h > w:
-                height = long_size
-                width = int(1.0 * w * long_size / h + 0.5)
-                short_size = width
-            else:
-                width = long_size
-                height = int(1.0 * h * long_size / w + 0.5)
-                short_size = height
+            height, width, gph, gpw, h_grids, w_grids, stride = scale_geometry(h, w, scale, self.base_size, crop_size)
+            long_size, short_size = max(height, width), min(height, width)
             cur_img = F.interpolate(image, (height, width), **up)
             if long_size <= crop_size:
                 pad_img = _pad_image(cur_img, self.module.mean, self.module.std, crop_size)
@@ -145,8 +144,7 @@ class BatchedMultiEval(torch.nn.Module):
                 pad_img = _pad_image(cur_img, self.module.mean, self.module.std, crop_size) \
                     if short_size < crop_size else cur_img
                 _, _, ph, pw = pad_img.shape
-                h_grids = int(math.ceil(1.0 * (ph - crop_size) / stride)) + 1
-                w_grids = int(math.ceil(1.0 * (pw - crop_size) / stride)) + 1
+                assert (ph, pw) == (gph, gpw)
                 boxes, crops = [], []
                 for idh in range(h_grids):
                     for idw in range(w_grids):
