@@ -4,7 +4,7 @@
 // laid out like the reference's parameters, per-bucket "gradients enqueued" notifications for the RCCL all-reduce, fused SGD.
 //
 // What the reference's autograd would traverse and what runs here:
-//   output_conv x2 bilinear, CrossEntropyLoss(ignore_index)      seg_stats + softmax_ce_backward + upsample2x_planes_backward_rows
+//   output_conv x2 bilinear, CrossEntropyLoss(ignore_index)      seg_stats (through the bilinear) + upsample_ce_bwd_rows on the low-res logits
 //   fp16 correlation, L2-norm, head1 (lseg_net.py:185-196)       two GEMMs + l2norm_scale_backward (fp16 roundings = identity)
 //   4 x FeatureFusionBlock_custom (lseg_blocks.py:337-358)       out_conv GEMMs, x2 upsample transpose, RCU: conv dgrad = forward
 //     with ResidualConvUnit_custom in train() mode (:265-288)    conv on flipped weights, wgrad = one GEMM on transposed operands,
