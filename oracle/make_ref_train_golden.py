@@ -7,7 +7,8 @@ criterion = CrossEntropyLoss(ignore_index), [3P] encoding SegmentationLosses wit
 back-propagated with torch autograd, and for every parameter the gradient's L2 norm, sum and first 16 elements are stored
 (the full gradients are 1.2 GB).  Pins oracle.lseg_oracle.training_step, the oracle the backward kernels will be held to.
 
-    python oracle/make_ref_train_golden.py
+    python oracle/make_ref_train_golden.py            # the small cases (seconds)
+    python oracle/make_ref_train_golden.py --full     # BASELINE configs[3] at its own shape: 480x480, ViT-L/16, K=150 (minutes, ~20 GB)
 """
 import os
 import sys
@@ -26,6 +27,21 @@ TRAIN_CASES = {
     "ref_train_vitl16_64x64_k5_b2": ("clip_vitl16_384", 64, 64, 2, 5, 21),
     "ref_train_vitb32_128x128_k4_b2": ("clip_vitb32_384", 128, 128, 2, 4, 22),
 }
+
+
+# BASELINE.json configs[3] (train_lseg.py fine-tune: ViT-L/16, 480x480 crops, 150 ADE20K labels) through the reference's own
+# network + autograd at its own shape; B=1 and a B=2 case (train-mode BatchNorm statistics over more than one image).
+TRAIN_FULL_CASES = {
+    "ref_train_full_vitl16_480x480_k150_b1": ("clip_vitl16_384", 480, 480, 1, 150, 31),
+    "ref_train_full_vitl16_480x480_k150_b2": ("clip_vitl16_384", 480, 480, 2, 150, 32),
+}
+N_SAMPLE = 64                                     # evenly strided elements stored per gradient (next to norm, sum, first 16)
+
+
+def sample_index(numel, n=N_SAMPLE):
+    """The strided sample every consumer of the fixtures recomputes: n indices spread evenly over [0, numel)."""
+    n = min(n, numel)
+    return (torch.arange(n, dtype=torch.int64) * (numel - 1)) // max(n - 1, 1)
 
 
 def synthetic_target(B, H, W, K, seed):
@@ -56,10 +72,12 @@ def run_ref_train_case(spec):
 
 def main():
     gd = os.path.join(ROOT, "tests", "golden")
-    for name, spec in TRAIN_CASES.items():
+    cases = TRAIN_FULL_CASES if "--full" in sys.argv else TRAIN_CASES
+    for name, spec in cases.items():
         tokens, loss, grads, none = run_ref_train_case(spec)
-        summ = {n: {"norm": float(g.float().norm()), "sum": float(g.float().sum()), "dtype": str(g.dtype),
-                    "head": g.flatten()[:16].float().clone()} for n, g in grads.items()}
+        summ = {n: {"norm": float(g.float().norm()), "sum": float(g.double().sum()), "dtype": str(g.dtype),
+                    "head": g.flatten()[:16].float().clone(),
+                    "sample": g.flatten()[sample_index(g.numel())].float().clone()} for n, g in grads.items()}
         torch.save({"spec": spec, "tokens": tokens, "loss": float(loss), "grads": summ, "no_grad": none},
                    os.path.join(gd, name + ".pt"))
         print(name, "loss", float(loss), len(summ), "gradients;", len(none), "parameters without")

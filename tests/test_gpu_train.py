@@ -157,10 +157,20 @@ def test_training_step_loss_and_gradients_match_the_oracle(bb, H, W, B, K, seed)
     assert not torch.equal(sd_dev[k0].cpu(), sd[k0])
 
 
+def _sample_index(numel, n=64):                       # == oracle/make_ref_train_golden.sample_index
+    n = min(n, numel)
+    return (torch.arange(n, dtype=torch.int64) * (numel - 1)) // max(n - 1, 1)
+
+
 @pytest.mark.parametrize("name", TRAIN_REF)
 def test_training_step_matches_fixtures_made_by_reference_autograd(name):
+    """The engine's training step against loss + gradients of the REFERENCE'S OWN network under torch autograd
+    (oracle/make_ref_train_golden.py).  `ref_train_full_*` = BASELINE configs[3] at its own shape (ViT-L/16, 480x480, K = 150;
+    B = 1 and B = 2 for the train-mode BatchNorm statistics): loss, every gradient's norm, its sum, its first 16 and 64 evenly
+    strided elements.  Full-size bar: median gradient-norm error <= 2 %."""
     g = torch.load(os.path.join(GOLD, name + ".pt"))
     bb, H, W, B, K, seed = g["spec"]
+    full = "_full_" in name
     cfg = get_config(bb)
     sd = synthetic_state_dict(cfg, seed=seed)
     x = synthetic_images(B, H, W, seed=seed)
@@ -168,19 +178,35 @@ def test_training_step_matches_fixtures_made_by_reference_autograd(name):
     assert abs(loss.item() - g["loss"]) <= 1e-2 * abs(g["loss"]), (loss.item(), g["loss"])
     names = {n for n in g["grads"] if not n.startswith("clip_pretrained.")}
     assert set(eng.grads) == names, sorted(set(eng.grads) ^ names)[:10]
-    nerr, herr = {}, {}
+    nerr, herr, serr, sumerr = {}, {}, {}, {}
     for n in sorted(names):
         r = g["grads"][n]
         mine = eng.grads[n].float().cpu()
+        rms = r["norm"] / max(1.0, mine.numel() ** 0.5)
         nerr[n] = abs(float(mine.norm()) - r["norm"]) / max(r["norm"], 1e-20)
-        scale = max(float(r["head"].abs().max()), r["norm"] / max(1.0, mine.numel() ** 0.5), 1e-20)
+        scale = max(float(r["head"].abs().max()), rms, 1e-20)
         herr[n] = (mine.flatten()[:16] - r["head"]).abs().max().item() / scale
+        if "sample" in r:
+            sscale = max(float(r["sample"].abs().max()), rms, 1e-20)
+            serr[n] = (mine.flatten()[_sample_index(mine.numel())] - r["sample"]).abs().max().item() / sscale
+            sumerr[n] = abs(float(mine.double().sum()) - r["sum"]) / max(r["norm"] * mine.numel() ** 0.5, 1e-20)
+    med = lambda d: sorted(d.values())[len(d) // 2]
     wn = sorted(nerr.items(), key=lambda kv: -kv[1])[:5]
     wh = sorted(herr.items(), key=lambda kv: -kv[1])[:5]
-    print(name, "loss", loss.item(), "vs", g["loss"], "; worst gradient-norm errors:", [(k, round(v, 4)) for k, v in wn],
-          "; median", round(sorted(nerr.values())[len(nerr) // 2], 4), "; worst first-16-elements errors:", [(k, round(v, 3)) for k, v in wh])
-    # measured: ViT-L/16 median norm error 0.6 %, worst 3.6 % (2x2-pixel refinenet4 maps of the 64x64 case); ViT-B/32 3.2 % / 6.4 %
-    assert wn[0][1] <= 0.10 and sorted(nerr.values())[len(nerr) // 2] <= 0.05 and wh[0][1] <= 1.0, (wn, wh)
+    ws = sorted(serr.items(), key=lambda kv: -kv[1])[:5]
+    line = (f"{name}: loss {loss.item():.5f} vs {g['loss']:.5f}; gradient-norm error median {med(nerr):.4f} worst "
+            f"{[(k, round(v, 4)) for k, v in wn[:3]]}; first-16 error median {med(herr):.3f} worst {wh[0][1]:.3f}; "
+            f"strided-64 error median {med(serr) if serr else -1:.3f} worst {ws[0][1] if ws else -1:.3f}; "
+            f"sum error worst {max(sumerr.values()) if sumerr else -1:.4f}")
+    print(line)
+    out_dir = os.path.join(os.path.dirname(GOLD), "..", "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "train_parity_table.txt"), "a") as f:
+            f.write(line + "\n")
+    # measured (small cases): ViT-L/16 median norm error 0.6 %, worst 3.6 % (2x2-pixel refinenet4 maps of the 64x64 case); ViT-B/32 3.2 % / 6.4 %
+    assert wn[0][1] <= 0.10 and med(nerr) <= (0.02 if full else 0.05) and wh[0][1] <= 1.0, (wn, wh)
+    if serr:
+        assert ws[0][1] <= 1.0 and max(sumerr.values()) <= 0.25, (ws, max(sumerr.values()))
 
 
 def test_fused_sgd_matches_torch_sgd():
