@@ -153,7 +153,10 @@ int lseg_set_debug(lseg_handle h, int enabled);
 
 /* ---- measurement -------------------------------------------------------------------
  * Per-kernel-family HIP-event timing on the engine's stream (bench.py roofline leg).
- * family names: "mlp_fc1" (the dominant GEMM), "forward". */
+ * family names, in mask-bit order: "forward" (bit 0), "mlp_fc1", "mlp_fc2", "attn_proj", "attn_qkv", "attention", "layernorm" (the
+ * ViT block's kernels: timm vision_transformer.py Block, invoked from lseg_vit.py:196-197).  lseg_set_profiling(h, 1) = forward +
+ * mlp_fc1; any other non-zero value is a bit mask over the families; 0 switches the events off.  Events for 64 forwards are created
+ * by the call, outside any timed region.  flops_per_launch = 2MNK of the family's GEMM (4 N^2 D per image for attention). */
 int lseg_set_profiling(lseg_handle h, int enabled);
 int lseg_get_profile(lseg_handle h, const char* family, double* total_ms, int64_t* launches,
                      double* flops_per_launch);
@@ -266,27 +269,16 @@ int lseg_op_upsample2x_nhwc_backward(const void* d_dout, void* d_din_pad, int B,
 int lseg_op_softmax_ce_backward(const float* d_scores, const int64_t* d_target, float* d_dscores, int B, int K, int H, int W,
                                 int ignore_index, const double* d_nll, void* stream);
 
-/* Backward of lseg_op_attention (softmax(Q K^T * scale) V, head_dim 64, no mask), flash-style recomputation; the
- * reference gets it from autograd through [3P] timm Attention.forward (lseg_vit.py:196-197).
- * d_q,d_k [BH,Npad,64], d_vt [BH,64,Npad], d_o / d_do [B,Ntok,H*64] (forward layouts, bf16/fp16);
- * d_lse2 [BH,Npad] fp32 = log2 of each query row's sum_k exp2(s_k * scale * log2e)  (the forward's running statistics);
- * outputs fp32 d_dq, d_dk, d_dv [BH,Npad,64] (rows >= Ntok of dk/dv are zero; dq is zeroed here, then accumulated). */
-int lseg_op_attention_backward(const void* d_q, const void* d_k, const void* d_vt, const void* d_o, const void* d_do,
-                               const float* d_lse2, float* d_dq, float* d_dk, float* d_dv, int B, int H, int Ntok, int Npad,
-                               int dtype, int causal, float scale, void* stream);
-
-/* The attention backward the training step runs (csrc/attention_bwd2.hip): same inputs, no mask, no atomics -- a dQ kernel and a
+/* Backward of lseg_op_attention (softmax(Q K^T * scale) V, head_dim 64, no mask); the reference gets it from autograd through
+ * [3P] timm Attention.forward (lseg_vit.py:196-197).  Flash-style recomputation (csrc/attention_bwd2.hip), no atomics:
+ * d_q,d_k [BH,Npad,64], d_vt [BH,64,Npad], d_o / d_do [B,Ntok,H*64] (forward layouts, bf16/fp16); d_lse2 [BH,Npad] fp32 = log2 of
+ * each query row's sum_k exp2(s_k * scale * log2e) (the forward's running statistics) -- a dQ kernel and a
  * dK/dV kernel in the forward kernel's MFMA / direct-to-LDS structure, writing d(qkv Linear output) [B*Ntok, 3*H*64] (bf16/fp16)
  * directly.  d_ws: lseg_op_attention_backward_ws_bytes(B, H, Npad) bytes of device scratch, or NULL (then allocated per call). */
 size_t lseg_op_attention_backward_ws_bytes(int B, int H, int Npad);
 int lseg_op_attention_backward_qkv(const void* d_q, const void* d_k, const void* d_vt, const void* d_o, const void* d_do,
                                    const float* d_lse2, void* d_dqkv, void* d_ws, int B, int H, int Ntok, int Npad, int dtype,
                                    float scale, void* stream);
-
-/* d(qkv Linear output) [B*Ntok, 3*H*64] (bf16/fp16) from the attention backward's fp32 d_dq, d_dk, d_dv [BH,Npad,64]:
- * the inverse of the QKV GEMM epilogue's head-major scatter; feeds lseg_op_linear_backward of the qkv layer. */
-int lseg_op_qkv_grad_pack(const float* d_dq, const float* d_dk, const float* d_dv, void* d_dqkv, int B, int H, int Ntok, int Npad,
-                          int out_dtype, void* stream);
 
 /* Train-mode BatchNorm2d on the padded-NHWC bf16 maps (ResidualConvUnit_custom bn1/bn2 under net.train(),
  * lseg_blocks.py:276-283; the reference runs SyncBatchNorm, i.e. d_stats / the backward sums are what a multi-GPU step
@@ -334,6 +326,12 @@ int lseg_op_upsample_ce_backward_rows(const float* d_low, const int64_t* d_targe
  *                          dev_target int64 [B,H,W] (then the loss is the mean CE over pixels != ignore_index and dev_loss, if not
  *                          NULL, receives double[2] = {sum of -log p[target], number of valid pixels}).  accumulate != 0 adds to the
  *                          gradient buffers (accumulate_grad_batches), 0 overwrites them.
+ *   lseg_train_loss        the criterion's VALUE on the last train-mode forward (`loss = self.criterion(out, target)`, :72) without the
+ *                          backward: dev_loss double[2] as above, dev_counts (or NULL) int64[2] = {correct, labeled} of the arg-max
+ *                          mask on the valid pixels (`train_accuracy`, :76-79).  A following lseg_backward / lseg_backward_scaled on
+ *                          the same target reuses its per-pixel log-sum-exp.
+ *   lseg_backward_scaled   lseg_backward(target) whose d(logits) is multiplied by *dev_grad_scale (a float in device memory, read by
+ *                          the kernel: no host synchronisation) -- the d(loss) autograd hands to `loss.backward()` (:81 via Lightning).
  *   lseg_grad_bucket       gradients complete in buckets: 0 = DPT head + reassemble, 1+j = ViT block depth-1-j (+ the readout hooked
  *                          on it), the last one also patch_embed / cls_token / pos_embed.  The bucket callback fires on the host right
  *                          after the last kernel of a bucket has been ENQUEUED on `stream` (record an event there and launch the
@@ -342,7 +340,10 @@ int lseg_op_upsample_ce_backward_rows(const float* d_low, const int64_t* d_targe
  *                          `stream`; called for the 2C batch sums of every BatchNorm (forward) and the 2C gradient sums (backward).
  *                          world_size = number of ranks (divides the sums).  NULL / 1 = per-GPU statistics.
  *   lseg_sgd_step          w -= lr * (mu * m + g + wd * w) on the bound fp32 parameters with the engine's momentum buffers, then
- *                          re-packs the MFMA operand copies. */
+ *                          re-packs the MFMA operand copies.
+ *   lseg_sgd_momentum      device pointer of a parameter's momentum buffer (torch.optim.SGD's state['momentum_buffer'], what
+ *                          Lightning checkpoints under 'optimizer_states'); lseg_sgd_mark_initialized(h, 1) after restoring them makes
+ *                          the next step a regular one (the first step of SGD copies the gradient into the buffer instead). */
 typedef void (*lseg_reduce_cb)(void* user, void* dev_ptr, int64_t n_floats, void* stream);
 typedef void (*lseg_bucket_cb)(void* user, int bucket, void* stream);
 int lseg_set_train(lseg_handle h, int enabled);
@@ -352,6 +353,10 @@ int lseg_grad_bucket(lseg_handle h, const char* key);          /* bucket index, 
 int lseg_num_grad_buckets(lseg_handle h);
 int lseg_backward(lseg_handle h, const float* dev_dlogits, const int64_t* dev_target, int ignore_index, int accumulate,
                   double* dev_loss, void* stream);
+int lseg_train_loss(lseg_handle h, const int64_t* dev_target, int ignore_index, double* dev_loss, int64_t* dev_counts, void* stream);
+int lseg_backward_scaled(lseg_handle h, const int64_t* dev_target, int ignore_index, int accumulate, const float* dev_grad_scale, void* stream);
+int lseg_sgd_momentum(lseg_handle h, const char* key, float** dev_out, size_t* n_elems);
+int lseg_sgd_mark_initialized(lseg_handle h, int initialized);
 int lseg_set_bn_sync(lseg_handle h, lseg_reduce_cb fn, void* user, int world_size);
 int lseg_set_bucket_callback(lseg_handle h, lseg_bucket_cb fn, void* user);
 int lseg_sgd_step(lseg_handle h, float lr_pretrained, float lr_scratch, float momentum, float weight_decay, void* stream);

@@ -102,8 +102,9 @@ int lseg_get_intermediate(lseg_handle h, const char* name, float* dev_out, size_
 
 int lseg_set_profiling(lseg_handle h, int enabled) {
     GUARD(h);
-    h->e->profiling = enabled != 0;
-    if (enabled) return h->e->reserve_events(2 * (h->e->cfg.depth + 1) * 64);     // events for 64 forwards, created outside any timed loop
+    // 1 = the whole forward + the MLP fc1 GEMM (rounds 1-2); otherwise a mask, bit f = family f in lseg_get_profile's order
+    h->e->prof_mask = enabled == 1 ? 3u : (unsigned)enabled;
+    if (enabled) return h->e->reserve_events(2 * h->e->events_per_forward() * 64);     // events for 64 forwards, created outside any timed loop
     return LSEG_OK;
 }
 int lseg_get_profile(lseg_handle h, const char* family, double* total_ms, int64_t* launches, double* flops) {
@@ -123,6 +124,16 @@ int lseg_backward(lseg_handle h, const float* dev_dlogits, const int64_t* dev_ta
     GUARD(h);
     return h->e->backward(dev_dlogits, dev_target, ignore_index, accumulate, dev_loss, (hipStream_t)stream);
 }
+int lseg_backward_scaled(lseg_handle h, const int64_t* dev_target, int ignore_index, int accumulate, const float* dev_grad_scale, void* stream) {
+    GUARD(h);
+    return h->e->backward(nullptr, dev_target, ignore_index, accumulate, nullptr, (hipStream_t)stream, dev_grad_scale);
+}
+int lseg_train_loss(lseg_handle h, const int64_t* dev_target, int ignore_index, double* dev_loss, int64_t* dev_counts, void* stream) {
+    GUARD(h);
+    return h->e->train_loss(dev_target, ignore_index, dev_loss, dev_counts, (hipStream_t)stream);
+}
+int lseg_sgd_momentum(lseg_handle h, const char* key, float** dev_out, size_t* n) { GUARD(h); return h->e->sgd_momentum(key, dev_out, n); }
+int lseg_sgd_mark_initialized(lseg_handle h, int initialized) { GUARD(h); return h->e->sgd_mark_initialized(initialized != 0); }
 int lseg_set_bn_sync(lseg_handle h, lseg_reduce_cb fn, void* user, int world_size) {
     GUARD(h);
     if (world_size < 1) return set_error(LSEG_ERR_INVALID, "world_size %d", world_size);
@@ -410,20 +421,6 @@ int lseg_op_softmax_ce_backward(const float* d_scores, const int64_t* d_target, 
     return launch_softmax_ce_backward(d_scores, d_target, d_dscores, B, K, H * W, ignore_index, d_nll, (hipStream_t)stream);
 }
 
-int lseg_op_attention_backward(const void* d_q, const void* d_k, const void* d_vt, const void* d_o, const void* d_do,
-                               const float* d_lse2, float* d_dq, float* d_dk, float* d_dv, int B, int H, int Ntok, int Npad,
-                               int dtype, int causal, float scale, void* stream) {
-    int r = require_device(); if (r) return r;
-    int dt;
-    if ((r = op_dt(dtype, &dt))) return r;
-    if (!d_q || !d_k || !d_vt || !d_o || !d_do || !d_lse2 || !d_dq || !d_dk || !d_dv)
-        return set_error(LSEG_ERR_INVALID, "attention_backward: NULL pointer");
-    if (B < 1 || H < 1 || Ntok < 1) return set_error(LSEG_ERR_INVALID, "attention_backward: bad shape");
-    if (hipMemsetAsync(d_dq, 0, (size_t)B * H * Npad * 64 * sizeof(float), (hipStream_t)stream) != hipSuccess)
-        return set_error(LSEG_ERR_HIP, "attention_backward: memset failed");
-    return launch_attention_backward(d_q, d_k, d_vt, d_o, d_do, d_lse2, d_dq, d_dk, d_dv, B, H, Ntok, Npad, dt, causal, scale, (hipStream_t)stream);
-}
-
 size_t lseg_op_attention_backward_ws_bytes(int B, int H, int Npad) { return attention_backward_ws_bytes(B, H, Npad); }
 
 int lseg_op_attention_backward_qkv(const void* d_q, const void* d_k, const void* d_vt, const void* d_o, const void* d_do,
@@ -441,15 +438,6 @@ int lseg_op_attention_backward_qkv(const void* d_q, const void* d_k, const void*
     r = launch_attention_backward_qkv(d_q, d_k, d_vt, d_o, d_do, d_lse2, d_dqkv, ws, B, H, Ntok, Npad, dt, scale, st);
     if (!d_ws) (void)hipFreeAsync(ws, st);
     return r;
-}
-
-int lseg_op_qkv_grad_pack(const float* d_dq, const float* d_dk, const float* d_dv, void* d_dqkv, int B, int H, int Ntok, int Npad,
-                          int out_dtype, void* stream) {
-    int r = require_device(); if (r) return r;
-    int dt;
-    if ((r = op_dt(out_dtype, &dt))) return r;
-    if (dt == DT_F32 || !d_dq || !d_dk || !d_dv || !d_dqkv) return set_error(LSEG_ERR_INVALID, "qkv_grad_pack: bf16/fp16 output, non-NULL pointers");
-    return launch_qkv_grad_pack(d_dq, d_dk, d_dv, d_dqkv, B, H, Ntok, Npad, dt, (hipStream_t)stream);
 }
 
 int lseg_op_bn_train_forward(const void* d_x_pad, void* d_y_pad, float* d_stats, const float* d_gamma, const float* d_beta,

@@ -1037,21 +1037,6 @@ __global__ void softmax_ce_backward_kernel(const float* __restrict__ scores, con
             out[(size_t)k * HW] = (__expf(col[(size_t)k * HW] - m) * inv_s - (k == t ? 1.f : 0.f)) * inv_n;
     }
 }
-// Gradient of the QKV projection's output from the attention backward's head-major fp32 tensors: the inverse of the
-// QKV GEMM epilogue's scatter (q,k,v [BH, Npad, 64] -> row m = (b, t), column which*D + head*64 + d), 16-bit out.
-__global__ void qkv_grad_pack_kernel(const float* __restrict__ dq, const float* __restrict__ dk, const float* __restrict__ dv,
-                                     uint16_t* __restrict__ out, int B, int H, int ntok, int npad, int dtype) {
-    const int D = H * 64;
-    const size_t n = (size_t)B * ntok * 3 * D;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int col = (int)(i % (3 * D));
-        const size_t m = i / (3 * D);
-        const int t = (int)(m % ntok), b = (int)(m / ntok);
-        const int which = col / D, rem = col - which * D, h = rem >> 6, d = rem & 63;
-        const float* src = which == 0 ? dq : (which == 1 ? dk : dv);
-        store_from_f32(out, i, dtype, src[(((size_t)b * H + h) * npad + t) * 64 + d]);
-    }
-}
 // ---- train-mode BatchNorm2d on the padded-NHWC maps (DPT ResidualConvUnit bn1/bn2, lseg_blocks.py:276-283, train()) ----
 // The maps carry a zero border, so per-channel sums over ALL padded positions equal the sums over the image; n = B*H*W.
 // Column statistics of 16-bit row-major matrices, 16 bytes per lane: a block = 32 column groups of 8 columns x 8 row lanes over
@@ -1317,7 +1302,7 @@ __global__ void upsample2x_planes_bwd_rows_kernel(const float* __restrict__ dout
 __global__ __launch_bounds__(256) void upsample_ce_bwd_rows_kernel(const float* __restrict__ low, const long long* __restrict__ target,
                                                                    const float* __restrict__ lse, const double* __restrict__ nll,
                                                                    uint16_t* __restrict__ rows, int B, int K, int H, int W, int ldk,
-                                                                   int ignore_index, int dtype) {
+                                                                   int ignore_index, int dtype, const float* __restrict__ gscale) {
     const int Ho = 2 * H, Wo = 2 * W;
     const size_t npix = (size_t)B * H * W;
     const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -1325,7 +1310,8 @@ __global__ __launch_bounds__(256) void upsample_ce_bwd_rows_kernel(const float* 
     const int x = (int)(i % W);
     const int y = (int)((i / W) % H);
     const int b = (int)(i / ((size_t)W * H));
-    const float inv_n = nll[1] > 0.0 ? (float)(1.0 / nll[1]) : 0.f;
+    // d(mean CE)/d(logit) carries 1 / (valid pixels); gscale = the incoming d(loss) of an autograd caller (loss.backward(): 1)
+    const float inv_n = (nll[1] > 0.0 ? (float)(1.0 / nll[1]) : 0.f) * (gscale ? *gscale : 1.f);
     const float ry = (float)(H - 1) / (float)(Ho - 1), rx = (float)(W - 1) / (float)(Wo - 1);
     // the 4 candidate rows / columns: weight onto (y, x), and where their own two taps sit inside the 3x3 neighbourhood
     float wy[4], ly[4], wx[4], lx[4];
@@ -2044,13 +2030,6 @@ int launch_softmax_ce_backward(const float* scores, const int64_t* target, float
     CHECK_LAUNCH();
     return 0;
 }
-int launch_qkv_grad_pack(const float* dq, const float* dk, const float* dv, void* out, int B, int H, int ntok, int npad, int dtype,
-                         hipStream_t st) {
-    hipLaunchKernelGGL(qkv_grad_pack_kernel, dim3(grid_for((size_t)B * ntok * 3 * H * 64)), dim3(256), 0, st, dq, dk, dv,
-                       (uint16_t*)out, B, H, ntok, npad, dtype);
-    CHECK_LAUNCH();
-    return 0;
-}
 // BatchNorm in train mode, split so that a SyncBatchNorm exchange (all-reduce of the [2C] sums) can sit between the two halves.
 // `count` = pixels behind the sums (B*H*W, times the world size after the exchange).
 // rows per block of the column-statistics kernels: ~1500 blocks over the chip, at least 32 rows (4 per row lane) per block
@@ -2138,12 +2117,12 @@ static bool x2_footprint_is_4(int H) {
     return true;
 }
 int launch_upsample_ce_backward_rows(const float* low, const int64_t* target, const float* lse, const double* nll, void* rows, int B, int K,
-                                     int H, int W, int ldk, int ignore_index, int dtype, hipStream_t st) {
+                                     int H, int W, int ldk, int ignore_index, int dtype, hipStream_t st, const float* gscale) {
     if (ldk < K || (ldk & 7)) return set_error(LSEG_ERR_INVALID, "fused CE backward: ldk=%d must be a multiple of 8 and >= K=%d", ldk, K);
     if (!x2_footprint_is_4(H) || !x2_footprint_is_4(W)) return set_error(LSEG_ERR_UNSUPPORTED, "fused CE backward: %dx%d map outside the 4-tap footprint", H, W);
     const size_t npix = (size_t)B * H * W;
     hipLaunchKernelGGL(upsample_ce_bwd_rows_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, st, low,
-                       reinterpret_cast<const long long*>(target), lse, nll, (uint16_t*)rows, B, K, H, W, ldk, ignore_index, dtype);
+                       reinterpret_cast<const long long*>(target), lse, nll, (uint16_t*)rows, B, K, H, W, ldk, ignore_index, dtype, gscale);
     CHECK_LAUNCH();
     return 0;
 }

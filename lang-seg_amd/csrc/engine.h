@@ -63,7 +63,11 @@ public:
     int set_train(bool on);
     int bind_grad(const char* key, float* dev_ptr);
     int grad_ptr(const char* key, float** out, size_t* n);
-    int backward(const float* dlogits, const int64_t* target, int ignore_index, int accumulate, double* dev_loss2, hipStream_t st);
+    int backward(const float* dlogits, const int64_t* target, int ignore_index, int accumulate, double* dev_loss2, hipStream_t st,
+                 const float* dev_grad_scale = nullptr);
+    int train_loss(const int64_t* target, int ignore_index, double* dev_loss2, int64_t* dev_counts2, hipStream_t st);
+    int sgd_momentum(const char* key, float** out, size_t* n);
+    int sgd_mark_initialized(bool on) { sgd_first_ = !on; return 0; }
     int sgd_step(float lr_pretrained, float lr_scratch, float momentum, float weight_decay, hipStream_t st);
     int n_buckets() const { return cfg.depth + 1; }
     int bucket_of(const std::string& key) const;
@@ -73,7 +77,7 @@ public:
 
     lseg_config cfg;
     int device;
-    bool text_cache = false, text_valid = false, profiling = false, debug = false;
+    bool text_cache = false, text_valid = false, debug = false;
     int group_k = 0;              // > 0: per-image label sets of this size (LSegNetZS), see lseg_set_text_grouping
     std::string err;
 
@@ -168,6 +172,7 @@ private:
 
     // ---- train mode (allocated by set_train(true)) ------------------------------------------------------------------------
     bool train_alloc_ = false, train_fwd_valid_ = false;
+    const int64_t* loss_target_ = nullptr; int loss_ignore_ = 0;      // train_loss() already ran seg_stats for this forward and this target
     int train_B_ = 0;
     std::vector<BlockSave> sv_;
     float* xlast_ = nullptr;               // output of the last block (= xin of a virtual block `depth`)
@@ -220,14 +225,19 @@ private:
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr, ev_text_done_ = nullptr;
     bool text_pending_ = false;
 
-    // ---- profiling ---------------------------------------------------------------------------------
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_fc1_, ev_fwd_;
-    std::vector<hipEvent_t> ev_pool_, ev_free_;
-    ProfileSlot prof_fc1_, prof_fwd_;
-    hipEvent_t get_event();
+    // ---- profiling: HIP-event pairs around kernel families on the caller's stream (lseg_set_profiling mask bit = family index) --------
 public:
+    enum ProfFamily { PF_FWD = 0, PF_FC1, PF_FC2, PF_PROJ, PF_QKV, PF_ATTN, PF_LN, PF_N };
+    unsigned prof_mask = 0;
     int reserve_events(int n);
+    int events_per_forward() const;
 private:
+    struct ProfFam { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; ProfileSlot slot; };
+    ProfFam pf_[PF_N];
+    std::vector<hipEvent_t> ev_pool_, ev_free_;
+    hipEvent_t get_event();
+    hipEvent_t prof_begin(int fam, hipStream_t st);
+    void prof_end(int fam, hipEvent_t e0, double flops, hipStream_t st);
 };
 
 }  // namespace lseg

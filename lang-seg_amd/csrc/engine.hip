@@ -567,19 +567,41 @@ int Engine::reserve_events(int n) {
     return 0;
 }
 
+hipEvent_t Engine::prof_begin(int fam, hipStream_t st) {
+    if (!((prof_mask >> fam) & 1u)) return nullptr;
+    hipEvent_t e = get_event();
+    if (e) (void)hipEventRecord(e, st);
+    return e;
+}
+
+void Engine::prof_end(int fam, hipEvent_t e0, double flops, hipStream_t st) {
+    if (!e0) return;
+    hipEvent_t e1 = get_event();
+    if (!e1) return;
+    (void)hipEventRecord(e1, st);
+    pf_[fam].ev.push_back({e0, e1});
+    pf_[fam].slot.flops = flops;
+}
+
+// event pairs one forward records under the current mask (sizing of the pre-created pool)
+int Engine::events_per_forward() const {
+    int n = 0;
+    const int per_block[PF_N] = {0, 1, 1, 1, 1, 1, 2};
+    for (int f = 0; f < PF_N; ++f)
+        if ((prof_mask >> f) & 1u) n += f == PF_FWD ? 1 : per_block[f] * cfg.depth;
+    return n;
+}
+
 int Engine::flush_events() {
-    auto drain = [&](std::vector<std::pair<hipEvent_t, hipEvent_t>>& v, ProfileSlot& s) -> int {
-        for (auto& p : v) {
+    for (int f = 0; f < PF_N; ++f) {
+        for (auto& p : pf_[f].ev) {
             LSEG_HIP_TRY(hipEventSynchronize(p.second));
             float ms = 0.f;
             LSEG_HIP_TRY(hipEventElapsedTime(&ms, p.first, p.second));
-            s.total_ms += ms; s.launches += 1;
+            pf_[f].slot.total_ms += ms; pf_[f].slot.launches += 1;
         }
-        v.clear();
-        return 0;
-    };
-    TRY(drain(ev_fc1_, prof_fc1_));
-    TRY(drain(ev_fwd_, prof_fwd_));
+        pf_[f].ev.clear();
+    }
     for (auto e : ev_pool_) ev_free_.push_back(e);       // recycled, not destroyed
     ev_pool_.clear();
     return 0;
@@ -587,10 +609,11 @@ int Engine::flush_events() {
 
 int Engine::get_profile(const char* family, double* ms, int64_t* launches, double* flops) {
     TRY(flush_events());
+    static const char* names[PF_N] = {"forward", "mlp_fc1", "mlp_fc2", "attn_proj", "attn_qkv", "attention", "layernorm"};
     ProfileSlot* s = nullptr;
-    if (!strcmp(family, "mlp_fc1")) s = &prof_fc1_;
-    else if (!strcmp(family, "forward")) s = &prof_fwd_;
-    else return set_error(LSEG_ERR_INVALID, "unknown profile family '%s'", family);
+    for (int f = 0; f < PF_N; ++f)
+        if (!strcmp(family, names[f])) s = &pf_[f].slot;
+    if (!s) return set_error(LSEG_ERR_INVALID, "unknown profile family '%s'", family);
     if (ms) *ms = s->total_ms;
     if (launches) *launches = s->launches;
     if (flops) *flops = s->flops;
@@ -612,8 +635,8 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
     const int D = c.dim, H = c.heads, F = c.features, M = B * ntok_;
     last_B_ = B;
     low_pending_ = false;
-    hipEvent_t fwd0 = nullptr, fwd1 = nullptr;
-    if (profiling) { fwd0 = get_event(); fwd1 = get_event(); if (fwd0) (void)hipEventRecord(fwd0, st); }
+    hipEvent_t fwd0 = prof_begin(PF_FWD, st);
+    const double ntok2 = (double)ntok_ * ntok_;
 
     // ---- text tower (lseg_net.py:181-183): re-run every call unless caching is on.  Its ~90 small
     // kernels are latency-bound, so they run on a side stream next to the image tower; fork/join
@@ -640,35 +663,46 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
     // ---- 24 x timm Block; hooks feed readout/reassemble/layer_rn immediately ------------------------------
     for (int i = 0; i < c.depth; ++i) {
         VitBlock& b = blocks_[i];
+        hipEvent_t pe = prof_begin(PF_LN, st);
         if (strict_) TRY(launch_ln_split(x_, b.g1, b.b1, ln_, pl(ln_), M, D, 1e-6f, st));
         else TRY(launch_layernorm(x_, DT_F32, b.g1, b.b1, ln_, img_dt_, M, D, 1e-6f, st));
+        prof_end(PF_LN, pe, 0.0, st);
         gemm_args_init(g);
         g.A = ln_; g.W = b.qkv.w; g.M = M; g.N = 3 * D; g.K = D; g.lda = D; g.ldw = D;
         g.bias = b.qkv.b; g.out_dtype = img_dt_; g.map_mode = MAP_QKV;
         g.C = q_; g.Ck = k_; g.Cv = vt_; g.qkv_dim = D; g.qkv_ntok = ntok_; g.qkv_npad = npad_; g.qkv_heads = H;
+        pe = prof_begin(PF_QKV, st);
         TRY(igemm(g, st));
+        prof_end(PF_QKV, pe, 2.0 * M * 3.0 * D * D, st);
+        pe = prof_begin(PF_ATTN, st);
         if (strict_) TRY(launch_attention_strict(q_, k_, vt_, att_, pl(q_), pl(vt_), pl(att_), B, H, ntok_, npad_, 0.125f, st));
         else TRY(launch_attention(q_, k_, vt_, att_, B, H, ntok_, npad_, img_dt_, 0, 0.125f, st));
+        prof_end(PF_ATTN, pe, 4.0 * B * ntok2 * D, st);          // QK^T + PV, SURVEY 8(d): 4 N^2 D per image and block
         gemm_args_init(g);
         g.A = att_; g.W = b.proj.w; g.M = M; g.N = D; g.K = D; g.lda = D; g.ldw = D;
         g.bias = b.proj.b; g.res_mode = RES_DEST; g.res = x_; g.res_dtype = DT_F32;
         g.C = x_; g.out_dtype = DT_F32; g.ldc = D; g.map_mode = MAP_LINEAR;
+        pe = prof_begin(PF_PROJ, st);
         TRY(igemm(g, st));
+        prof_end(PF_PROJ, pe, 2.0 * M * (double)D * D, st);
+        pe = prof_begin(PF_LN, st);
         if (strict_) TRY(launch_ln_split(x_, b.g2, b.b2, ln_, pl(ln_), M, D, 1e-6f, st));
         else TRY(launch_layernorm(x_, DT_F32, b.g2, b.b2, ln_, img_dt_, M, D, 1e-6f, st));
+        prof_end(PF_LN, pe, 0.0, st);
         gemm_args_init(g);
         g.A = ln_; g.W = b.fc1.w; g.M = M; g.N = 4 * D; g.K = D; g.lda = D; g.ldw = D;
         g.bias = b.fc1.b; g.act = ACT_GELU; g.C = mlp_; g.out_dtype = img_dt_; g.ldc = 4 * D; g.map_mode = MAP_LINEAR;
         g.tag = 1;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (profiling) { e0 = get_event(); e1 = get_event(); if (e0) (void)hipEventRecord(e0, st); }
+        pe = prof_begin(PF_FC1, st);
         TRY(igemm(g, st));
-        if (profiling && e0 && e1) { (void)hipEventRecord(e1, st); ev_fc1_.push_back({e0, e1}); prof_fc1_.flops = 2.0 * M * 4.0 * D * D; }
+        prof_end(PF_FC1, pe, 2.0 * M * 4.0 * D * D, st);
         gemm_args_init(g);
         g.A = mlp_; g.W = b.fc2.w; g.M = M; g.N = D; g.K = 4 * D; g.lda = 4 * D; g.ldw = 4 * D;
         g.bias = b.fc2.b; g.res_mode = RES_DEST; g.res = x_; g.res_dtype = DT_F32;
         g.C = x_; g.out_dtype = DT_F32; g.ldc = D; g.map_mode = MAP_LINEAR;
+        pe = prof_begin(PF_FC2, st);
         TRY(igemm(g, st));
+        prof_end(PF_FC2, pe, 2.0 * M * 4.0 * D * D, st);
 
         for (int l = 0; l < 4; ++l) {
             if (c.hooks[l] != i) continue;
@@ -761,7 +795,7 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
         if (logits && !argmax_out && c.arch_option == 0 && !no_4x) {
             TRY(launch_upsample4x_planes_scaled(rpl_, nscale_, logits, B * kk, kk, lh_[0], lw_[0], st));
             last_low_ = low_; last_kout_ = kk;
-            if (profiling && fwd0 && fwd1) { (void)hipEventRecord(fwd1, st); ev_fwd_.push_back({fwd0, fwd1}); }
+            prof_end(PF_FWD, fwd0, 0.0, st);
             return 0;
         }
         TRY(materialize_low(st));
@@ -822,7 +856,7 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
     if (argmax_out) TRY(launch_seg_stats_ex(low, nullptr, B, Kout, 4 * hw1, -1, nullptr, nullptr, argmax_out, 1, h1, w1, st));
     // ---- scratch.output_conv: bilinear x2, align_corners=True (lseg_net.py:203) ----------------------------------
     if (logits) TRY(launch_upsample2x_planes(low, logits, B * Kout, h1, w1, st));
-    if (profiling && fwd0 && fwd1) { (void)hipEventRecord(fwd1, st); ev_fwd_.push_back({fwd0, fwd1}); }
+    prof_end(PF_FWD, fwd0, 0.0, st);
     return 0;
 }
 

@@ -45,9 +45,6 @@ int launch_layernorm_backward(const void* dy, int dy_dtype, const float* x, cons
                               void* dx16 = nullptr);             // optional 16-bit copy (dy's type) of the updated dx
 constexpr int LN_BWD_PARTIAL_BLOCKS = 1024;
 int launch_transpose16(const void* in, void* out, int R, int C, int ldi, int ldo, hipStream_t st, int shift = 0, int relu = 0);
-int launch_attention_backward(const void* q, const void* k, const void* vt, const void* o, const void* d_o, const float* lse2,
-                              float* dq, float* dk, float* dv, int B, int H, int ntok, int npad, int dtype, int causal, float scale,
-                              hipStream_t stream);
 int launch_bn_train_forward(const void* x, void* y, float* stats, const float* gamma, const float* beta, int B, int H, int W, int C,
                             float eps, int dtype, hipStream_t st);
 int launch_bn_train_backward(const void* dy, const void* x, const float* stats, const float* gamma, void* dx, float* bstats,
@@ -55,8 +52,6 @@ int launch_bn_train_backward(const void* dy, const void* x, const float* stats, 
 int launch_relu_backward(const void* dy, const void* x, void* dx, size_t n, hipStream_t st);
 int launch_upsample2x_planes_backward_rows(const float* dout, void* rows, int B, int K, int H, int W, int ldk, int dtype, hipStream_t st);
 int launch_l2norm_scale_backward(const void* da, int da_dtype, const float* x, void* dx, int dx_dtype, int M, int C, float scale, hipStream_t st);
-int launch_qkv_grad_pack(const float* dq, const float* dk, const float* dv, void* out, int B, int H, int ntok, int npad, int dtype,
-                         hipStream_t st);
 int launch_gelu_backward(const void* dy, const void* pre, void* dx, size_t n, int dtype, hipStream_t st, int quick = 0);
 int launch_upsample2x_nhwc_backward(const void* dout, void* din, int B, int H, int W, int C, int dtype, hipStream_t st);
 int launch_softmax_ce_backward(const float* scores, const int64_t* target, float* dz, int B, int K, int HW, int ignore_index,
@@ -67,7 +62,7 @@ int launch_relu_backward_add(const void* dy, const void* x, const void* add, voi
 int launch_seg_stats_ex(const float* scores, const int64_t* target, int B, int K, int HW, int ignore_index, unsigned long long* counts,
                         double* nll, uint8_t* argmax_out, int up, int h, int w, hipStream_t st, float* lse_out = nullptr);
 int launch_upsample_ce_backward_rows(const float* low, const int64_t* target, const float* lse, const double* nll, void* rows, int B, int K,
-                                     int H, int W, int ldk, int ignore_index, int dtype, hipStream_t st);
+                                     int H, int W, int ldk, int ignore_index, int dtype, hipStream_t st, const float* gscale = nullptr);
 int launch_seg_stats(const float* scores, const int64_t* target, int B, int K, int HW, int ignore_index,
                      unsigned long long* counts, double* nll, hipStream_t st);
 

@@ -283,6 +283,7 @@ int Engine::forward_train(const float* x_in, int B, float* logits, hipStream_t s
     if (group_k > 0) return set_error(LSEG_ERR_UNSUPPORTED, "train mode with per-image label sets is not implemented");
     if (!train_alloc_) return set_error(LSEG_ERR_STATE, "train mode was not enabled (lseg_set_train)");
     train_fwd_valid_ = false;
+    loss_target_ = nullptr;
     last_B_ = B;
     low_pending_ = false;
     eval_stale_ = true;             // the BatchNorm running statistics move: the eval-mode (BN-folded) packs are refreshed by the next eval forward
@@ -607,8 +608,25 @@ int Engine::block_backward(int i, int B, int acc, hipStream_t st) {
 
 // lseg_backward: gradients of mean CE(ignore_index) (target given) or of <dlogits, logits> (dlogits given) w.r.t. every
 // pretrained.* / scratch.* parameter the forward touched
-int Engine::backward(const float* dlogits, const int64_t* target, int ignore_index, int acc, double* dev_loss2, hipStream_t st) {
+// The value of the criterion on the last train-mode forward (lsegmentation_module.py:72), without the backward: mean CE pieces
+// {sum of -log p[target], valid pixels} and, optionally, the pixel-accuracy counts {correct, labeled} (train_accuracy, :77-79).
+// The per-pixel log-sum-exp it leaves behind is reused by a following lseg_backward on the same target.
+int Engine::train_loss(const int64_t* target, int ignore_index, double* dev_loss2, int64_t* dev_counts2, hipStream_t st) {
+    if (!train_mode || !train_fwd_valid_) return set_error(LSEG_ERR_STATE, "lseg_train_loss needs a train-mode lseg_forward first");
+    if (!target) return set_error(LSEG_ERR_INVALID, "lseg_train_loss: target is NULL");
+    LSEG_HIP_TRY(hipSetDevice(device));
+    const int h1 = 2 * lh_[0], w1 = 2 * lw_[0], hw1 = h1 * w1;
+    TRY(launch_seg_stats_ex(low_, target, train_B_, K_, 4 * hw1, ignore_index, counts_, nll_, nullptr, 1, h1, w1, st, lse_px_));
+    if (dev_loss2) LSEG_HIP_TRY(hipMemcpyAsync(dev_loss2, nll_, 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (dev_counts2) LSEG_HIP_TRY(hipMemcpyAsync(dev_counts2, counts_, 2 * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+    loss_target_ = target; loss_ignore_ = ignore_index;
+    return 0;
+}
+
+int Engine::backward(const float* dlogits, const int64_t* target, int ignore_index, int acc, double* dev_loss2, hipStream_t st,
+                     const float* dev_grad_scale) {
     if (!train_mode || !train_fwd_valid_) return set_error(LSEG_ERR_STATE, "lseg_backward needs a train-mode lseg_forward first");
+    if (dlogits && dev_grad_scale) return set_error(LSEG_ERR_INVALID, "lseg_backward: a gradient scale only applies to the fused loss (target given)");
     if (!dlogits && !target) return set_error(LSEG_ERR_INVALID, "lseg_backward: give d(logits) or a target mask");
     LSEG_HIP_TRY(hipSetDevice(device));
     const lseg_config& c = cfg;
@@ -618,8 +636,9 @@ int Engine::backward(const float* dlogits, const int64_t* target, int ignore_ind
     if (!acc) TRY(zero_begin(zero_bwd_, st));
     // ---- loss + x2 upsample^T: the correlation's dY rows ---------------------------------------------------------------------
     if (!dlogits) {      // CrossEntropyLoss(ignore_index) on output_conv(low): one pass for the loss and the per-pixel log-sum-exp, one for the rows
-        TRY(launch_seg_stats_ex(low_, target, B, K_, 4 * hw1, ignore_index, counts_, nll_, nullptr, 1, h1, w1, st, lse_px_));
-        TRY(launch_upsample_ce_backward_rows(low_, target, lse_px_, nll_, drows_, B, K_, h1, w1, Kp, ignore_index, img_dt_, st));
+        if (!(loss_target_ == target && loss_ignore_ == ignore_index))      // else: lseg_train_loss left nll_ / lse_px_ of this forward and target
+            TRY(launch_seg_stats_ex(low_, target, B, K_, 4 * hw1, ignore_index, counts_, nll_, nullptr, 1, h1, w1, st, lse_px_));
+        TRY(launch_upsample_ce_backward_rows(low_, target, lse_px_, nll_, drows_, B, K_, h1, w1, Kp, ignore_index, img_dt_, st, dev_grad_scale));
         if (dev_loss2) LSEG_HIP_TRY(hipMemcpyAsync(dev_loss2, nll_, 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
     } else {             // autograd hand-over: d(logits) [B,K,2h,2w] given
         LSEG_HIP_TRY(hipMemsetAsync(drows_, 0, (size_t)Mp1 * Kp * 2, st));
@@ -716,6 +735,20 @@ int Engine::build_sgd_table() {
     sgd_nseg_ = (int)segs.size(); sgd_blocks_ = blk;
     sgd_dirty_ = false;
     return 0;
+}
+
+// the momentum buffer of a trainable parameter (torch.optim.SGD's state['momentum_buffer']): checkpoint / resume, engine rebuilds
+int Engine::sgd_momentum(const char* key, float** out, size_t* n) {
+    if (sgd_dirty_) TRY(build_sgd_table());
+    size_t off = 0;
+    for (auto& kv : grads_) {          // same walk as build_sgd_table
+        auto it = bound_.find(kv.first);
+        if (it == bound_.end() || it->second.dtype != LSEG_F32 || !kv.second.ptr) continue;
+        if (kv.first.compare(0, 11, "pretrained.") != 0 && kv.first.compare(0, 8, "scratch.") != 0) continue;
+        if (kv.first == key) { if (out) *out = mom_flat_ + off; if (n) *n = kv.second.n; return 0; }
+        off += (kv.second.n + 3) / 4 * 4;
+    }
+    return set_error(LSEG_ERR_MISSING_PARAM, "no momentum buffer for '%s'", key ? key : "");
 }
 
 int Engine::sgd_step(float lr_pre, float lr_scr, float mu, float wd, hipStream_t st) {

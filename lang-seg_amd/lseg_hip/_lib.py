@@ -68,6 +68,10 @@ SIGNATURES = {
     "lseg_grad_bucket": (_i, [_vp, C.c_char_p]),
     "lseg_num_grad_buckets": (_i, [_vp]),
     "lseg_backward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "lseg_backward_scaled": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "lseg_train_loss": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "lseg_sgd_momentum": (_i, [_vp, C.c_char_p, C.POINTER(_vp), C.POINTER(_sz)]),
+    "lseg_sgd_mark_initialized": (_i, [_vp, _i]),
     "lseg_set_bn_sync": (_i, [_vp, _vp, _vp, _i]),
     "lseg_set_bucket_callback": (_i, [_vp, _vp, _vp]),
     "lseg_sgd_step": (_i, [_vp, _f, _f, _f, _f, _vp]),
@@ -82,7 +86,6 @@ SIGNATURES = {
     "lseg_op_seg_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "lseg_op_seg_stats_lowres": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "lseg_op_linear_backward": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "lseg_op_attention_backward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "lseg_op_attention_backward_ws_bytes": (_sz, [_i, _i, _i]),
     "lseg_op_attention_backward_qkv": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "lseg_op_quickgelu_backward": (_i, [_vp, _vp, _vp, C.c_int64, _i, _vp]),
@@ -95,7 +98,6 @@ SIGNATURES = {
     "lseg_op_eval_accumulate": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "lseg_op_eval_resize": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "lseg_op_l2norm_scale_backward": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _f, _vp]),
-    "lseg_op_qkv_grad_pack": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "lseg_op_gelu_backward": (_i, [_vp, _vp, _vp, C.c_int64, _i, _vp]),
     "lseg_op_upsample2x_nhwc_backward": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "lseg_op_softmax_ce_backward": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -99,18 +99,23 @@ class GradBucketer:
         self.buckets = groups
         self.keys = [[n for n, _ in g] for g in groups]
         self.flat = []
+        self.views = []
+        any_dev = named[0][1].device if named else torch.device("cpu")       # empty buckets live where the parameters do (nccl needs that)
         for g in groups:
             n = sum(p.numel() for _, p in g)
-            dev = g[0][1].device if g else torch.device("cpu")
+            dev = g[0][1].device if g else any_dev
             flat = torch.zeros(max(n, 1), dtype=dtype or torch.float32, device=dev)
             off = 0
+            vs = []
             for _, p in g:
                 view = flat[off:off + p.numel()].view_as(p)
                 if p.grad is not None:
                     view.copy_(p.grad)
                 p.grad = view                                  # autograd accumulates into the bucket from now on
+                vs.append(view)
                 off += p.numel()
             self.flat.append(flat)
+            self.views.append(vs)
         self.exchange = BucketExchange(self.flat, group)
         self.world = self.exchange.world
 
@@ -118,6 +123,16 @@ class GradBucketer:
         return len(self.buckets)
 
     def ready(self, i: int):
+        """Bucket i's gradients are final.  `optimizer.zero_grad()` defaults to set_to_none=True (also Lightning's default), which drops
+        the bucket views; autograd then allocates fresh .grad tensors: their values are copied into the bucket and the views are
+        re-attached, so the flat buffer that is all-reduced always holds this step's gradients (zeros for parameters without one)."""
+        for (_, p), view in zip(self.buckets[i], self.views[i]):
+            if p.grad is None:
+                view.zero_()
+                p.grad = view
+            elif p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad)
+                p.grad = view
         self.exchange.ready(i)
 
     def finish(self):

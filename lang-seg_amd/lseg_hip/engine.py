@@ -29,6 +29,21 @@ def _stream_ptr(device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
 
 
+class _HipMemcpy:
+    """device-to-device hipMemcpyAsync by raw pointer (engine-owned memory: BatchNorm sums, momentum buffers)."""
+    _hip = None
+
+    @classmethod
+    def copy(cls, dst: int, src: int, nbytes: int, stream: int):
+        if cls._hip is None:
+            cls._hip = C.CDLL("libamdhip64.so")
+            cls._hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+            cls._hip.hipMemcpyAsync.restype = C.c_int
+        rc = cls._hip.hipMemcpyAsync(C.c_void_p(dst), C.c_void_p(src), nbytes, 3, C.c_void_p(stream))
+        if rc != 0:
+            raise RuntimeError(f"hipMemcpyAsync failed with {rc}")
+
+
 def to_c_config(cfg: LSegConfig, img_h: int, img_w: int, max_batch: int, max_labels: int,
                 image_dtype: str = "bf16", full_text_context: bool = False) -> _lib.LSegConfigC:
     c = _lib.LSegConfigC()
@@ -74,6 +89,9 @@ class HipEngine:
         self._group = 0
         self._keep: List[torch.Tensor] = []
         self.training = False
+        self.image_dtype = image_dtype
+        self.grads: Dict[str, torch.Tensor] = {}
+        self._cb_error: Optional[BaseException] = None     # first exception raised inside a ctypes callback (ctypes would swallow it)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -149,6 +167,7 @@ class HipEngine:
             C.c_void_p(logits.data_ptr()) if logits is not None else None,
             C.c_void_p(amax.data_ptr()) if amax is not None else None,
             C.c_void_p(_stream_ptr(self.device))))
+        self._raise_callback_error()
         if want_logits and want_argmax:
             return logits, amax
         return logits if want_logits else amax
@@ -176,7 +195,7 @@ class HipEngine:
         for k in self.trainable_keys(sd):
             groups[self.lib.lseg_grad_bucket(self._h, k.encode())].append(k)
         self.grad_buckets: List[torch.Tensor] = []
-        self.grads: Dict[str, torch.Tensor] = {}
+        self.grads = {}
         for ks in groups:
             n = sum(sd[k].numel() for k in ks)
             flat = torch.zeros(max(n, 1), dtype=torch.float32, device=self.device)
@@ -195,34 +214,103 @@ class HipEngine:
         _lib.check(self.lib.lseg_set_train(self._h, int(enabled)))
         self.training = bool(enabled)
 
+    def _raise_callback_error(self):
+        """Exceptions raised inside the bucket / SyncBatchNorm callbacks cannot cross the C frames (ctypes prints and drops them):
+        the trampolines park the first one here and it is re-raised as soon as the C call that triggered it has returned."""
+        if self._cb_error is not None:
+            e, self._cb_error = self._cb_error, None
+            raise RuntimeError("a gradient-bucket / SyncBatchNorm callback failed during the engine call; gradients or batch "
+                               "statistics of this step are NOT exchanged") from e
+
     def backward(self, target: Optional[torch.Tensor] = None, dlogits: Optional[torch.Tensor] = None,
-                 ignore_index: int = -1, accumulate: bool = False) -> Optional[torch.Tensor]:
+                 ignore_index: int = -1, accumulate: bool = False, grad_scale: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
         """After a train-mode forward.  target int64 [B,H,W] -> returns the mean cross-entropy (0-dim tensor on the device,
-        no host sync); or dlogits fp32 [B,K,H,W] (autograd hand-over) -> None.  Gradients land in self.grads / grad_buckets."""
+        no host sync); or dlogits fp32 [B,K,H,W] (autograd hand-over) -> None.  Gradients land in self.grads / grad_buckets.
+        grad_scale (fp32 0-dim device tensor, target form only): d(loss) of an autograd caller, read by the kernel (lseg_backward_scaled)."""
         st = C.c_void_p(_stream_ptr(self.device))
         if dlogits is not None:
             dl = dlogits.contiguous()
             assert dl.dtype == torch.float32 and dl.device == self.device
             _lib.check(self.lib.lseg_backward(self._h, C.c_void_p(dl.data_ptr()), None, ignore_index, int(accumulate), None, st))
+            self._raise_callback_error()
             return None
         t = target.contiguous()
         assert t.dtype == torch.int64 and t.device == self.device
+        if grad_scale is not None:
+            gs = grad_scale.detach().to(self.device, torch.float32).reshape(1).contiguous()
+            self._keep = [t, gs]                                  # alive until the kernels that read them have been enqueued AND run
+            _lib.check(self.lib.lseg_backward_scaled(self._h, C.c_void_p(t.data_ptr()), ignore_index, int(accumulate),
+                                                     C.c_void_p(gs.data_ptr()), st))
+            self._raise_callback_error()
+            return None
         _lib.check(self.lib.lseg_backward(self._h, None, C.c_void_p(t.data_ptr()), ignore_index, int(accumulate),
                                           C.c_void_p(self._loss.data_ptr()), st))
+        self._raise_callback_error()
         return (self._loss[0] / self._loss[1]).float()
 
+    def train_loss(self, target: torch.Tensor, ignore_index: int = -1, want_counts: bool = False):
+        """Value of the criterion on the last train-mode forward without the backward (lseg_train_loss): the mean cross-entropy as a
+        0-dim fp32 device tensor (no host sync) and, optionally, int64[2] = {correct, labeled} of the arg-max mask."""
+        t = target.contiguous()
+        assert t.dtype == torch.int64 and t.device == self.device
+        self._loss_target = t                                     # the engine remembers the pointer for the following backward
+        nll = torch.empty(2, dtype=torch.float64, device=self.device)
+        cnt = torch.empty(2, dtype=torch.int64, device=self.device) if want_counts else None
+        _lib.check(self.lib.lseg_train_loss(self._h, C.c_void_p(t.data_ptr()), ignore_index, C.c_void_p(nll.data_ptr()),
+                                            C.c_void_p(cnt.data_ptr()) if cnt is not None else None,
+                                            C.c_void_p(_stream_ptr(self.device))))
+        loss = (nll[0] / nll[1]).float()
+        return (loss, cnt) if want_counts else loss
+
+    # ---- momentum buffers of the fused SGD (torch.optim.SGD state['momentum_buffer']; checkpoints, engine rebuilds) ----
+    def _momentum_ptr(self, key: str):
+        p, n = C.c_void_p(), C.c_size_t(0)
+        _lib.check(self.lib.lseg_sgd_momentum(self._h, key.encode(), C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def get_momentum(self, key: str) -> torch.Tensor:
+        ptr, n = self._momentum_ptr(key)
+        out = torch.empty(n, dtype=torch.float32, device=self.device)
+        _HipMemcpy.copy(out.data_ptr(), ptr, 4 * n, _stream_ptr(self.device))
+        return out.view(self.bound[key].shape)
+
+    def set_momentum(self, key: str, value: torch.Tensor):
+        ptr, n = self._momentum_ptr(key)
+        v = value.detach().to(self.device, torch.float32).contiguous()
+        if v.numel() != n:
+            raise ValueError(f"momentum of '{key}' has {v.numel()} elements, expected {n}")
+        _HipMemcpy.copy(ptr, v.data_ptr(), 4 * n, _stream_ptr(self.device))
+        torch.cuda.current_stream(self.device).synchronize()       # v may be a temporary
+
+    def mark_sgd_initialized(self, initialized: bool = True):
+        _lib.check(self.lib.lseg_sgd_mark_initialized(self._h, int(initialized)))
+
     def sgd_step(self, lr_pretrained: float, lr_scratch: float, momentum: float = 0.9, weight_decay: float = 1e-4):
+        """Fused SGD on the bound fp32 masters + re-pack of the engine's operand copies.  The masters (the caller's tensors) and the
+        BatchNorm running statistics are written through raw pointers: tensor._version does NOT move -- other consumers of the
+        same tensors (other engines of an LSegNet) must be told (LSeg.invalidate_engines)."""
         _lib.check(self.lib.lseg_sgd_step(self._h, lr_pretrained, lr_scratch, momentum, weight_decay,
                                           C.c_void_p(_stream_ptr(self.device))))
 
+    def _guarded(self, fn):
+        def call(*a):
+            try:
+                fn(*a)
+            except BaseException as e:          # noqa: BLE001  (must not unwind through the C frames; re-raised by _raise_callback_error)
+                if self._cb_error is None:
+                    self._cb_error = e
+        return call
+
     def set_bucket_callback(self, fn):
         """fn(bucket_index) is called on the host as soon as the bucket's last gradient kernel is enqueued."""
-        self._bucket_cb = _lib.BUCKET_CB(lambda user, b, stream: fn(int(b))) if fn is not None else None
+        g = self._guarded(fn) if fn is not None else None
+        self._bucket_cb = _lib.BUCKET_CB(lambda user, b, stream: g(int(b))) if fn is not None else None
         _lib.check(self.lib.lseg_set_bucket_callback(self._h, C.cast(self._bucket_cb, C.c_void_p) if fn else None, None))
 
     def set_bn_sync(self, fn, world_size: int):
         """fn(dev_ptr, n_floats) must sum the n floats at dev_ptr over the ranks, ordered on the current stream."""
-        self._bn_cb = _lib.REDUCE_CB(lambda user, p, n, stream: fn(int(p), int(n))) if fn is not None else None
+        g = self._guarded(fn) if fn is not None else None
+        self._bn_cb = _lib.REDUCE_CB(lambda user, p, n, stream: g(int(p), int(n))) if fn is not None else None
         _lib.check(self.lib.lseg_set_bn_sync(self._h, C.cast(self._bn_cb, C.c_void_p) if fn else None, None, int(world_size)))
 
     def forward_stats(self, target: torch.Tensor, ignore_index: int = -1) -> dict:
@@ -252,8 +340,18 @@ class HipEngine:
             raise ValueError(f"intermediate '{name}' has {n.value} elements, expected {out.numel()} {tuple(shape)}")
         return out
 
-    def set_profiling(self, enabled: bool):
-        _lib.check(self.lib.lseg_set_profiling(self._h, int(enabled)))
+    PROFILE_FAMILIES = ("forward", "mlp_fc1", "mlp_fc2", "attn_proj", "attn_qkv", "attention", "layernorm")
+
+    def set_profiling(self, enabled):
+        """True = HIP-event timing of the whole forward + the MLP fc1 GEMM; a list of family names (PROFILE_FAMILIES) = exactly those;
+        False = off.  The events are created here, outside any timed region (lseg_set_profiling)."""
+        if isinstance(enabled, (list, tuple, set)):
+            mask = 1 << 30               # an unused family bit: keeps a one-family mask apart from the ABI's "1 = forward + mlp_fc1"
+            for f in enabled:
+                mask |= 1 << self.PROFILE_FAMILIES.index(f)
+        else:
+            mask = int(bool(enabled))
+        _lib.check(self.lib.lseg_set_profiling(self._h, mask))
 
     def profile(self, family: str):
         ms, n, fl = C.c_double(0), C.c_int64(0), C.c_double(0)

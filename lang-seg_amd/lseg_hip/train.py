@@ -17,7 +17,6 @@ utils.py:20-22,34) around `LSegmentationModule.training_step` (modules/lsegmenta
 
 One process per GPU; `torch.distributed` backend "nccl" is RCCL on ROCm, "gloo" in the CPU tests of `BucketExchange`.
 """
-import ctypes as C
 from typing import Dict, List, Optional
 
 import torch
@@ -52,8 +51,9 @@ class BucketExchange:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._work = [None] * len(buckets)
         self._ready = [False] * len(buckets)
-        cuda = bool(buckets) and buckets[0].is_cuda
-        self._stream = torch.cuda.Stream(device=buckets[0].device) if cuda else None
+        cuda = any(b.is_cuda for b in buckets)
+        self._dev = next((b.device for b in buckets if b.is_cuda), None)
+        self._stream = torch.cuda.Stream(device=self._dev) if cuda else None
         self._event = torch.cuda.Event() if cuda else None
 
     def __len__(self):
@@ -93,22 +93,34 @@ class BucketExchange:
                     flat.div_(self.world)
                 self._work[i] = None
         if self._stream is not None and self.world > 1:
-            torch.cuda.current_stream(self.buckets[0].device).wait_stream(self._stream)
+            torch.cuda.current_stream(self._dev).wait_stream(self._stream)
+        self._ready = [False] * len(self.buckets)
+
+    def abort(self):
+        """Forget a step that failed half-way (an exception between ready() calls): wait for what was launched, clear the flags."""
+        for i, w in enumerate(self._work):
+            if w is not None:
+                w.wait()
+                self._work[i] = None
         self._ready = [False] * len(self.buckets)
 
 
-class _HipCopy:
-    """device-to-device hipMemcpyAsync by raw pointer (the BatchNorm sums live in engine-owned memory)."""
+class BnSync:
+    """SyncBatchNorm exchange (utils.py:34): sums the engine's 2C per-layer BatchNorm sums over the ranks, in place, ordered on the
+    current stream -- between the statistics and the normalisation kernels (forward) and between the gradient sums and dx (backward)."""
 
-    def __init__(self):
-        self.hip = C.CDLL("libamdhip64.so")
-        self.hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
-        self.hip.hipMemcpyAsync.restype = C.c_int
+    def __init__(self, engine, world: int, group=None):
+        self.eng, self.group = engine, group
+        self._buf = torch.zeros(1 << 16, dtype=torch.float32, device=engine.device)
+        engine.set_bn_sync(self, world)
 
-    def __call__(self, dst: int, src: int, nbytes: int, stream: int):
-        rc = self.hip.hipMemcpyAsync(C.c_void_p(dst), C.c_void_p(src), nbytes, 3, C.c_void_p(stream))
-        if rc != 0:
-            raise RuntimeError(f"hipMemcpyAsync failed with {rc}")
+    def __call__(self, ptr: int, n: int):
+        from .engine import _HipMemcpy
+        st = torch.cuda.current_stream(self.eng.device).cuda_stream
+        buf = self._buf[:n]
+        _HipMemcpy.copy(buf.data_ptr(), ptr, 4 * n, st)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        _HipMemcpy.copy(ptr, buf.data_ptr(), 4 * n, st)
 
 
 class DataParallelTrainer:
@@ -122,24 +134,21 @@ class DataParallelTrainer:
         engine.set_bucket_callback(self.exchange.ready)
         self.sync_bn = bool(sync_bn) and self.world > 1
         if self.sync_bn:
-            self._copy = _HipCopy()
-            self._bn_buf = torch.zeros(1 << 16, dtype=torch.float32, device=engine.device)
-            self._group = group
-            engine.set_bn_sync(self._bn_allreduce, self.world)
+            self._bn = BnSync(engine, self.world, group)
 
-    def _bn_allreduce(self, ptr: int, n: int):
-        st = torch.cuda.current_stream(self.eng.device).cuda_stream
-        buf = self._bn_buf[:n]
-        self._copy(buf.data_ptr(), ptr, 4 * n, st)
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self._group)
-        self._copy(ptr, buf.data_ptr(), 4 * n, st)
+    def forward_backward(self, x: torch.Tensor, target: torch.Tensor, ignore_index: int = -1, accumulate: bool = False) -> torch.Tensor:
+        """Train-mode forward + fused loss/backward + gradient exchange, without the optimizer step."""
+        if not self.eng.training:                        # an eval forward on the same engine (validation) switched it off
+            self.eng.set_train(True)
+        self.eng.forward(x, want_logits=False)
+        loss = self.eng.backward(target=target, ignore_index=ignore_index, accumulate=accumulate)
+        self.exchange.finish()
+        return loss
 
     def step(self, x: torch.Tensor, target: torch.Tensor, lr_pretrained: float, lr_scratch: float, momentum: float = 0.9,
              weight_decay: float = 1e-4, ignore_index: int = -1, optimize: bool = True) -> torch.Tensor:
         """One training step; returns the (local) mean cross-entropy as a 0-dim device tensor, no host synchronisation."""
-        self.eng.forward(x, want_logits=False)
-        loss = self.eng.backward(target=target, ignore_index=ignore_index)
-        self.exchange.finish()
+        loss = self.forward_backward(x, target, ignore_index)
         if optimize:
             self.eng.sgd_step(lr_pretrained, lr_scratch, momentum, weight_decay)
         return loss

@@ -31,6 +31,106 @@ except ImportError:
 from lseg_hip.metrics import batch_pix_accuracy, batch_intersection_union      # noqa: E402
 
 
+class EngineSGD(torch.optim.SGD):
+    """The optimizer `configure_optimizers` returns (lsegmentation_module.py:119-175: SGD, momentum 0.9, weight decay, two parameter
+    groups -- pretrained at base_lr, scratch at 10 x base_lr -- under a poly LambdaLR).  A regular torch.optim.SGD for every caller
+    (param_groups, lr schedulers, closures, add_param_group); when the gradients of this step were produced by the HIP engine
+    (`training_step` -> `loss.backward()`), `step()` runs the engine's fused lseg_sgd_step instead of torch's foreach kernels: one launch
+    over the fp32 masters that also refreshes the engine's bf16 operand copies -- no re-bind, no re-pack of 344 M parameters.
+    Momentum lives in the engine; state_dict() / load_state_dict() move it to / from torch's `momentum_buffer` layout, so Lightning
+    checkpoints (`optimizer_states`) keep working.  zero_grad() only flags the engine (the next backward overwrites its buckets)."""
+
+    def __init__(self, params, net=None, **kw):
+        super().__init__(params, **kw)
+        self._net = net
+        self._pending_momentum = None
+
+    def _engine(self):
+        net = self._net
+        if net is None:
+            return None
+        for eng in net._engines.values():
+            ts = getattr(eng, "_ts", None)
+            if ts is not None and ts.fresh:
+                return eng
+        return None
+
+    def _fusable(self):
+        g = self.param_groups
+        if len(g) != 2:
+            return False
+        same = all(g[0][k] == g[1][k] for k in ("momentum", "weight_decay", "dampening", "nesterov"))
+        return same and g[0]["dampening"] == 0 and not g[0]["nesterov"] and not g[0].get("maximize", False)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:                               # Lightning hands training_step + backward over as the closure
+            with torch.enable_grad():
+                loss = closure()
+        eng = self._engine()
+        if eng is None or not self._fusable() or self._net.autograd_grads:
+            super().step()
+            return loss
+        ts = eng._ts
+        if self._pending_momentum is not None:                # restored from a checkpoint: push it into the engine once
+            self._push_momentum(eng, self._pending_momentum)
+            self._pending_momentum = None
+        g = self.param_groups
+        eng.sgd_step(g[0]["lr"], g[1]["lr"], g[0]["momentum"], g[0]["weight_decay"])
+        ts.sgd_steps += 1
+        ts.fresh = False
+        self._net.invalidate_engines(except_=eng)
+        return loss
+
+    def zero_grad(self, set_to_none=True):
+        eng_any = False
+        if self._net is not None and not self._net.autograd_grads:
+            for eng in self._net._engines.values():
+                ts = getattr(eng, "_ts", None)
+                if ts is not None:
+                    ts.lazy_zero, ts.fresh = True, False
+                    eng_any = True
+        if not eng_any:
+            super().zero_grad(set_to_none=set_to_none)
+
+    # ---- checkpoint compatibility with torch.optim.SGD ------------------------------------------------------------------------
+    def _index_keys(self):
+        """optimizer parameter index (torch's state_dict numbering) -> state-dict key of the network."""
+        names = {id(p): k for k, p in self._net.named_parameters()}
+        out, i = {}, 0
+        for grp in self.param_groups:
+            for p in grp["params"]:
+                out[i] = names.get(id(p))
+                i += 1
+        return out
+
+    def state_dict(self):
+        sd = super().state_dict()
+        eng = next((e for e in (self._net._engines.values() if self._net is not None else []) if getattr(e, "_ts", None) is not None
+                    and e._ts.sgd_steps > 0), None)
+        if eng is not None:
+            for i, k in self._index_keys().items():
+                if k in eng.grads:
+                    sd["state"][i] = {"momentum_buffer": eng.get_momentum(k)}
+            torch.cuda.current_stream(eng.device).synchronize()
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        keys = self._index_keys()
+        mom = {keys[i]: st["momentum_buffer"] for i, st in state_dict.get("state", {}).items()
+               if isinstance(st, dict) and st.get("momentum_buffer") is not None and keys.get(i)}
+        self._pending_momentum = mom or None
+
+    @staticmethod
+    def _push_momentum(eng, mom):
+        for k, v in mom.items():
+            if k in eng.grads:
+                eng.set_momentum(k, v)
+        eng.mark_sgd_initialized(True)
+
+
 class LSegmentationModule(_Base):
     def __init__(self, data_path, dataset, batch_size, base_lr, max_epochs, **kwargs):
         super().__init__()
@@ -70,12 +170,31 @@ class LSegmentationModule(_Base):
         inter, union = batch_intersection_union(pred.data, target.data, self.nclass)
         return correct, labeled, inter, union
 
-    def training_step(self, batch, batch_nb):                 # :66-81 (autocast/GradScaler are disabled there: self.enabled = False)
-        img, target = batch
-        out = self(img)                                       # train-mode engine forward; autograd node = lseg_backward
-        multi_loss = isinstance(out, tuple)
+    def _fused_criterion(self):
+        """ignore_index when `self.criterion` is the plain cross-entropy the fused loss implements -- nn.CrossEntropyLoss / [3P] encoding
+        SegmentationLosses(se_loss=False, aux=False), mean over pixels != ignore_index, no class weights, no label smoothing -- else None."""
         if not hasattr(self, "criterion"):
             self.criterion = self.get_criterion(**self.other_kwargs)
+        c = self.criterion
+        if not isinstance(c, nn.CrossEntropyLoss) or c.weight is not None or c.reduction != "mean" or getattr(c, "label_smoothing", 0.0) != 0.0:
+            return None
+        if getattr(c, "se_loss", False) or getattr(c, "aux", False):
+            return None
+        return int(c.ignore_index)
+
+    def training_step(self, batch, batch_nb):                 # :66-81 (autocast/GradScaler are disabled there: self.enabled = False)
+        img, target = batch
+        ignore = self._fused_criterion()
+        if ignore is not None and hasattr(self.net, "forward_loss") and not self.other_kwargs.get("materialize_logits", False):
+            # `out = self(img); loss = self.criterion(out, target)` as ONE autograd node on the engine: no [B,K,H,W] logits, the loss
+            # value and the train-accuracy counts come from the low-resolution logits through the x2 bilinear (lseg_train_loss)
+            loss = self.net.forward_loss(img, target, ignore_index=ignore)
+            counts = self.net._last_train_counts              # int64[2] on the device: correct, labeled (== _filter_invalid + Accuracy)
+            self._train_counts = counts if getattr(self, "_train_counts", None) is None else self._train_counts + counts
+            self.log("train_loss", loss)
+            return loss
+        out = self(img)                                       # train-mode engine forward; autograd node = lseg_backward(dlogits)
+        multi_loss = isinstance(out, tuple)
         loss = self.criterion(*out, target) if multi_loss else self.criterion(out, target)
         final_output = out[0] if multi_loss else out
         train_pred, train_gt = self._filter_invalid(final_output, target)
@@ -84,20 +203,63 @@ class LSegmentationModule(_Base):
         self.log("train_loss", loss)
         return loss
 
+    def training_epoch_end(self, outs):                       # :83-84
+        c = getattr(self, "_train_counts", None)
+        if c is not None:                                     # fused path: Accuracy().compute() == correct / labeled over the epoch
+            c = c.cpu()
+            self.log("train_acc_epoch", float(c[0]) / max(1, int(c[1])))
+            self._train_counts = None
+        elif hasattr(self, "train_accuracy"):
+            self.log("train_acc_epoch", self.train_accuracy.compute())
+
+    def validation_step(self, batch, batch_nb):               # :86-105 -- loss, pixAcc, IoU counts from ONE engine pass, no logits
+        img, target = batch
+        ignore = self._fused_criterion()
+        if ignore is None or not hasattr(self.net, "forward_metrics"):
+            raise NotImplementedError("validation_step needs the plain cross-entropy criterion (se_loss / aux are never enabled by the reference's scripts)")
+        r = self.net.forward_metrics(img, target, ignore_index=ignore)
+        if not hasattr(self, "val_iou"):
+            from lseg_hip.metrics import SegmentationMetric as DeviceMetric
+            self.val_iou = DeviceMetric(self.nclass)
+        self.val_iou._accumulate(r["correct"], r["labeled"], r["area_inter"], r["area_union"])
+        pixAcc, iou = self.val_iou.get()
+        self.log("val_loss_step", r["nll_sum"] / max(1, r["nll_count"]))
+        self.log("pix_acc_step", pixAcc)
+        self.log("val_acc_step", r["correct"] / max(1, r["labeled"]))
+        self.log("val_iou", iou)
+
+    def validation_epoch_end(self, outs):                     # :107-112
+        if not hasattr(self, "val_iou"):
+            return
+        pixAcc, iou = self.val_iou.get()
+        self.log("val_acc_epoch", pixAcc)
+        self.log("val_iou_epoch", iou)
+        self.log("pix_acc_epoch", pixAcc)
+        self.val_iou.reset()
+
     def native_training_step(self, img, target, lr_scale=1.0):
-        """The same step without autograd in the loop (the fast path bench.py --train measures): engine forward + fused
-        upsample/CE/backward + bucketed RCCL all-reduce + fused SGD, through lseg_hip.train.DataParallelTrainer."""
-        from lseg_hip.train import DataParallelTrainer
+        """One whole step without autograd or torch.optim in the loop: engine forward + fused upsample/CE/backward + bucketed gradient
+        all-reduce (when torch.distributed is up) + fused SGD at base_lr * lr_scale.  Same engine, buckets and exchange as
+        training_step -> loss.backward() -> EngineSGD.step(); returns the local mean cross-entropy (device tensor, no sync)."""
         net = self.net
-        B, _, H, W = img.shape
-        eng = net._engine(B, H, W, net.text.shape[0], img.device)
-        if getattr(self, "_trainer", None) is None or self._trainer.eng is not eng:
-            eng.set_tokens(net.text)
-            self._trainer = DataParallelTrainer(eng, dict(net.state_dict()), sync_bn=True)
+        ignore = self.other_kwargs.get("ignore_index", -1)
+        eng, keys, _ = net._train_inputs(img, "")
+        eng.forward(img.float(), want_logits=False)
+        ts = eng._ts
+        try:
+            loss = eng.backward(target=target.to(eng.device, torch.int64), ignore_index=ignore, accumulate=False)
+            if ts.exchange is not None:
+                ts.exchange.finish()
+        except BaseException:
+            if ts.exchange is not None:
+                ts.exchange.abort()
+            raise
         wd = self.other_kwargs.get("weight_decay", 1e-4)
-        loss = self._trainer.step(img.float(), target, self.base_lr * lr_scale, self.base_lr * 10 * lr_scale, 0.9, wd,
-                                  self.other_kwargs.get("ignore_index", -1))
-        return loss                                           # the fused SGD updated the parameters' storage in place
+        eng.sgd_step(self.base_lr * lr_scale, self.base_lr * 10 * lr_scale, 0.9, wd)
+        ts.sgd_steps += 1
+        ts.lazy_zero, ts.fresh = True, False
+        net.invalidate_engines(except_=eng)
+        return loss
 
     def _filter_invalid(self, pred, target):                  # :114-117
         valid = target != self.other_kwargs["ignore_index"]
@@ -108,8 +270,9 @@ class LSegmentationModule(_Base):
         params_list = [{"params": self.net.pretrained.parameters(), "lr": self.base_lr}]
         if hasattr(self.net, "scratch"):
             params_list.append({"params": self.net.scratch.parameters(), "lr": self.base_lr * 10})
-        opt = torch.optim.SGD(params_list, lr=self.base_lr, momentum=0.9,
-                              weight_decay=self.other_kwargs.get("weight_decay", 1e-4))
+        # torch.optim.SGD whose step() is the engine's fused lseg_sgd_step when this step's gradients came from the engine
+        opt = EngineSGD(params_list, net=self.net, lr=self.base_lr, momentum=0.9,
+                        weight_decay=self.other_kwargs.get("weight_decay", 1e-4))
         sch = torch.optim.lr_scheduler.LambdaLR(opt, lambda x: pow(1.0 - x / self.epochs, 0.9))
         return [opt], [sch]
 

@@ -7,6 +7,7 @@ include/lseg_hip.h).  There is NO PyTorch/CPU fallback: without the built extens
 a GPU the forward raises.
 """
 import math
+import os
 import warnings
 from collections import OrderedDict
 
@@ -18,6 +19,9 @@ from lseg_hip.config import get_config
 from lseg_hip.tokenizer import tokenize
 from .lseg_blocks import FeatureFusionBlock_custom, Interpolate, _make_encoder
 from .lseg_vit import _NoForward
+
+# MFMA operand type of inference engines unless the constructor says otherwise (image_dtype=...); see LSeg.__init__
+DEFAULT_IMAGE_DTYPE = os.environ.get("LSEG_IMAGE_DTYPE", "fp16")
 
 
 class depthwise_conv(_NoForward):                      # lseg_net.py:29-40
@@ -55,21 +59,55 @@ def _make_fusion_block(features, use_bn):
                                      expand=False, align_corners=True)
 
 
+class _TrainState:
+    """What one training engine carries across steps: the gradient exchange (when torch.distributed is up), the lazy zero_grad flag,
+    the number of fused optimizer steps (momentum lives in the engine), pending momentum to restore."""
+
+    def __init__(self):
+        self.exchange = None
+        self.lazy_zero = True            # no gradient values to add to yet: the next backward overwrites
+        self.fresh = False               # the engine's buckets hold this step's (exchanged) gradients -> EngineSGD may use the fused step
+        self.sgd_steps = 0
+        self.sync_bn = False
+
+
 class _EngineTrainFn(torch.autograd.Function):
-    """Autograd node of the train-mode forward: `loss.backward()` (Lightning's, or anyone's) lands in lseg_backward with the
-    gradient of the logits; the parameter gradients come back as views of the engine's flat buckets (lseg_bind_grad).
-    The parameters are inputs only so that autograd routes their gradients; the arithmetic is all in the HIP engine."""
+    """Autograd node of the train-mode forward with the LOGITS as output (any criterion): `loss.backward()` (Lightning's, or
+    anyone's) lands in lseg_backward with the gradient of the logits.  The parameters are inputs only so that autograd knows the
+    output depends on them; the arithmetic is all in the HIP engine and the gradients are written straight into the flat buckets
+    behind each parameter's .grad (or handed to autograd when the net was built with autograd_grads=True: DDP-wrapper mode)."""
 
     @staticmethod
     def forward(ctx, x, net, eng, keys, *params):
-        ctx.eng, ctx.keys = eng, keys
+        ctx.net, ctx.eng, ctx.keys = net, eng, keys
         return eng.forward(x)
 
     @staticmethod
     def backward(ctx, dlogits):
-        ctx.eng.backward(dlogits=dlogits)
-        grads = tuple(ctx.eng.grads[k] if k in ctx.eng.grads else None for k in ctx.keys)
+        grads = ctx.net._engine_backward(ctx.eng, ctx.keys, dlogits=dlogits)
         return (None, None, None, None) + grads
+
+
+class _EngineLossFn(torch.autograd.Function):
+    """Autograd node of forward + criterion for the plain cross-entropy the reference trains with (SegmentationLosses with
+    se_loss=False, aux=False == nn.CrossEntropyLoss(ignore_index), lsegmentation_module.py:72,236-244): the [B,K,H,W] logits and their
+    gradient (2 x 1.1 GB at B = 8) never exist -- the loss VALUE comes from lseg_train_loss on the low-resolution logits through the
+    x2 bilinear, the backward is lseg_backward_scaled(target, d(loss)) with d(loss) read on the device (no host synchronisation)."""
+
+    @staticmethod
+    def forward(ctx, x, target, net, eng, keys, ignore_index, *params):
+        ctx.net, ctx.eng, ctx.keys, ctx.ignore_index = net, eng, keys, ignore_index
+        eng.forward(x, want_logits=False)
+        t = target.detach().to(eng.device, torch.int64).contiguous()
+        ctx.target = t
+        loss, counts = eng.train_loss(t, ignore_index, want_counts=True)
+        net._last_train_counts = counts
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        grads = ctx.net._engine_backward(ctx.eng, ctx.keys, target=ctx.target, ignore_index=ctx.ignore_index, grad_scale=g)
+        return (None, None, None, None, None, None) + grads
 
 
 class LSeg(BaseModel):
@@ -97,38 +135,57 @@ class LSeg(BaseModel):
             self.scratch.head_block = depthwise_block(activation=act)
         self.scratch.output_conv = head
         self.text = tokenize(self.labels, self.cfg.text.ctx, self.cfg.text.vocab)     # lseg_net.py:158
-        self._engines = OrderedDict()            # (H, W, device index) -> HipEngine, least recently used first
+        self._engines = OrderedDict()            # (H, W, device index, train) -> HipEngine, least recently used first
         self.max_engines = kwargs.get("max_engines", 4)
-        self.image_dtype = kwargs.get("image_dtype", "bf16")
+        # MFMA operand type of the image tower.  The reference's tower is fp32; of the two 16-bit types fp16 (11 significand bits) is 8x
+        # closer to it than bf16 (8) at the same MFMA rate (DESIGN.md par. 4, bench.py `dtype_selection`).  Training engines are bf16:
+        # the per-logit gradient of a mean over 1.8 M pixels is ~1e-7 and would flush to zero in fp16.
+        self.image_dtype = kwargs.get("image_dtype", DEFAULT_IMAGE_DTYPE)
         self.cache_text = kwargs.get("cache_text", False)
+        # DDP-wrapper mode: hand the parameter gradients to autograd (DistributedDataParallel's hooks then reduce them) instead of
+        # writing them behind .grad and exchanging the flat buckets ourselves
+        self.autograd_grads = bool(kwargs.get("autograd_grads", os.environ.get("LSEG_AUTOGRAD_GRADS", "") not in ("", "0")))
+        self.sync_batchnorm = kwargs.get("sync_batchnorm", True)       # utils.py:34 (only matters when torch.distributed is initialised)
+        self._native_epoch = 0                   # bumped whenever the engine wrote the masters / running statistics through raw pointers
+        self._last_train_counts = None
 
     # ---- engine plumbing -----------------------------------------------------------------------
 
-    def _engine(self, B, H, W, K, device):
-        """One engine per (image size, device): each holds its own packed weights + activation plan (~1 GB for ViT-L/16).  The
-        cache is bounded (callers with varying image sizes: lseg_app, `evaluate` on uncropped images): the least recently used
-        engine of THIS device is closed when more than `max_engines` exist.  Replicas made by DataParallel.replicate
+    def _engine(self, B, H, W, K, device, train=False):
+        """One engine per (image size, device, train/eval): each holds its own packed weights + activation plan (~1 GB for ViT-L/16
+        in eval mode).  The cache is bounded (callers with varying image sizes: lseg_app, `evaluate` on uncropped images): the least
+        recently used EVAL engine of THIS device is closed when more than `max_engines` exist; training engines (momentum, bound
+        gradients, possibly referenced by a live autograd graph) are never evicted.  Replicas made by DataParallel.replicate
         (additional_utils/encoding_models.py:43) share this dict object; the device index in the key keeps their engines apart."""
         from lseg_hip.engine import HipEngine
-        key = (H, W, device.index)
+        key = (H, W, device.index, bool(train))
         eng = self._engines.get(key)
         if eng is not None:
             self._engines.move_to_end(key)
         else:
-            mine = [k for k in self._engines if k[2] == device.index]
-            while len(mine) >= max(1, self.max_engines):
+            mine = [k for k in self._engines if k[2] == device.index and not k[3] and self._engines[k] is not getattr(self, "_last_engine", None)]
+            n_eval = len([k for k in self._engines if k[2] == device.index and not k[3]])
+            while mine and n_eval >= max(1, self.max_engines):
                 self._engines.pop(mine.pop(0)).close()
+                n_eval -= 1
         if eng is None or eng.max_batch < B or eng.max_labels < K:
+            carried = None
             if eng is not None:
+                if train and getattr(eng, "_ts", None) is not None and eng._ts.sgd_steps > 0:
+                    # a bigger batch on a training engine: rebuild it, but the optimizer state moves over
+                    carried = ({k: eng.get_momentum(k) for k in eng.grads}, eng._ts.sgd_steps)
+                    torch.cuda.current_stream(device).synchronize()
                 eng.close()
             eng = HipEngine(self.cfg, H, W, max_batch=max(B, eng.max_batch if eng else 1),
                             max_labels=max(K, eng.max_labels if eng else 1), device=device,
-                            image_dtype=self.image_dtype)
+                            image_dtype="bf16" if train else self.image_dtype)
             eng._stamp = None
             eng._tok = None
+            eng._ts = None
+            eng._carried = carried
             self._engines[key] = eng
         stamp = self._stamp()
-        if eng._stamp != stamp:                       # first use, load_state_dict, optimizer step, .cuda() ...
+        if eng._stamp != stamp:                       # first use, load_state_dict, torch.optim step, .cuda(), a fused step on another engine ...
             eng.load_state_dict(self.state_dict())
             eng._stamp = stamp
             eng._tok = None
@@ -136,12 +193,22 @@ class LSeg(BaseModel):
 
     def _stamp(self):
         # (storage, version) of every tensor of the state dict: changes on load_state_dict, optimizer steps, .cuda(), .half() ...
+        # plus a counter for what tensor versions cannot see: the fused SGD step and the train-mode BatchNorm write the masters /
+        # running statistics through raw pointers.
         # The tensor list is cached (building the state dict costs ~1 ms on ViT-L; it only changes when a module is replaced, which
         # _apply / load_state_dict signal by bumping _stamp_epoch)
         ep = getattr(self, "_stamp_epoch", 0)
         if getattr(self, "_stamp_cache", None) is None or self._stamp_cache[0] != ep:
             self._stamp_cache = (ep, [p for p in self.state_dict(keep_vars=True).values() if isinstance(p, torch.Tensor)])
-        return tuple((p.data_ptr(), p._version) for p in self._stamp_cache[1])
+        return (self._native_epoch,) + tuple((p.data_ptr(), p._version) for p in self._stamp_cache[1])
+
+    def invalidate_engines(self, except_=None):
+        """The engine `except_` changed the bound tensors in place without moving their versions (lseg_sgd_step on the masters,
+        train-mode BatchNorm on the running statistics): every OTHER cached engine (another image size: uncropped validation,
+        lseg_app) must re-bind and re-pack before its next forward; `except_` itself is already consistent."""
+        self._native_epoch += 1
+        if except_ is not None:
+            except_._stamp = self._stamp()
 
     def _apply(self, fn, *a, **k):
         self._stamp_epoch = getattr(self, "_stamp_epoch", 0) + 1
@@ -163,6 +230,97 @@ class LSeg(BaseModel):
         finally:
             self.train(was)
 
+    # ---- training step plumbing (lsegmentation_module.py:66-81 + what Lightning's DDP does around it) -----------------------------
+    def _train_engine(self, B, H, W, K, device):
+        import torch.distributed as dist
+        from lseg_hip.train import BucketExchange
+        eng = self._engine(B, H, W, K, device, train=True)
+        if eng._ts is None:
+            sd = self.state_dict()
+            eng.enable_training({k: v for k, v in sd.items()})
+            ts = _TrainState()
+            world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+            if world > 1 and not self.autograd_grads:
+                ts.exchange = BucketExchange(eng.grad_buckets)
+                eng.set_bucket_callback(ts.exchange.ready)
+                if self.sync_batchnorm:
+                    from lseg_hip.train import BnSync
+                    ts.bn = BnSync(eng, world)
+                    ts.sync_bn = True
+            eng._ts = ts
+            eng._named = [(k, p) for k, p in self.named_parameters() if k in eng.grads]
+            eng._nbt = [b for k, b in self.named_buffers() if k.endswith("num_batches_tracked") and k.startswith("scratch.")
+                        and ".refinenet4.resConfUnit1." not in k]
+            if eng._carried is not None:
+                mom, steps = eng._carried
+                for k, v in mom.items():
+                    eng.set_momentum(k, v)
+                eng.mark_sgd_initialized(True)
+                ts.sgd_steps = steps
+                eng._carried = None
+        if not eng.training:
+            eng.set_train(True)
+        return eng
+
+    def _set_tokens(self, eng, text, labelset):
+        tkey = (tuple(text.shape), text.data_ptr() if labelset == "" else hash(text.numpy().tobytes()))
+        if eng._tok != tkey:
+            eng.set_tokens(text)
+            eng._tok = tkey
+        eng.set_text_cache(bool(self.cache_text))
+
+    def _engine_backward(self, eng, keys, dlogits=None, target=None, ignore_index=-1, grad_scale=None):
+        """Runs lseg_backward and puts the gradients where the caller's optimizer looks for them.  Returns the tuple autograd gets for
+        the parameter inputs: Nones (the engine wrote behind .grad itself) or, in DDP-wrapper mode, the gradient tensors."""
+        ts = eng._ts
+        named = eng._named
+        if self.autograd_grads:
+            acc = False                                  # autograd accumulates into .grad itself; the buckets are scratch
+        else:
+            # accumulate (accumulate_grad_batches, train.sh) iff every .grad still is the engine's view AND holds values: after
+            # zero_grad(set_to_none=True) / a first step the views are re-attached and overwritten; EngineSGD.zero_grad only flags
+            attached = all(p.grad is not None and p.grad.data_ptr() == eng.grads[k].data_ptr() for k, p in named)
+            acc = attached and not ts.lazy_zero
+        try:
+            if dlogits is not None:
+                eng.backward(dlogits=dlogits, accumulate=acc)
+            else:
+                eng.backward(target=target, ignore_index=ignore_index, accumulate=acc, grad_scale=grad_scale)
+            if ts.exchange is not None:
+                ts.exchange.finish()
+        except BaseException:
+            if ts.exchange is not None:
+                ts.exchange.abort()
+            raise
+        ts.lazy_zero = False
+        ts.fresh = True
+        if self.autograd_grads:
+            return tuple(eng.grads[k] for k in keys)
+        for k, p in named:
+            p.grad = eng.grads[k]
+        return tuple(None for _ in keys)
+
+    def _train_inputs(self, x, labelset):
+        text = self.text if labelset == "" else tokenize(labelset, self.cfg.text.ctx, self.cfg.text.vocab)
+        if not x.is_cuda:
+            raise RuntimeError("LSegNet needs CUDA/HIP tensors (no CPU path, like the reference: lseg_vit.py:224)")
+        B, _, H, W = x.shape
+        eng = self._train_engine(B, H, W, text.shape[0], x.device)
+        self._set_tokens(eng, text, labelset)
+        if eng._nbt:
+            torch._foreach_add_(eng._nbt, 1)             # nn.BatchNorm2d.num_batches_tracked (state-dict parity; momentum is fixed at 0.1)
+        self.invalidate_engines(except_=eng)             # train-mode BatchNorm moves the running statistics through raw pointers
+        return eng, tuple(k for k, _ in eng._named), [p for _, p in eng._named]
+
+    def forward_loss(self, x, target, labelset="", ignore_index=-1):
+        """`criterion(self(x), target)` for the reference's criterion (mean cross-entropy over pixels != ignore_index) as ONE autograd
+        node: the value, and under `loss.backward()` the gradients, without the [B,K,H,W] logits.  Also leaves the pixel-accuracy
+        counts {correct, labeled} of this batch in `self._last_train_counts` (int64[2], device)."""
+        if not (self.training and torch.is_grad_enabled()):
+            raise RuntimeError("forward_loss is the training-step path: call it under net.train() with grad enabled")
+        eng, keys, params = self._train_inputs(x, labelset)
+        return _EngineLossFn.apply(x.float(), target, self, eng, keys, int(ignore_index), *params)
+
     def forward(self, x, labelset="", _want_logits=True):
         if labelset == "":
             text = self.text
@@ -173,20 +331,13 @@ class LSeg(BaseModel):
                                "'cuda'), lseg_vit.py:224) this network has no CPU path, and the HIP engine has no "
                                "PyTorch fallback")
         B, _, H, W = x.shape
+        if self.training and torch.is_grad_enabled():              # net.train() under autograd: training_step (:66-81)
+            eng, keys, params = self._train_inputs(x, labelset)
+            return _EngineTrainFn.apply(x.float(), self, eng, keys, *params)
         eng = self._engine(B, H, W, text.shape[0], x.device)
-        train = self.training and torch.is_grad_enabled()          # net.train() under autograd: training_step (:66-81)
-        if train and not getattr(eng, "grads", None):
-            eng.enable_training({k: v for k, v in self.state_dict().items()})
-        if eng.training != train:
-            eng.set_train(train)
-        tkey = (tuple(text.shape), text.data_ptr() if labelset == "" else hash(text.numpy().tobytes()))
-        if eng._tok != tkey:
-            eng.set_tokens(text)
-            eng._tok = tkey
-        eng.set_text_cache(bool(self.cache_text))
-        if train:
-            named = [(k, p) for k, p in self.named_parameters() if k in eng.grads]
-            return _EngineTrainFn.apply(x.float(), self, eng, tuple(k for k, _ in named), *[p for _, p in named])
+        if eng.training:
+            eng.set_train(False)
+        self._set_tokens(eng, text, labelset)
         self._last_engine = eng
         return eng.forward(x.float(), want_logits=_want_logits)
 

@@ -18,7 +18,7 @@ import torch.nn as nn
 from lseg_hip.config import get_config
 from lseg_hip.tokenizer import tokenize
 from .lseg_blocks import Interpolate, _make_encoder
-from .lseg_net import BaseModel, LSeg as _LSegShared, _make_fusion_block
+from .lseg_net import BaseModel, DEFAULT_IMAGE_DTYPE, LSeg as _LSegShared, _make_fusion_block
 
 
 class LSeg(_LSegShared):
@@ -47,8 +47,12 @@ class LSeg(_LSegShared):
         self.texts = [tokenize(["others", name], self.cfg.text.ctx, self.cfg.text.vocab) for name in self.label_list]
         self._engines = OrderedDict()
         self.max_engines = kwargs.get("max_engines", 4)
-        self.image_dtype = kwargs.get("image_dtype", "bf16")
+        self.image_dtype = kwargs.get("image_dtype", DEFAULT_IMAGE_DTYPE)
         self.cache_text = kwargs.get("cache_text", False)
+        self.autograd_grads = False
+        self.sync_batchnorm = False
+        self._native_epoch = 0
+        self._last_train_counts = None
 
     def forward(self, x, class_info):
         ids = [int(c) for c in (class_info.tolist() if torch.is_tensor(class_info) else class_info)]

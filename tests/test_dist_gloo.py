@@ -89,15 +89,31 @@ def _bucket_worker(rank, world, port, q):
     keys = [ks for ks in b.keys]
     gathered = [None] * world
     dist.all_gather_object(gathered, mine)
+    # second step after optimizer.zero_grad() with its default set_to_none=True (Lightning's default too): the bucket views are
+    # gone, autograd allocates fresh .grad tensors -- the exchange must still reduce THIS step's values, not the stale flat buffers
+    g2 = torch.Generator().manual_seed(200 + rank)
+    for i, (n, p) in enumerate(params):
+        p.grad = None
+    for i, (n, p) in enumerate(params):
+        if i % 13 != 5:
+            p.grad = torch.randn(p.shape, generator=g2)
+    mine2 = [None if p.grad is None else p.grad.clone() for _, p in params]
+    for i in range(len(b)):
+        b.ready(i)
+    b.finish()
+    out2 = {n: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for n, p in params}
+    gathered2 = [None] * world
+    dist.all_gather_object(gathered2, mine2)
     if rank == 0:                               # verify here: only small python objects cross the process boundary
         bad = []
-        for i, (n, _) in enumerate(params):
-            if n.startswith("clip_pretrained."):      # frozen tower: in no optimizer group, in no bucket
-                continue
-            g0 = gathered[0][i] if gathered[0][i] is not None else torch.zeros_like(out[n])
-            g1 = gathered[1][i] if gathered[1][i] is not None else torch.zeros_like(out[n])
-            if not torch.allclose(out[n], (g0 + g1) / 2, atol=1e-6):
-                bad.append(n)
+        for res, gat, tag in ((out, gathered, ""), (out2, gathered2, "#2")):
+            for i, (n, _) in enumerate(params):
+                if n.startswith("clip_pretrained."):      # frozen tower: in no optimizer group, in no bucket
+                    continue
+                g0 = gat[0][i] if gat[0][i] is not None else torch.zeros_like(res[n])
+                g1 = gat[1][i] if gat[1][i] is not None else torch.zeros_like(res[n])
+                if not torch.allclose(res[n], (g0 + g1) / 2, atol=1e-6):
+                    bad.append(n + tag)
         q.put((bad, keys, len(params), unreadied_raises))
     dist.barrier()
     dist.destroy_process_group()

@@ -1,5 +1,5 @@
 """A whole ViT block ([3P] timm Block: x += proj(attn(LN1 x)); x += fc2(GELU(fc1(LN2 x)))) back-propagated through the
-C-ABI backward bricks -- linear / gelu / layernorm / attention backward + qkv_grad_pack -- against torch autograd of the
+C-ABI backward bricks -- linear / gelu / layernorm / attention backward (writing d(qkv) directly) -- against torch autograd of the
 same block in fp32.  The glue between the bricks (dtype casts, saved activations) is torch here; in the engine it will be
 the C++ training step.  Shows that the bricks' layouts and conventions compose."""
 import ctypes as C

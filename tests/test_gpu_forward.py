@@ -173,7 +173,7 @@ def test_lsegnet_module_forward_is_the_engine(golden_dir):
     cfg, sd, tok, x, eng, logits, amax = run_engine(spec, debug=False)
     labels = read_labels(MG.LABELS)[:5]
     net = LSegNet(labels=labels, backbone="tiny16", features=cfg.features, arch_option=0, block_depth=0,
-                  activation="lrelu")
+                  activation="lrelu", image_dtype="bf16")          # the same operand type as run_engine's engine (the class default is fp16)
     net.load_state_dict(sd)
     net = net.eval().cuda()
     with torch.no_grad():

@@ -352,40 +352,6 @@ def test_softmax_ce_backward(lib, B, K, H, W):
     assert dz[(target < 0).unsqueeze(1).expand_as(dz)].abs().max().item() == 0
 
 
-@pytest.mark.parametrize("dtype,B,H,N,causal", [(torch.bfloat16, 1, 2, 130, False), (torch.float16, 2, 3, 64, False),
-                                                (torch.bfloat16, 1, 2, 901, False), (torch.bfloat16, 1, 1, 37, False),
-                                                (torch.float16, 3, 8, 77, True), (torch.float16, 2, 2, 5, True)])
-def test_attention_backward(lib, dtype, B, H, N, causal):
-    """Backward of the (unmasked) attention brick: flash-style recomputation from the forward's layouts and per-row
-    log2-sum-exp, against torch autograd in fp32 on the same 16-bit-rounded q, k, v."""
-    Npad = ((N + 127) // 128) * 128
-    q, k, v = rnd((B, H, N, 64), dtype, 70), rnd((B, H, N, 64), dtype, 71), rnd((B, H, N, 64), dtype, 72)
-    d_o = rnd((B, N, H * 64), dtype, 73)
-    qp = torch.zeros((B * H, Npad, 64), dtype=dtype).cuda(); qp[:, :N] = q.reshape(B * H, N, 64)
-    kp = torch.zeros((B * H, Npad, 64), dtype=dtype).cuda(); kp[:, :N] = k.reshape(B * H, N, 64)
-    vt = torch.zeros((B * H, 64, Npad), dtype=dtype).cuda(); vt[:, :, :N] = v.reshape(B * H, N, 64).transpose(1, 2)
-    out = torch.zeros((B, N, H * 64), dtype=dtype).cuda()
-    _lib.check(lib.lseg_op_attention(P(qp), P(kp), P(vt), P(out), B, H, N, Npad, DT[dtype], int(causal), 0.125, stream()))
-    qr, kr, vr = (t.float().requires_grad_(True) for t in (q, k, v))
-    s = (qr @ kr.transpose(-1, -2)) * 0.125
-    if causal:                                           # CLIP text tower: -inf strictly above the diagonal
-        s = s + torch.full((N, N), float("-inf"), device=s.device).triu_(1)
-    ref = (s.softmax(-1) @ vr).transpose(1, 2).reshape(B, N, H * 64)
-    ref.backward(d_o.float())
-    lse2 = torch.zeros((B * H, Npad), dtype=torch.float32).cuda()
-    lse2[:, :N] = (torch.logsumexp(s.detach(), dim=-1) * 1.4426950408889634).reshape(B * H, N)
-    dq, dk, dv = (torch.full((B * H, Npad, 64), float("nan"), dtype=torch.float32).cuda() for _ in range(3))
-    _lib.check(lib.lseg_op_attention_backward(P(qp), P(kp), P(vt), P(out), P(d_o), P(lse2), P(dq), P(dk), P(dv),
-                                              B, H, N, Npad, DT[dtype], int(causal), 0.125, stream()))
-    torch.cuda.synchronize()
-    tol = 3e-2 if dtype == torch.bfloat16 else 6e-3
-    for got, want, name in ((dq, qr.grad, "dq"), (dk, kr.grad, "dk"), (dv, vr.grad, "dv")):
-        g = got[:, :N].reshape(B, H, N, 64)
-        err = (g - want).abs().max().item()
-        assert math.isfinite(err) and err <= tol * max(1.0, want.abs().max().item()), (name, err, want.abs().max().item())
-    assert dk[:, N:((N + 63) // 64) * 64].abs().max().item() == 0 if N % 64 else True      # masked keys get no gradient
-
-
 @pytest.mark.parametrize("dtype,B,H,N", [(torch.bfloat16, 1, 2, 130), (torch.float16, 2, 3, 64), (torch.bfloat16, 1, 2, 901),
                                           (torch.bfloat16, 2, 1, 37), (torch.bfloat16, 3, 4, 257)])
 def test_attention_backward_qkv(lib, dtype, B, H, N):

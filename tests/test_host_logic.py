@@ -187,6 +187,7 @@ def test_engine_cache_is_bounded_and_keeps_replicas_on_their_own_device(monkeypa
         def __init__(self, cfg, H, W, max_batch, max_labels, device=None, image_dtype="bf16"):
             self.key = (H, W, device.index)
             self.max_batch, self.max_labels, self.training = max_batch, max_labels, False
+            self.image_dtype = image_dtype
             made.append(self.key)
 
         def load_state_dict(self, sd):
@@ -204,7 +205,7 @@ def test_engine_cache_is_bounded_and_keeps_replicas_on_their_own_device(monkeypa
     net._engine(1, 96, 64, 2, d0)
     net._engine(1, 64, 64, 2, d0)                       # touch: (96, 64) is now the least recently used
     net._engine(1, 128, 128, 2, d0)                     # third size on device 0 -> evicts (96, 64)
-    assert closed == [(96, 64, 0)] and len([k for k in net._engines if k[2] == 0]) == 2
+    assert closed == [(96, 64, 0)] and len([k for k in net._engines if k[2] == 0]) == 2 and all(not k[3] for k in net._engines)
     replica = copy.copy(net)                            # what replicate() does to the module object
     e_b = replica._engine(1, 64, 64, 2, d1)
     assert e_b is not e_a and e_b.key == (64, 64, 1)

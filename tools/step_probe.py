@@ -12,14 +12,14 @@ from lseg_hip.synth import synthetic_state_dict, synthetic_tokens, synthetic_ima
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, nargs="+", default=[36]); ap.add_argument("--steps", type=int, default=10); ap.add_argument("--warmup", type=int, default=3)
 ap.add_argument("--backbone", default="clip_vitl16_384"); ap.add_argument("--size", type=int, default=480); ap.add_argument("--labels", type=int, default=150)
-ap.add_argument("--text-cache", action="store_true"); ap.add_argument("--no-logits", action="store_true")
+ap.add_argument("--text-cache", action="store_true"); ap.add_argument("--no-logits", action="store_true"); ap.add_argument("--dtype", default="bf16")
 a = ap.parse_args()
 cfg = get_config(a.backbone)
 sd = {k: v.cuda() for k, v in synthetic_state_dict(cfg, seed=0).items()}
 labels = read_labels(os.path.join(ROOT, "lang-seg_amd", "label_files", "ade20k_objectInfo150.txt"))[: a.labels]
 tok = synthetic_tokens(labels, cfg.text.vocab, cfg.text.ctx)
 for B in a.batch:
-    eng = HipEngine(cfg, a.size, a.size, max_batch=B, max_labels=len(labels))
+    eng = HipEngine(cfg, a.size, a.size, max_batch=B, max_labels=len(labels), image_dtype=a.dtype)
     eng.load_state_dict(sd); eng.set_tokens(tok)
     if a.text_cache: eng.set_text_cache(True)
     x = synthetic_images(B, a.size, a.size, seed=0).cuda()
