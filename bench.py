@@ -11,7 +11,9 @@ MFMA operand type (`dtype`): the reference's image tower is fp32; both 16-bit op
 are not equally close to the reference.  With `--dtype auto` (default) the bench measures BOTH -- argmax-mask mismatch fraction and
 max |dlogit| against the reference-run fixture tests/golden/ref_full_vitl16_480x480_k150.pt (made by /root/reference's own
 LSegNet.forward, oracle/make_ref_golden.py --full), and images/sec on the timed workload -- and times the headline on the one
-that meets <= 0.3 % mask flips at equal speed (>= 98 % of the faster one); both results are printed under `dtype_selection`.
+that meets <= 0.3 % mask flips at equal speed (>= 97 % of the faster one: the box-to-box spread of this bench is +-3 %, and fp16
+operands toggle more multiplier bits than bf16, which the chip's power management turns into ~2 % lower clocks on random data);
+both results are printed under `dtype_selection`.
 
 Launch:  python bench.py --gpus 1 --steps K --warmup W
    or:   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -260,13 +262,13 @@ def main():
     if len(cands) > 1:
         ok = {d: parity.get(d) is not None and parity[d]["argmax_mismatch_frac"] <= 0.003 for d in cands}
         fast = max(probe.values())
-        rule = ("the operand type that meets <= 0.3 % argmax flips vs the reference-run fixture at >= 98 % of the faster one's probe rate; "
+        rule = ("the operand type that meets <= 0.3 % argmax flips vs the reference-run fixture at >= 97 % of the faster one's probe rate; "
                 "ties and no-qualifier -> the closer one, then bf16")
-        qual = [d for d in cands if ok[d] and probe[d] >= 0.98 * fast]
+        qual = [d for d in cands if ok[d] and probe[d] >= 0.97 * fast]
         if qual:
             chosen = min(qual, key=lambda d: parity[d]["argmax_mismatch_frac"])
         elif all(parity.get(d) for d in cands):
-            chosen = min((d for d in cands if probe[d] >= 0.98 * fast), key=lambda d: parity[d]["argmax_mismatch_frac"])
+            chosen = min((d for d in cands if probe[d] >= 0.97 * fast), key=lambda d: parity[d]["argmax_mismatch_frac"])
         if dist is not None:                     # one decision for the whole job: rank 0's
             box = [chosen]
             dist.broadcast_object_list(box, src=0)

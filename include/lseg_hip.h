@@ -83,7 +83,12 @@ typedef struct {
                                * reference's tower is fp32).  ~1/4 of the bf16 rate; a validation mode: its masks equal the
                                * reference's except at fp16-ulp ties of the reference's own fp16 logits.  Inference only. */
     int32_t flags;            /* bit 0: run the text tower on all text_ctx positions (reference schedule)
-                               * instead of the exact causal truncation to max(EOT)+1 positions */
+                               * instead of the exact causal truncation to max(EOT)+1 positions
+                               * bit 1 (training): keep the gradient of the fp16 correlation in bf16 / fp32 instead of reproducing the
+                               * reference's HALF-precision backward of `logit_scale * image_features.half() @ text_features.t()`
+                               * (lseg_net.py:194): there d(logits), dA = d(logits) @ text and logit_scale * dA are fp16 tensors, and with
+                               * d(logits) ~ 1 / (valid pixels) ~ 1e-6 they sit in fp16's subnormal range (step 6e-8) -- softmax
+                               * probabilities below ~N * 3e-8 flush to zero.  Default (bit clear) = the reference's arithmetic. */
 } lseg_config;
 
 typedef struct lseg_engine* lseg_handle;

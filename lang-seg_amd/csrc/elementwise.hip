@@ -1414,18 +1414,23 @@ __global__ __launch_bounds__(256) void l2norm_scale_bwd_kernel(const uint16_t* _
             const uint2 u = reinterpret_cast<const uint2*>(da + (size_t)row * C)[g];
             gv[i].x = load_as_f32(&u, 0, da_dtype); gv[i].y = load_as_f32(&u, 1, da_dtype);
             gv[i].z = load_as_f32(&u, 2, da_dtype); gv[i].w = load_as_f32(&u, 3, da_dtype);
+            if (da_dtype == DT_F16) {      // the reference's d(image_features.half()) = fp16(logit_scale * dA), a HALF tensor (lseg_net.py:194 under autograd)
+                gv[i].x = round_f16(scale * gv[i].x); gv[i].y = round_f16(scale * gv[i].y);
+                gv[i].z = round_f16(scale * gv[i].z); gv[i].w = round_f16(scale * gv[i].w);
+            }
             s += xv[i].x * xv[i].x + xv[i].y * xv[i].y + xv[i].z * xv[i].z + xv[i].w * xv[i].w;
             d += xv[i].x * gv[i].x + xv[i].y * gv[i].y + xv[i].z * gv[i].z + xv[i].w * gv[i].w;
         }
     }
     const float n2 = wave_sum(s);
+    const float post = da_dtype == DT_F16 ? 1.f : scale;            // fp16 da: the scale was applied (and rounded) at the load
     const float inv = rsqrtf(n2), proj = wave_sum(d) / n2;          // xh . da / ||x|| = (x . da) / ||x||^2 ... applied to x below
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int g = lane + 64 * i;
         if (g < nv) {
-            const float r[4] = {scale * inv * (gv[i].x - xv[i].x * proj), scale * inv * (gv[i].y - xv[i].y * proj),
-                                scale * inv * (gv[i].z - xv[i].z * proj), scale * inv * (gv[i].w - xv[i].w * proj)};
+            const float r[4] = {post * inv * (gv[i].x - xv[i].x * proj), post * inv * (gv[i].y - xv[i].y * proj),
+                                post * inv * (gv[i].z - xv[i].z * proj), post * inv * (gv[i].w - xv[i].w * proj)};
             uint2 pk;
             pk.x = pack2_dt(r[0], r[1], dx_dtype);
             pk.y = pack2_dt(r[2], r[3], dx_dtype);

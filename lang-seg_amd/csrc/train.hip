@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "engine.h"
@@ -389,8 +390,12 @@ int Engine::forward_train(const float* x_in, int B, float* logits, hipStream_t s
     TRY(launch_gemm(g, DT_F16, st));
     // the text features as the dgrad operand of the correlation: bf16, transposed, K padded to the GEMM's K-step
     const int Kp = (int)up64(K_);
-    TRY(launch_convert(tnorm_, DT_F16, tn16_, DT_BF16, (size_t)K_ * c.out_c, st));
-    TRY(launch_transpose16(tn16_, tnT_, K_, c.out_c, c.out_c, Kp, st));
+    if (cfg.flags & 2) {
+        TRY(launch_convert(tnorm_, DT_F16, tn16_, DT_BF16, (size_t)K_ * c.out_c, st));
+        TRY(launch_transpose16(tn16_, tnT_, K_, c.out_c, c.out_c, Kp, st));
+    } else {
+        TRY(launch_transpose16(tnorm_, tnT_, K_, c.out_c, c.out_c, Kp, st));      // fp16 as it is: the reference's dgrad is a half x half product
+    }
     // output_conv (x2 bilinear) only when the caller wants the logits: the loss and its gradient are taken on the low-resolution ones
     if (logits) TRY(launch_upsample2x_planes(low_, logits, B * K_, h1, w1, st));
     last_low_ = low_; last_kout_ = K_;
@@ -403,6 +408,8 @@ int Engine::forward_train(const float* x_in, int B, float* logits, hipStream_t s
 // split-K plan of a weight-gradient GEMM [M x N] over nk K-steps: enough (tile, K-range) work items to fill the chip twice with
 // 128x128 tiles, ranges of at least 8 K-steps, partials within the workspace.  Fills g.nsplit / g.split_steps; returns the split count.
 int Engine::pick_split(int M, int N, int nk, GemmArgs& g) {
+    static const bool off = getenv("LSEG_NO_SPLITK") != nullptr;        // tools: bisecting switch
+    if (off) return 1;
     const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128);
     long ns = (2L * 256 + tiles - 1) / tiles;
     if (ns > nk / 8) ns = nk / 8;
@@ -634,23 +641,30 @@ int Engine::backward(const float* dlogits, const int64_t* target, int ignore_ind
     const int h1 = 2 * lh_[0], w1 = 2 * lw_[0], hw1 = h1 * w1, Mp1 = B * hw1, Kp = (int)up64(K_);
     const float logit_scale = expf(logf(1.0f / 0.07f));
     if (!acc) TRY(zero_begin(zero_bwd_, st));
+    // The reference back-propagates through `logit_scale * image_features.half() @ text_features.t()` (lseg_net.py:194) in HALF precision:
+    // d(logits) is cast to fp16 (the `.float()` of :196 under autograd), dA = d(logits) @ text_features is an fp16 tensor (fp32
+    // accumulation), and so is logit_scale * dA.  With d(logits) ~ 1 / (valid pixels) these values live in fp16's SUBNORMAL range (step
+    // 2^-24 = 6e-8): a softmax probability below ~3e-8 * N contributes nothing.  The rows, the GEMM and the scale below reproduce exactly
+    // that (fp16 rows, fp16 x fp16 MFMA with fp32 accumulation, fp16 output, fp16 rounding of the scaled value) unless flags bit 1 asks
+    // for the un-rounded gradient.
+    const int hdt = (cfg.flags & 2) ? img_dt_ : DT_F16;
     // ---- loss + x2 upsample^T: the correlation's dY rows ---------------------------------------------------------------------
     if (!dlogits) {      // CrossEntropyLoss(ignore_index) on output_conv(low): one pass for the loss and the per-pixel log-sum-exp, one for the rows
         if (!(loss_target_ == target && loss_ignore_ == ignore_index))      // else: lseg_train_loss left nll_ / lse_px_ of this forward and target
             TRY(launch_seg_stats_ex(low_, target, B, K_, 4 * hw1, ignore_index, counts_, nll_, nullptr, 1, h1, w1, st, lse_px_));
-        TRY(launch_upsample_ce_backward_rows(low_, target, lse_px_, nll_, drows_, B, K_, h1, w1, Kp, ignore_index, img_dt_, st, dev_grad_scale));
+        TRY(launch_upsample_ce_backward_rows(low_, target, lse_px_, nll_, drows_, B, K_, h1, w1, Kp, ignore_index, hdt, st, dev_grad_scale));
         if (dev_loss2) LSEG_HIP_TRY(hipMemcpyAsync(dev_loss2, nll_, 2 * sizeof(double), hipMemcpyDeviceToDevice, st));
     } else {             // autograd hand-over: d(logits) [B,K,2h,2w] given
         LSEG_HIP_TRY(hipMemsetAsync(drows_, 0, (size_t)Mp1 * Kp * 2, st));
-        TRY(launch_upsample2x_planes_backward_rows(dlogits, drows_, B, K_, h1, w1, Kp, img_dt_, st));
+        TRY(launch_upsample2x_planes_backward_rows(dlogits, drows_, B, K_, h1, w1, Kp, hdt, st));
     }
     // ---- head: correlation, L2-norm, head1 -------------------------------------------------------------------------------------
     GemmArgs g;
     gemm_args_init(g);
     g.A = drows_; g.W = tnT_; g.M = Mp1; g.N = c.out_c; g.K = Kp; g.lda = Kp; g.ldw = Kp;
-    g.bias = zeros_; g.C = da_; g.out_dtype = img_dt_; g.ldc = c.out_c; g.map_mode = MAP_LINEAR;
-    TRY(launch_gemm(g, img_dt_, st));
-    TRY(launch_l2norm_scale_backward(da_, img_dt_, feat_, df_, img_dt_, Mp1, c.out_c, logit_scale, st));
+    g.bias = zeros_; g.C = da_; g.out_dtype = hdt; g.ldc = c.out_c; g.map_mode = MAP_LINEAR;
+    TRY(launch_gemm(g, hdt, st));
+    TRY(launch_l2norm_scale_backward(da_, hdt, feat_, df_, img_dt_, Mp1, c.out_c, logit_scale, st));
     TRY(lin_bwd(df_, Mp1, c.out_c, F, path_[0], head1_.wt, dpath0_, grad("scratch.head1.weight", (size_t)c.out_c * F),
                 grad("scratch.head1.bias", c.out_c), acc, st));
     // ---- refinenet1..4, reassemble -------------------------------------------------------------------------------------------
