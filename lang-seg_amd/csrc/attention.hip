@@ -19,6 +19,8 @@
 //     accumulator layout of the first (key = 16*s + 4*(lane>>5) + (j&3) + 8*(j>>2)) is turned
 //     into the standard operand order (8 contiguous keys per lane) by one v_permlane32_swap per
 //     packed word -- no LDS round trip of P -- and V^T is read with conflict-free ds_read_b128.
+#include <cstdlib>
+
 #include "ops.h"
 #include "../../include/lseg_hip.h"
 
@@ -34,15 +36,17 @@ struct AttnArgs {
 
 namespace {
 
-template <typename T>
-__global__ __launch_bounds__(256, 3) void lseg_attention_kernel(const AttnArgs a) {
+// NW waves per workgroup = 32 * NW query rows: 4 for the bulk shapes; 2 when the grid would not fill the chip (B = 1: 8 x 16 workgroups of
+// 4 waves on 256 CUs -> 15 x 16 of 2)
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW, 3) void lseg_attention_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (K 8 KB + Vt 8 KB)
     constexpr int TILE = 8192, STAGE = 2 * TILE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform
     const int hi = lane >> 5, ql = lane & 31;
     const int bh = blockIdx.y;
-    const int q0 = (blockIdx.x * 4 + w) * 32;
+    const int q0 = (blockIdx.x * NW + w) * 32;
     const uint16_t* Q = a.q + (size_t)bh * a.npad * 64;
     const uint16_t* K = a.k + (size_t)bh * a.npad * 64;
     const uint16_t* Vt = a.vt + (size_t)bh * 64 * a.npad;
@@ -59,16 +63,17 @@ __global__ __launch_bounds__(256, 3) void lseg_attention_kernel(const AttnArgs a
 
     int kv_end = a.ntok;
     if (a.causal) {
-        const int qend = (blockIdx.x + 1) * 128;
+        const int qend = (blockIdx.x + 1) * 32 * NW;
         kv_end = qend < a.ntok ? qend : a.ntok;
     }
     const int n_tiles = (kv_end + 63) >> 6;
 
     // per-lane byte offsets of the two K rows / two V^T rows this lane streams per tile (swizzled chunk)
-    uint32_t k_off[2], v_off[2];
+    constexpr int SPW = 8 / NW;                // 8-row slabs of a 64-row tile per wave
+    uint32_t k_off[SPW], v_off[SPW];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const int r = (s * 4 + w) * 8 + (lane >> 3);
+    for (int s = 0; s < SPW; ++s) {
+        const int r = (s * NW + w) * 8 + (lane >> 3);
         const int ch = ((lane & 7) ^ swz(r)) << 3;
         k_off[s] = (uint32_t)(r * 64 + ch) * 2u;
         v_off[s] = (uint32_t)(r * a.npad + ch) * 2u;
@@ -79,9 +84,9 @@ __global__ __launch_bounds__(256, 3) void lseg_attention_kernel(const AttnArgs a
         const char* kb = reinterpret_cast<const char*>(K + (size_t)t * 64 * 64);     // wave-uniform bases
         const char* vb = reinterpret_cast<const char*>(Vt + (size_t)t * 64);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            glds_slab_off(kb, k_off[s], sk + (s * 4 + w) * 1024);
-            glds_slab_off(vb, v_off[s], sv + (s * 4 + w) * 1024);
+        for (int s = 0; s < SPW; ++s) {
+            glds_slab_off(kb, k_off[s], sk + (s * NW + w) * 1024);
+            glds_slab_off(vb, v_off[s], sv + (s * NW + w) * 1024);
         }
     };
 
@@ -225,11 +230,21 @@ int launch_attention_lse(const void* q, const void* k, const void* vt, void* out
     a.lse2 = lse2;
     a.B = B; a.H = H; a.ntok = ntok; a.npad = npad; a.causal = causal;
     a.scale_log2e = scale * 1.4426950408889634f;
-    dim3 grid((ntok + 127) / 128, B * H);
     const size_t lds = 2 * 2 * 8192;
-    if (dtype == DT_BF16) hipLaunchKernelGGL(lseg_attention_kernel<BF16>, grid, dim3(256), lds, stream, a);
-    else if (dtype == DT_F16) hipLaunchKernelGGL(lseg_attention_kernel<F16>, grid, dim3(256), lds, stream, a);
-    else return set_error(LSEG_ERR_INVALID, "attention: dtype %d", dtype);
+    if (dtype != DT_BF16 && dtype != DT_F16) return set_error(LSEG_ERR_INVALID, "attention: dtype %d", dtype);
+    int dev = 0;
+    LSEG_HIP_TRY(hipGetDevice(&dev));
+    static const int force_nw = getenv("LSEG_ATTN_WAVES") ? atoi(getenv("LSEG_ATTN_WAVES")) : 0;      // tools: 2 | 4
+    const bool narrow = force_nw ? force_nw == 2 : ((long)((ntok + 127) / 128) * B * H < 2L * device_cu_count(dev) && !causal);
+    if (narrow) {
+        dim3 grid((ntok + 63) / 64, B * H);
+        if (dtype == DT_BF16) hipLaunchKernelGGL((lseg_attention_kernel<BF16, 2>), grid, dim3(128), lds, stream, a);
+        else hipLaunchKernelGGL((lseg_attention_kernel<F16, 2>), grid, dim3(128), lds, stream, a);
+    } else {
+        dim3 grid((ntok + 127) / 128, B * H);
+        if (dtype == DT_BF16) hipLaunchKernelGGL((lseg_attention_kernel<BF16, 4>), grid, dim3(256), lds, stream, a);
+        else hipLaunchKernelGGL((lseg_attention_kernel<F16, 4>), grid, dim3(256), lds, stream, a);
+    }
     LSEG_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -73,6 +73,109 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const void* in, int in_d
     }
 }
 
+// ---- residual update + LayerNorm behind a split-K GEMM (small batches: engine.hip "split-K residual GEMMs") ----------------------------
+// x[row] += bias + sum_s part[s * stride + row * D ...] (fixed order: deterministic), written back to the fp32 residual stream, then
+// LayerNorm of the updated row (gamma == NULL: update only).  One wave per row like layernorm_kernel.
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_reduce_kernel(float* __restrict__ x, const float* __restrict__ part, int nsplit, size_t stride,
+                                                               const float* __restrict__ bias, const float* gamma, const float* beta,
+                                                               void* out, int out_dtype, int M, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = D >> 2;
+    float4 v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int g = lane + 64 * i;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g < nv) {
+            float4 a = reinterpret_cast<const float4*>(x + (size_t)row * D)[g];
+            const float4 b = reinterpret_cast<const float4*>(bias)[g];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            for (int sp = 0; sp < nsplit; ++sp) {
+                const float4 p = reinterpret_cast<const float4*>(part + (size_t)sp * stride + (size_t)row * D)[g];
+                a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+            }
+            reinterpret_cast<float4*>(x + (size_t)row * D)[g] = a;
+            v[i] = a;
+            s += a.x + a.y + a.z + a.w;
+        }
+    }
+    if (!gamma) return;
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int g = lane + 64 * i;
+        if (g < nv) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += a * a + b * b + c * c + d * d;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int g = lane + 64 * i;
+        if (g < nv) {
+            const float4 ga = reinterpret_cast<const float4*>(gamma)[g];
+            const float4 be = reinterpret_cast<const float4*>(beta)[g];
+            const float y[4] = {(v[i].x - mean) * rstd * ga.x + be.x, (v[i].y - mean) * rstd * ga.y + be.y,
+                                (v[i].z - mean) * rstd * ga.z + be.z, (v[i].w - mean) * rstd * ga.w + be.w};
+            uint2 pk;
+            pk.x = pack2_dt(y[0], y[1], out_dtype);
+            pk.y = pack2_dt(y[2], y[3], out_dtype);
+            reinterpret_cast<uint2*>((uint16_t*)out + (size_t)row * D)[g] = pk;
+        }
+    }
+}
+
+// ---- epilogue of a split-K 3x3 conv (engine.hip conv3x3, small batches): sum the fp32 partial slabs [ns][B*Ho*Wo][C], add the bias, optional
+// ReLU, optional skip inputs (padded NHWC, like the output), write the padded-NHWC map and optionally its ReLU copy.  8 channels per thread.
+__global__ void conv_reduce_pad_kernel(const float* __restrict__ part, int ns, size_t stride, const float* __restrict__ bias,
+                                       const uint16_t* __restrict__ res, const uint16_t* __restrict__ res2, uint16_t* __restrict__ out,
+                                       uint16_t* __restrict__ out_relu, int B, int Ho, int Wo, int C, int relu, int dtype) {
+    const int c8n = C >> 3;
+    const size_t total = (size_t)B * Ho * Wo * c8n;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c8n) * 8;
+        const size_t m = i / c8n;
+        const int x = (int)(m % Wo), y = (int)((m / Wo) % Ho), b = (int)(m / ((size_t)Wo * Ho));
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = bias ? bias[c + k] : 0.f;
+        for (int sp = 0; sp < ns; ++sp) {
+            const float4 a = *reinterpret_cast<const float4*>(part + (size_t)sp * stride + m * C + c);
+            const float4 d = *reinterpret_cast<const float4*>(part + (size_t)sp * stride + m * C + c + 4);
+            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += d.x; v[5] += d.y; v[6] += d.z; v[7] += d.w;
+        }
+        if (relu) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = v[k] > 0.f ? v[k] : 0.f;
+        }
+        const size_t o = (((size_t)b * (Ho + 2) + y + 1) * (Wo + 2) + x + 1) * C + c;
+        if (res) {
+            const uint4 u = *reinterpret_cast<const uint4*>(res + o);
+            const uint16_t* e = reinterpret_cast<const uint16_t*>(&u);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += load_as_f32(e, k, dtype);
+            if (res2) {
+                const uint4 u2 = *reinterpret_cast<const uint4*>(res2 + o);
+                const uint16_t* e2 = reinterpret_cast<const uint16_t*>(&u2);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] += load_as_f32(e2, k, dtype);
+            }
+        }
+        const uint4 pk = make_uint4(pack2_dt(v[0], v[1], dtype), pack2_dt(v[2], v[3], dtype), pack2_dt(v[4], v[5], dtype), pack2_dt(v[6], v[7], dtype));
+        *reinterpret_cast<uint4*>(out + o) = pk;
+        if (out_relu) {     // the same rounding first, then the sign test (identical to the GEMM epilogue's ReLU copy)
+            auto rl = [](uint32_t w) { return ((w & 0x8000u) ? 0u : (w & 0xffffu)) | ((w & 0x80000000u) ? 0u : (w & 0xffff0000u)); };
+            *reinterpret_cast<uint4*>(out_relu + o) = make_uint4(rl(pk.x), rl(pk.y), rl(pk.z), rl(pk.w));
+        }
+    }
+}
+
 // ---- patch im2col: x fp32 NCHW -> A [B*gh*gw, 3*P*P] (k = c*P*P + i*P + j), lseg_vit.py:179 ------
 __global__ void im2col_patch_kernel(const float* x, uint16_t* A, int B, int H, int W, int P, int dtype) {
     const int gh = H / P, gw = W / P, Kd = 3 * P * P;
@@ -1842,6 +1945,24 @@ int launch_layernorm(const void* in, int in_dtype, const float* gamma, const flo
     else if (D <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, dim3(blocks), dim3(256), 0, st, in, in_dtype, gamma, beta, out, out_dtype, M, D, eps);
     else if (D <= 1024) hipLaunchKernelGGL(layernorm_kernel<4>, dim3(blocks), dim3(256), 0, st, in, in_dtype, gamma, beta, out, out_dtype, M, D, eps);
     else hipLaunchKernelGGL(layernorm_kernel<8>, dim3(blocks), dim3(256), 0, st, in, in_dtype, gamma, beta, out, out_dtype, M, D, eps);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_conv_reduce_pad(const float* part, int ns, size_t stride, const float* bias, const void* res, const void* res2, void* out, void* out_relu,
+                           int B, int Ho, int Wo, int C, int relu, int dtype, hipStream_t st) {
+    if (C % 8) return set_error(LSEG_ERR_UNSUPPORTED, "conv_reduce_pad: C=%d must be a multiple of 8", C);
+    hipLaunchKernelGGL(conv_reduce_pad_kernel, dim3(grid_for((size_t)B * Ho * Wo * (C / 8))), dim3(256), 0, st, part, ns, stride, bias,
+                       (const uint16_t*)res, (const uint16_t*)res2, (uint16_t*)out, (uint16_t*)out_relu, B, Ho, Wo, C, relu, dtype);
+    CHECK_LAUNCH();
+    return 0;
+}
+int launch_layernorm_reduce(float* x, const float* part, int nsplit, size_t stride, const float* bias, const float* gamma, const float* beta,
+                            void* out, int out_dtype, int M, int D, float eps, hipStream_t st) {
+    if (D % 4 != 0 || D > 64 * 4 * 8 || out_dtype == DT_F32) return set_error(LSEG_ERR_UNSUPPORTED, "layernorm_reduce: D=%d / 16-bit output only", D);
+    const int blocks = (M + 3) / 4;
+#define LNR(V) hipLaunchKernelGGL(layernorm_reduce_kernel<V>, dim3(blocks), dim3(256), 0, st, x, part, nsplit, stride, bias, gamma, beta, out, out_dtype, M, D, eps)
+    if (D <= 256) LNR(1); else if (D <= 512) LNR(2); else if (D <= 1024) LNR(4); else LNR(8);
+#undef LNR
     CHECK_LAUNCH();
     return 0;
 }

@@ -125,6 +125,8 @@ private:
     std::map<const void*, size_t> plane_;       // 16-bit buffer -> element offset of its lo plane
     size_t pl(const void* p) const { auto it = plane_.find(p); return it == plane_.end() ? 0 : it->second; }
     int igemm(GemmArgs& g, hipStream_t st);     // image-tower GEMM: fills the split-precision planes when strict_
+    int split_residual(GemmArgs& g, int M, int N, int K);
+    float* ws_split_ = nullptr; size_t ws_split_rows_ = 0;
     float* pack_tmp_ = nullptr; size_t pack_tmp_n_ = 0;
     uint16_t* relu_tmp_ = nullptr;
     int pack_tmp(size_t n, hipStream_t st);

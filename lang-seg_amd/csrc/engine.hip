@@ -108,6 +108,8 @@ int Engine::init() {
     const size_t B = c.max_batch, D = c.dim, F = c.features;
     const size_t M = B * ntok_;
     ALLOC(x_, float, M * D);
+    ws_split_rows_ = 8192;                              // split-K partial slabs of the residual GEMMs at small batches (forward(): "split-K")
+    ALLOC(ws_split_, float, ws_split_rows_ * D);
     ALLOC16(ln_, M * D);
     ALLOC16(q_, B * c.heads * npad_ * 64);
     ALLOC16(k_, B * c.heads * npad_ * 64);
@@ -510,6 +512,31 @@ int Engine::conv3x3(const void* in, const Lin& w, const void* res, const void* r
     if (res) { g.res_mode = RES_DEST; g.res = res; g.res_dtype = img_dt_; g.res2 = res2; }
     g.C = out; g.out_dtype = img_dt_; g.ldc = w.n; g.map_mode = MAP_PADDED;
     if (relu_written) *relu_written = false;
+    // Small batches: the deep levels of the pyramid are a handful of tiles with a 36..144-step contraction (layer3_rn at B = 1: 60 tiles of
+    // 64 x 64, K = 9216, 95 us on a quarter of the chip).  Split-K work items into fp32 slabs + one streaming epilogue kernel.
+    static const int split_on = getenv("LSEG_SPLITK") ? atoi(getenv("LSEG_SPLITK")) : 1;
+    if (split_on && !train_mode && !strict_ && !relu_in && (w.n % 64) == 0) {
+        const int nk = w.k / 64;
+        const long tiles = (long)((g.M + 63) / 64) * (w.n / 64);
+        long ns = 512 / tiles;
+        if (ns > nk / 8) ns = nk / 8;
+        if (ns > 8) ns = 8;
+        while (ns > 1 && (size_t)ns * g.M * w.n > ws_split_rows_ * (size_t)cfg.dim) --ns;
+        if (ns >= 2) {
+            const int steps = (int)((nk + ns - 1) / ns);
+            ns = (nk + steps - 1) / steps;
+        }
+        if (ns >= 2) {
+            GemmArgs p = g;
+            p.bias = nullptr; p.act = ACT_NONE; p.res_mode = RES_NONE; p.res = nullptr; p.res2 = nullptr;
+            p.C = ws_split_; p.out_dtype = DT_F32; p.ldc = w.n; p.map_mode = MAP_LINEAR;
+            p.nsplit = (int)ns; p.split_steps = (nk + (int)ns - 1) / (int)ns; p.c_split_stride = (size_t)g.M * w.n;
+            TRY(launch_gemm(p, img_dt_, st));
+            TRY(launch_conv_reduce_pad(ws_split_, (int)ns, p.c_split_stride, w.b, res, res2, out, out_relu, B, Ho, Wo, w.n, relu_out, img_dt_, st));
+            if (relu_written) *relu_written = out_relu != nullptr;
+            return 0;
+        }
+    }
     if (out_relu && !strict_ && gemm_epilogue_is_pad16(g, img_dt_)) {       // also keep ReLU(out): the next unit's conv input
         g.C_relu = out_relu;
         if (relu_written) *relu_written = true;
@@ -620,6 +647,39 @@ int Engine::get_profile(const char* family, double* ms, int64_t* launches, doubl
     return 0;
 }
 
+// Split-K for the two GEMMs that add into the fp32 residual stream (attn.proj K = D, mlp.fc2 K = 4D; N = D) when the batch is small:
+// at B = 1 their 901 x 1024 output is 64 tiles of 128 x 128 on 256 CUs, and the K = 4096 contraction runs 64 K-steps deep on a
+// quarter of the chip.  The K range is cut into ns work items per tile (>= 4 K-steps each, ~2 resident workgroups per CU in total);
+// each writes an fp32 partial slab (EPI_PART32), and the LayerNorm that follows anyway adds bias + slabs into x_ in a fixed order
+// (launch_layernorm_reduce) -- no extra launch, no atomics, deterministic.  Returns ns (0: the GEMM was left as it is).
+int Engine::split_residual(GemmArgs& g, int M, int N, int K) {
+    static const int enabled = getenv("LSEG_SPLITK") ? atoi(getenv("LSEG_SPLITK")) : 1;      // tools: 0 switches it off
+    if (strict_ || !enabled || (N % 256) != 0) return 0;
+    // Tile and split factor together, from measured per-K-step costs of the two tile shapes (us per 64-deep K-step of one work item on
+    // one CU: 256x256 2.07, 128x128 0.87, 0.81 with two work items resident; ~4 K-steps of fixed cost per item; tools/step_probe.py
+    // sweeps): a CU works through ceil(items / CUs) items; the slabs cost the LayerNorm ns * M * N * 4 bytes at ~4 TB/s.
+    const int nk = K / 64, cus = device_cu_count(device);
+    const long t_mid = (long)((M + 127) / 128) * (N / 128), t_huge = (long)((M + 255) / 256) * (N / 256);
+    double best = 1e30; int best_ns = 1, best_tile = 0;
+    for (int tile = 2; tile <= 6; tile += 4) {
+        for (int ns = 1; ns <= 8; ns *= 2) {
+            if (ns > 1 && (nk / ns < 4 || (size_t)ns * M > ws_split_rows_)) break;
+            const long items = (tile == 2 ? t_mid : t_huge) * ns;
+            const long per_cu = (items + cus - 1) / cus;
+            const double step_us = tile == 2 ? (per_cu >= 2 ? 0.81 : 0.87) : 2.07;
+            const double cost = per_cu * ((double)nk / ns + 4.0) * step_us + (ns > 1 ? (double)ns * M * N * 4.0 / 4.0e6 : 0.0);
+            if (cost < best * 0.97) { best = cost; best_ns = ns; best_tile = tile; }       // a split must buy >= 3 %
+        }
+    }
+    if (best_ns < 2) return 0;                      // unsplit: leave the launch (and its tile choice) to the GEMM's own model
+    const int steps = (nk + best_ns - 1) / best_ns;
+    const int ns = (nk + steps - 1) / steps;
+    if (ns < 2) return 0;
+    g.bias = nullptr; g.res_mode = RES_NONE; g.res = nullptr;
+    g.C = ws_split_; g.nsplit = ns; g.split_steps = steps; g.c_split_stride = (size_t)M * N; g.tile_hint = best_tile;
+    return ns;
+}
+
 int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out, hipStream_t st) {
     if (!finalized_) return set_error(LSEG_ERR_STATE, "parameters not finalised (call lseg_finalize_params)");
     if (K_ < 1) return set_error(LSEG_ERR_STATE, "no text tokens set (call lseg_set_text_tokens)");
@@ -661,10 +721,13 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
     TRY(launch_cls_rows(cls_, pos_, x_, B, ntok_, D, st));
 
     // ---- 24 x timm Block; hooks feed readout/reassemble/layer_rn immediately ------------------------------
+    int pend_ns = 0;                    // > 0: x_ still lacks `pend_bias` + the pend_ns split-K slabs in ws_split_ (see split_residual)
+    const float* pend_bias = nullptr;
     for (int i = 0; i < c.depth; ++i) {
         VitBlock& b = blocks_[i];
         hipEvent_t pe = prof_begin(PF_LN, st);
         if (strict_) TRY(launch_ln_split(x_, b.g1, b.b1, ln_, pl(ln_), M, D, 1e-6f, st));
+        else if (pend_ns) { TRY(launch_layernorm_reduce(x_, ws_split_, pend_ns, (size_t)M * D, pend_bias, b.g1, b.b1, ln_, img_dt_, M, D, 1e-6f, st)); pend_ns = 0; }
         else TRY(launch_layernorm(x_, DT_F32, b.g1, b.b1, ln_, img_dt_, M, D, 1e-6f, st));
         prof_end(PF_LN, pe, 0.0, st);
         gemm_args_init(g);
@@ -682,11 +745,14 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
         g.A = att_; g.W = b.proj.w; g.M = M; g.N = D; g.K = D; g.lda = D; g.ldw = D;
         g.bias = b.proj.b; g.res_mode = RES_DEST; g.res = x_; g.res_dtype = DT_F32;
         g.C = x_; g.out_dtype = DT_F32; g.ldc = D; g.map_mode = MAP_LINEAR;
+        pend_ns = split_residual(g, M, D, D);                 // small batches: partial slabs, summed into x_ by the LayerNorm that follows
+        pend_bias = b.proj.b;
         pe = prof_begin(PF_PROJ, st);
         TRY(igemm(g, st));
         prof_end(PF_PROJ, pe, 2.0 * M * (double)D * D, st);
         pe = prof_begin(PF_LN, st);
         if (strict_) TRY(launch_ln_split(x_, b.g2, b.b2, ln_, pl(ln_), M, D, 1e-6f, st));
+        else if (pend_ns) { TRY(launch_layernorm_reduce(x_, ws_split_, pend_ns, (size_t)M * D, pend_bias, b.g2, b.b2, ln_, img_dt_, M, D, 1e-6f, st)); pend_ns = 0; }
         else TRY(launch_layernorm(x_, DT_F32, b.g2, b.b2, ln_, img_dt_, M, D, 1e-6f, st));
         prof_end(PF_LN, pe, 0.0, st);
         gemm_args_init(g);
@@ -700,9 +766,18 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
         g.A = mlp_; g.W = b.fc2.w; g.M = M; g.N = D; g.K = 4 * D; g.lda = 4 * D; g.ldw = 4 * D;
         g.bias = b.fc2.b; g.res_mode = RES_DEST; g.res = x_; g.res_dtype = DT_F32;
         g.C = x_; g.out_dtype = DT_F32; g.ldc = D; g.map_mode = MAP_LINEAR;
+        pend_ns = split_residual(g, M, D, 4 * D);
+        pend_bias = b.fc2.b;
         pe = prof_begin(PF_FC2, st);
         TRY(igemm(g, st));
         prof_end(PF_FC2, pe, 2.0 * M * 4.0 * D * D, st);
+        // the slabs are normally summed by the next block's LayerNorm; a hooked block (the readout reads x_) and the last one need x_ now
+        bool hooked = i + 1 == c.depth;
+        for (int l = 0; l < 4; ++l) hooked = hooked || c.hooks[l] == i;
+        if (pend_ns && hooked) {
+            TRY(launch_layernorm_reduce(x_, ws_split_, pend_ns, (size_t)M * D, pend_bias, nullptr, nullptr, ln_, img_dt_, M, D, 1e-6f, st));
+            pend_ns = 0;
+        }
 
         for (int l = 0; l < 4; ++l) {
             if (c.hooks[l] != i) continue;

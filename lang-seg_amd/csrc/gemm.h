@@ -68,6 +68,7 @@ struct GemmArgs {
     // whose operand bytes per flop are twice as high on the per-CU L2->LDS path.  Needs bias == NULL, no residual, MAP_LINEAR.
     int nsplit, split_steps;
     size_t c_split_stride;
+    int tile_hint;              // 0: the launcher's cost model picks the tile; 2 = 128x128, 6 = 256x256 (callers that plan tile and split-K together)
 };
 
 void gemm_args_init(GemmArgs& g);

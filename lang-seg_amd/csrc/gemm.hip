@@ -381,6 +381,8 @@ enum Epi {
     EPI_PAD16 = 5,        // MAP_PADDED NHWC (1-pixel zero border), T(act(acc + bias) [+ res [+ res2]]): the DPT head's 3x3 convs
     EPI_LIN16_F16 = 6,    // MAP_LINEAR, C = fp16(acc + bias) from bf16 operands: the commuted head's g (the fp16 operand of the correlation)
     EPI_PIX16 = 7,        // MAP_PIXSHUF, T(acc + bias[n % C]): ConvTranspose2d(k = s) as a GEMM whose columns scatter to the s x s sub-pixels
+    EPI_PART32 = 8,       // split-K partial slab: C[split * c_split_stride + m*ldc + n] = acc, fp32, no bias (weight gradients; the residual GEMMs
+                          // of small batches, whose slabs the following LayerNorm sums into the fp32 residual stream)
 };
 
 // two adjacent 16-column sub-tiles (4 columns per lane each) -> 8 contiguous columns (16 bytes) per lane
@@ -397,7 +399,7 @@ __device__ __forceinline__ uint4 widen16(const float (&x)[4], const float (&y)[4
 // mrow0 + j*16 + (lane&15), columns ncol0 + i*16 + (lane>>4)*4 .. +3.
 template <typename T, int EPI, int MI, int NI>
 __device__ __forceinline__ void fast_epilogue(const GemmArgs& g, f32x4_t (&acc)[NI][MI], int mrow0, int ncol0, int lane,
-                                              const float4 (&bias)[NI]) {
+                                              const float4 (&bias)[NI], size_t c_extra) {
     const int r16 = lane >> 4, ml = lane & 15;
     const int cw = (r16 & 1) * 16 + (r16 >> 1) * 8;       // lane's 8 columns inside a 32-column pair after the swap
     auto biased = [&](auto ic, auto jc, float (&v)[4]) {
@@ -455,6 +457,17 @@ __device__ __forceinline__ void fast_epilogue(const GemmArgs& g, f32x4_t (&acc)[
                         *reinterpret_cast<float4*>(p + i * 16) =
                             make_float4(v[0] + rv[jl][i].x, v[1] + rv[jl][i].y, v[2] + rv[jl][i].z, v[3] + rv[jl][i].w);
                 });
+            });
+        });
+    } else if constexpr (EPI == EPI_PART32) {
+        float* cbase = (float*)g.C + c_extra + ncol0 + r16 * 4;
+        static_for<0, MI>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int m = mrow0 + j * 16 + ml;
+            float* p = cbase + (size_t)m * g.ldc;
+            static_for<0, NI>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if (m < g.M) *reinterpret_cast<float4*>(p + i * 16) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
             });
         });
     } else if constexpr (EPI == EPI_PAD16) {
@@ -902,7 +915,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
             int mbc, nbc;
             tile_coords(tile % per_split, tiles_m, tiles_n, mbc, nbc, g.group_m);
             pm0 = mbc * BM; pn0 = nbc * BN;
-            if constexpr (EPI != EPI_GENERIC && BIAS_PREFETCH) {
+            if constexpr (EPI != EPI_GENERIC && EPI != EPI_PART32 && BIAS_PREFETCH) {
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
                     biasv[i] = *reinterpret_cast<const float4*>(g.bias + (EPI == EPI_PIX16 ? (pn0 + wn * WN + i * 16) % g.ps_C : pn0 + wn * WN + i * 16) + (lane >> 4) * 4);
@@ -970,12 +983,13 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
                 });
             });
         } else if constexpr (EPI != EPI_GENERIC) {
-            if constexpr (!BIAS_PREFETCH) {       // 128-accumulator tiles have no registers to spare across the K-loop
+            if constexpr (!BIAS_PREFETCH && EPI != EPI_PART32) {       // 128-accumulator tiles have no registers to spare across the K-loop
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
                     biasv[i] = *reinterpret_cast<const float4*>(g.bias + (EPI == EPI_PIX16 ? (n0c + wn * WN + i * 16) % g.ps_C : n0c + wn * WN + i * 16) + (lane >> 4) * 4);
             }
-            fast_epilogue<T, EPI, MI, NI>(g, acc, m0c + wm * WM, n0c + wn * WN, lane, biasv);
+            fast_epilogue<T, EPI, MI, NI>(g, acc, m0c + wm * WM, n0c + wn * WN, lane, biasv,
+                                          nsplit > 1 ? (size_t)(tile / per_split) * g.c_split_stride : 0);
         } else {
         int ncol[NI];
         ColPart cp[NI], cpw[NI / 2];
@@ -1048,7 +1062,7 @@ int pick_tile(const GemmArgs& g, hipStream_t stream) {
         // 256x256 tiles (one 8-wave workgroup per CU) move half the operand bytes per MFMA through the
         // CU's L1/LDS-DMA path and run ~12% faster per flop than two 128x128 workgroups -- when the
         // tile count quantises well over the 256 CUs.  Persistent schedules: ceil(tiles / slots) rounds.
-        const long t_huge = (long)((g.M + 255) / 256) * ((g.N + 255) / 256);
+        const long t_huge = (long)((g.M + 255) / 256) * ((g.N + 255) / 256) * (g.nsplit > 1 ? g.nsplit : 1);
         const double time_huge = (double)((t_huge + 255) / 256) * 4.0 / 1.12;
         const double time_mid = (double)((t_mid + 511) / 512) * 2.0;
         if (time_huge < time_mid) pick = 6;
@@ -1057,6 +1071,7 @@ int pick_tile(const GemmArgs& g, hipStream_t stream) {
         static const int res32_mid = getenv("LSEG_RES32_MID") ? atoi(getenv("LSEG_RES32_MID")) : 0;
         if (res32_mid && EPI == EPI_RES32 && g.K <= res32_mid) pick = 2;
     }
+    if (g.tile_hint == 2 || g.tile_hint == 6) pick = g.tile_hint;
     if (force) pick = force;
     if (pick == 6 && (g.N % 256) != 0) pick = 2;      // the specialised epilogues write whole tile rows: N must be a multiple of BN
     if constexpr (EPI != EPI_GENERIC) {
@@ -1072,6 +1087,10 @@ template <typename T>
 int select_epi(const GemmArgs& g) {
     constexpr int dt = std::is_same<T, BF16>::value ? DT_BF16 : DT_F16;
     static const bool off = getenv("LSEG_GEMM_GENERIC_EPI") != nullptr;       // A/B switch (tools)
+    if (!off && g.nsplit > 1 && !g.split && !(g.dbg & 3) && !g.bias && !g.round_mid && (g.N % 128) == 0 && g.map_mode == MAP_LINEAR &&
+        g.res_mode == RES_NONE && g.act == ACT_NONE && g.out_dtype == DT_F32 && (g.ldc % 4) == 0 && (g.c_split_stride % 4) == 0 &&
+        !(reinterpret_cast<uintptr_t>(g.C) & 15) && !(g.conv && g.relu_in))
+        return EPI_PART32;
     if (off || g.split || g.nsplit > 1 || (g.dbg & 3) || !g.bias || g.round_mid || (g.N % 128) != 0) return EPI_GENERIC;
     if (g.map_mode == MAP_PIXSHUF && !g.conv && g.bias_mod == g.ps_C && (g.ps_C % 32) == 0 && g.N == g.ps_s * g.ps_s * g.ps_C && g.out_dtype == dt &&
         g.res_mode == RES_NONE && g.act == ACT_NONE && !(reinterpret_cast<uintptr_t>(g.C) & 15) && !(reinterpret_cast<uintptr_t>(g.bias) & 15))
@@ -1111,6 +1130,7 @@ int dispatch(const GemmArgs& g, hipStream_t stream) {
     }
     const int epi = select_epi<T>(g);
     if (g.conv) {
+        if (epi == EPI_PART32) return pick_tile<T, true, false, EPI_PART32, 0>(g, stream);
         if (epi == EPI_PAD16) {
             if (g.relu_in) return pick_tile<T, true, true, EPI_PAD16, 0>(g, stream);
             return pick_tile<T, true, false, EPI_PAD16, 0>(g, stream);
@@ -1130,6 +1150,7 @@ int dispatch(const GemmArgs& g, hipStream_t stream) {
         case EPI_LIN16_F16: return pick_tile<T, false, false, EPI_LIN16_F16, 0>(g, stream);
         case EPI_PIX16: return pick_tile<T, false, false, EPI_PIX16, 0>(g, stream);
         case EPI_QKV16: return pick_tile<T, false, false, EPI_QKV16, 0>(g, stream);
+        case EPI_PART32: return pick_tile<T, false, false, EPI_PART32, 0>(g, stream);
         default: return pick_tile<T, false, false, EPI_GENERIC, 0>(g, stream);
     }
 }

@@ -10,6 +10,12 @@ int launch_attention(const void* q, const void* k, const void* vt, void* out, in
 
 int launch_layernorm(const void* in, int in_dtype, const float* gamma, const float* beta, void* out, int out_dtype,
                      int M, int D, float eps, hipStream_t st);
+// x += bias + sum of `nsplit` split-K partial slabs (`stride` floats apart), then LayerNorm of the updated rows (gamma NULL: update only)
+int launch_layernorm_reduce(float* x, const float* part, int nsplit, size_t stride, const float* bias, const float* gamma, const float* beta,
+                            void* out, int out_dtype, int M, int D, float eps, hipStream_t st);
+// epilogue of a split-K 3x3 conv: sum of `ns` fp32 slabs [B*Ho*Wo, C] + bias, ReLU, skip inputs -> padded NHWC map (+ its ReLU copy)
+int launch_conv_reduce_pad(const float* part, int ns, size_t stride, const float* bias, const void* res, const void* res2, void* out, void* out_relu,
+                           int B, int Ho, int Wo, int C, int relu, int dtype, hipStream_t st);
 int launch_im2col_patch(const float* x, void* A, int B, int H, int W, int P, int dtype, hipStream_t st);
 int launch_pos_resize(const float* pos, float* out, int g_old, int gh, int gw, int D, hipStream_t st);
 int launch_cls_rows(const float* cls, const float* pos, float* x, int B, int ntok, int D, hipStream_t st);

@@ -265,7 +265,7 @@ def test_zero_shot_network_matches_oracle_and_golden(golden_dir):
     assert (out.cpu() - ref).abs().max().item() <= LOGIT_TOL
     assert (out.cpu() - g["logits"]).abs().max().item() <= LOGIT_TOL
     # same numbers as the shared-label path run on each image alone with its pair
-    eng = HipEngine(cfg, 64, 64, max_batch=1, max_labels=2)
+    eng = HipEngine(cfg, 64, 64, max_batch=1, max_labels=2, image_dtype=net.image_dtype)      # the class default (fp16), not HipEngine's (bf16)
     eng.load_state_dict(sd)
     for b in range(x.shape[0]):
         eng.set_tokens(tok[2 * b:2 * b + 2])
@@ -498,3 +498,40 @@ def test_module_metrics_path_needs_no_logits():
     for k in ("area_inter", "area_pred", "area_lab", "area_union"):
         assert torch.equal(full[k], fused[k]), k
     assert abs(full["nll_sum"] - fused["nll_sum"]) <= 1e-6 * abs(full["nll_sum"])
+
+
+def test_split_k_residual_gemms_at_small_batch_equal_the_unsplit_schedule(tmp_path):
+    """B = 1 at the BASELINE shape: attn.proj / mlp.fc2 run as split-K work items whose fp32 partial slabs the following LayerNorm sums
+    into the residual stream (engine.hip split_residual).  Same logits as the unsplit schedule (LSEG_SPLITK=0, read once per
+    process -> a second interpreter) up to fp32 summation order; and the partial sums are deterministic (two runs bit-equal)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from lseg_hip.config import get_config; from lseg_hip.engine import HipEngine\n"
+        "from lseg_hip.synth import synthetic_state_dict, synthetic_tokens, synthetic_images, read_labels\n"
+        "cfg = get_config('clip_vitl16_384'); sd = synthetic_state_dict(cfg, seed=0)\n"
+        "tok = synthetic_tokens(read_labels(%r)[:7], cfg.text.vocab, cfg.text.ctx)\n"
+        "outs = []\n"
+        "for B in (1, 2):\n"
+        "    eng = HipEngine(cfg, 160, 160, max_batch=B, max_labels=7, image_dtype='fp16'); eng.load_state_dict(sd); eng.set_tokens(tok)\n"
+        "    x = synthetic_images(B, 160, 160, seed=1).cuda()\n"
+        "    a = eng.forward(x).clone(); b = eng.forward(x); torch.cuda.synchronize()\n"
+        "    assert torch.equal(a, b)\n"
+        "    outs.append(a.cpu())\n"
+        "torch.save(outs, sys.argv[1])\n"
+    ) % (os.path.join(root, "lang-seg_amd"), root, MG.LABELS)
+    res = {}
+    for tag, target in (("split", None), ("plain", "0")):
+        env = dict(os.environ)
+        env.pop("LSEG_SPLITK", None)
+        if target is not None:
+            env["LSEG_SPLITK"] = target
+        out = str(tmp_path / (tag + ".pt"))
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=600)
+        res[tag] = torch.load(out)
+    for a, b in zip(res["split"], res["plain"]):
+        assert a.shape == b.shape and torch.isfinite(a).all()
+        d = (a - b).abs().max().item()
+        assert 0 < d <= 2e-2, d          # > 0: the split schedule really ran (101 tokens x 1024: 8 tiles -> 4 / 8 K-ranges); tiny: fp32 order + fp16 re-rounding

