@@ -105,6 +105,15 @@ class BPETokenizer:
         return ids
 
 
+    def decode(self, ids: Sequence[int]) -> str:
+        """[3P] SimpleTokenizer.decode: vocabulary strings joined, byte table inverted, '</w>' -> ' '."""
+        if not hasattr(self, "dec"):
+            self.dec = {i: v for v, i in self.enc.items()}
+            self.u2b = {u: b for b, u in self.b2u.items()}
+        text = "".join(self.dec[int(i)] for i in ids)
+        return bytearray(self.u2b[c] for c in text).decode("utf-8", errors="replace").replace("</w>", " ")
+
+
 _bpe = None
 
 

@@ -78,3 +78,43 @@ def test_text_normalisation(tok):
     assert t.encode("  Tree   HOUSE ") == t.encode("tree") + t.encode("house")     # lower-case, collapsed whitespace
     assert t.encode("tree&amp;house") == t.encode("tree") + t.encode("&") + t.encode("house")   # html.unescape
     assert t.encode("") == []
+
+
+def test_decode_inverts_encode(tok):
+    t, _ = tok
+    for text in ("tree house", "windowpanes & sky", "a"):
+        assert t.decode(t.encode(text)).strip() == text
+
+
+# ---- real CLIP vocabulary (bpe_simple_vocab_16e6.txt.gz): runs where the file is available (LSEG_BPE_VOCAB or next to the package) ----
+def _real_vocab():
+    from lseg_hip import tokenizer as T
+    return T._vocab_path()
+
+
+@pytest.mark.skipif(_real_vocab() is None, reason="CLIP's bpe_simple_vocab_16e6.txt.gz is not on this machine (no network); set LSEG_BPE_VOCAB")
+def test_real_clip_vocabulary_known_answers_and_the_150_ade_labels():
+    """`clip.tokenize` (lseg_net.py:158,163-164) on the real vocabulary: published known-answer ids (CLIP / HF CLIPTokenizer documentation
+    examples) and structural checks on the 150 ADE20K label strings the reference feeds it (lseg_module.py:97-109)."""
+    import torch
+    from lseg_hip.tokenizer import BPETokenizer, tokenize
+    from lseg_hip.synth import read_labels
+    tok = BPETokenizer(_real_vocab())
+    SOT, EOT = 49406, 49407
+    assert tok.enc["<|startoftext|>"] == SOT and tok.enc["<|endoftext|>"] == EOT and len(tok.enc) == 49408
+    known = {"a photo of a cat": [320, 1125, 539, 320, 2368], "a diagram": [320, 22697], "a dog": [320, 1929], "a cat": [320, 2368]}
+    for text, ids in known.items():
+        assert tok.encode(text) == ids, (text, tok.encode(text))
+    assert tok.encode("A  Photo\nof a CAT ") == known["a photo of a cat"]          # lower-casing, whitespace collapsing
+    labels = read_labels(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lang-seg_amd", "label_files",
+                                      "ade20k_objectInfo150.txt"))
+    assert len(labels) == 150
+    t = tokenize(labels, 77, 49408)
+    assert t.shape == (150, 77) and t.dtype == torch.int64
+    assert (t[:, 0] == SOT).all()
+    eot = t.argmax(dim=-1)                                   # encode_text pools at the row maximum = the EOT position
+    assert (t[torch.arange(150), eot] == EOT).all() and (eot >= 2).all() and (eot <= 8).all()
+    for k in range(150):
+        assert (t[k, eot[k] + 1:] == 0).all() and (t[k, 1:eot[k]] < SOT).all() and (t[k, 1:eot[k]] >= 0).all()
+        assert tok.decode(t[k, 1:eot[k]].tolist()).strip() == labels[k].lower().strip(), (labels[k], t[k, :eot[k] + 1].tolist())
+    assert t[labels.index("wall"), 1:3].tolist()[1] == EOT    # common single words are one token

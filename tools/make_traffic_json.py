@@ -1,41 +1,77 @@
 #!/usr/bin/env python
-"""profiles/<round>_traffic.json (argv[3], default profiles/r02_traffic.json) from the PMC summary of tools/collect_profiles.sh (gpurun_out/profiles/summary.json).
-HBM-side traffic of the profiled MLP fc1 GEMM (the TAG=1 kernel symbol), per launch:
-  FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled on gfx950 (MI355X_MICROARCH.md, HBM/rocprofv3 section)."""
+"""profiles/<round>_traffic.json from the rocprofv3 passes of tools/collect_profiles.sh (gpurun_out/profiles/summary.json):
+per-launch HBM-side traffic (PMC FETCH_SIZE / WRITE_SIZE, separate passes; FETCH doubled on gfx950 per MI355X_MICROARCH.md's
+HBM/rocprofv3 section) and average duration (kernel-trace statistics of the same command) of the dominant kernels, against their
+ALGORITHMIC bytes / flops.  MFMA-bound kernels get TFLOP/s fractions of the dense 16-bit peak (2.5 PF/s), HBM-bound ones GB/s
+fractions of 8 TB/s.   usage: make_traffic_json.py summary.json <batch> <out.json> <dtype> [commit]"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "profiles", "summary.json")
-batch = int(sys.argv[2]) if len(sys.argv) > 2 else 36
-pmc = json.load(open(src))["pmc"]
-name = [k for k in pmc if "lseg_gemm_kernel" in k and k.rstrip().endswith(", 1>(lseg::GemmArgs)")]
-# the bench's self-check adds one single-image forward (a smaller tile configuration of the same tagged kernel):
-# the timed batch is the instance with the larger per-launch MFMA count
-name.sort(key=lambda k: -pmc[k].get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0))
-c = pmc[name[0]]
-M, N, K = batch * 901, 4096, 1024
-out = {"mlp_fc1_gemm": {
-    "kernel": name[0], "batch": batch,
-    "FETCH_SIZE_KB": c["FETCH_SIZE"], "WRITE_SIZE_KB": c["WRITE_SIZE"],
-    "traffic_bytes_per_launch": (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024,
-    "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); FETCH counts L2->fabric requests incl. Infinity-Cache hits",
-    "algorithmic_bytes_per_launch": 2 * (M * K + N * K + M * N),
-    **{k: c[k] for k in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "TCC_HIT_sum", "TCC_MISS_sum", "SQ_LDS_BANK_CONFLICT") if k in c}}}
-# the correlation kernel (labels as GEMM rows, 160x128 tiles) and the two attention kernels, when profiled
-def add(key, pred, alg_bytes=None):
-    names = [k for k in pmc if pred(k)]
-    if not names:
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 36
+dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r03_traffic.json")
+dtype = sys.argv[4] if len(sys.argv) > 4 else "fp16"
+commit = sys.argv[5] if len(sys.argv) > 5 else None
+S = json.load(open(src))
+pmc = S.get("pmc", {})
+stats = {k["name"]: k for k in S.get("kernel_stats", [])}
+T = "lseg::F16" if dtype == "fp16" else "lseg::BF16"
+ntok, D, K = 901, 1024, 150
+M = B * ntok
+
+
+def find(pred):
+    names = [k for k in set(pmc) | set(stats) if pred(k)]
+    # the bench's self-check adds single-image launches of the same symbols: the timed batch is the instance with the most work
+    names.sort(key=lambda k: -(stats.get(k, {}).get("total_ns", 0)))
+    return names[0] if names else None
+
+
+def entry(key, pred, alg_bytes=None, flops=None, bound="mfma"):
+    n = find(pred)
+    if not n:
         return
-    names.sort(key=lambda k: -(pmc[k].get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0) + pmc[k].get("SQ_INSTS_VALU_MFMA_MOPS_F16", 0)))
-    c = pmc[names[0]]
-    e = {"kernel": names[0], **{k: c[k] for k in c}}
+    e = {"kernel": n, "batch": B, "dtype": dtype, "bound": bound}
+    c = pmc.get(n, {})
+    for k in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "GRBM_GUI_ACTIVE", "TCC_HIT_sum", "TCC_MISS_sum",
+              "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+        if k in c:
+            e[k] = c[k]
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         e["traffic_bytes_per_launch"] = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024
+        e["traffic_note"] = "FETCH_SIZE (KB) x 2: gfx950 reports half of wide coalesced reads; L2->fabric requests incl. Infinity-Cache hits"
+    st = stats.get(n)
+    if st:
+        e["avg_launch_us"] = st["avg_ns"] / 1e3
+        e["launches_in_stats_pass"] = st["calls"]
     if alg_bytes:
         e["algorithmic_bytes_per_launch"] = alg_bytes
+        if "traffic_bytes_per_launch" in e:
+            e["traffic_over_algorithmic"] = e["traffic_bytes_per_launch"] / alg_bytes
+        if st and bound == "hbm":
+            e["achieved_GBps"] = alg_bytes / st["avg_ns"]
+            e["frac_of_8TBps"] = e["achieved_GBps"] / 8000.0
+    if flops and st:
+        e["flops_per_launch"] = flops
+        e["achieved_TFLOPs"] = flops / st["avg_ns"] / 1e3
+        e["frac_of_2.5PF"] = e["achieved_TFLOPs"] / 2500.0
     out[key] = e
-P = batch * 57600
-add("correlation_gemm", lambda k: "lseg_gemm_kernel" in k and "TileCfg<160, 128" in k, 2 * P * 512 + 150 * 512 * 2 + 4 * P * 150)
-add("attention", lambda k: "lseg_attention_kernel<lseg::BF16>" in k)
-dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r02_traffic.json")
+
+
+out = {"_meta": {"commit": commit, "batch": B, "dtype": dtype,
+                 "how": "tools/collect_profiles.sh: rocprofv3 --kernel-trace --stats of `bench.py --steps 5`, then one --pmc pass per counter group"}}
+g = lambda epi, tag: (lambda k: "lseg_gemm_kernel<" + T in k and k.rstrip().endswith(f", false, false, {epi}, {tag}>(lseg::GemmArgs)") and "TileCfg<256, 256" in k)
+entry("mlp_fc1_gemm", g(2, 1), 2 * (M * D + 4 * D * D + M * 4 * D), 2.0 * M * 4 * D * D)
+# attn.proj and mlp.fc2 share the symbol (fp32 residual epilogue): per-launch averages over both shapes
+entry("res32_gemm", g(3, 0), (2 * (M * D + D * D) + 8 * M * D + 2 * (M * 4 * D + 4 * D * D) + 8 * M * D) // 2, (2.0 * M * D * D + 2.0 * M * 4 * D * D) / 2)
+entry("qkv_gemm", g(4, 0), 2 * (M * D + 3 * D * D + M * 3 * D), 2.0 * M * 3 * D * D)
+entry("attention", lambda k: "lseg_attention_kernel<" + T + ", 4>" in k, 2 * 4 * B * 16 * 1024 * 64, 4.0 * B * ntok * ntok * D)
+# ---- HBM-bound kernels of the head: algorithmic bytes = what the schedule must move once
+P122, P120 = B * 122 * 122, B * 120 * 120
+entry("correlation_label_planes", lambda k: "lseg_gemm_kernel<lseg::F16" in k and "TileCfg<160, 128" in k,
+      2 * P122 * 512 + 2 * K * 512 + 4 * K * P122, 2.0 * K * P122 * 512, bound="hbm")
+entry("upsample4x_logits", lambda k: "upsample4x_planes_scaled_kernel" in k, 4 * K * P122 + 4 * B * 240 * 240 + 4 * B * K * 480 * 480, bound="hbm")
+entry("pixel_gram", lambda k: "pixel_gram_kernel" in k, 2 * P122 * 512 + 4 * 5 * P120, bound="hbm")
+entry("layernorm", lambda k: "layernorm_kernel<4>" in k, M * D * (4 + 2), bound="hbm")
 json.dump(out, open(dst, "w"), indent=1)
-print(json.dumps(out, indent=1))
+print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk in ("avg_launch_us", "achieved_TFLOPs", "frac_of_2.5PF", "achieved_GBps", "frac_of_8TBps",
+                                                                "traffic_over_algorithmic")} for k, v in out.items() if k != "_meta"}, indent=1))
