@@ -331,7 +331,13 @@ int lseg_op_linear_backward(const void* d_dy, const void* d_x, const void* d_w, 
         g.C = d_dx; g.out_dtype = ab; g.ldc = K; g.map_mode = MAP_LINEAR;
         if ((r = launch_gemm(g, ab, st))) { cleanup(); return r; }
     }
-    if (d_dw) {     // dW[N,K] = dY^T[N,M] . X[M,K]    (A = dY^T [N,Mp], "weights" = X^T [K,Mp], contraction over M)
+    float* wsk = nullptr;
+    if (d_dw && wgrad_kmajor_ok(N, K, (size_t)16 * N * K)) {     // the operands as they are (K-major path: no transposed copies)
+        if (hipMallocAsync((void**)&wsk, (size_t)16 * N * K * sizeof(float), st) != hipSuccess) { cleanup(); return set_error(LSEG_ERR_HIP, "linear_backward: out of device memory"); }
+        r = launch_wgrad_kmajor(d_dy, N, d_x, K, M, N, K, d_dw, 0, wsk, (size_t)16 * N * K, ab, st);
+        (void)hipFreeAsync(wsk, st);
+        if (r) { cleanup(); return r; }
+    } else if (d_dw) {     // dW[N,K] = dY^T[N,M] . X[M,K]    (A = dY^T [N,Mp], "weights" = X^T [K,Mp], contraction over M)
         if (hipMallocAsync((void**)&dyt, (size_t)N * Mp * 2, st) != hipSuccess ||
             hipMallocAsync((void**)&xt, (size_t)K * Mp * 2, st) != hipSuccess) { cleanup(); return set_error(LSEG_ERR_HIP, "linear_backward: out of device memory"); }
         if ((r = launch_transpose16(d_dy, dyt, M, N, N, Mp, st)) || (r = launch_transpose16(d_x, xt, M, K, K, Mp, st))) { cleanup(); return r; }
@@ -375,6 +381,17 @@ int lseg_op_conv3x3_backward(const void* d_dy_pad, const void* d_x_pad, const vo
         // positions whose shifted partner falls outside the image.  One GEMM: dY^T [Co, Mp] x (9 shifted X^T) [9*Ci, Mp]^T.
         if (!d_x_pad) return fail(set_error(LSEG_ERR_INVALID, "conv3x3_backward: wgrad needs the forward input"));
         const int Mp = B * (H + 2) * (W + 2), Mpp = (Mp + 63) / 64 * 64;
+        const size_t wsn = (size_t)16 * Cout * 9 * Cin;
+        if ((Cin % 128) == 0 && wgrad_kmajor_ok(Cout, 9 * Cin, wsn)) {      // the maps as they are (K-major operands, tap shifts in the loader)
+            float* wsk = nullptr;
+            int ns = 1;
+            if (hipMallocAsync((void**)&wsk, wsn * sizeof(float), st) != hipSuccess) return fail(set_error(LSEG_ERR_HIP, "conv3x3_backward: out of device memory"));
+            r = launch_conv_wgrad_kmajor(d_dy_pad, d_x_pad, 0, B, H, W, Cin, Cout, wsk, wsn, DT_BF16, &ns, st);
+            if (!r) r = launch_sum_partials(wsk, d_dw, ns, (size_t)Cout * 9 * Cin, (size_t)Cout * 9 * Cin, 0, st);
+            (void)hipFreeAsync(wsk, st);
+            cleanup();
+            return r;
+        }
         if (hipMallocAsync((void**)&dyt, (size_t)Cout * Mpp * 2, st) != hipSuccess ||
             hipMallocAsync((void**)&xt9, (size_t)9 * Cin * Mpp * 2, st) != hipSuccess) return fail(set_error(LSEG_ERR_HIP, "conv3x3_backward: out of device memory"));
         if ((r = launch_transpose16(d_dy_pad, dyt, Mp, Cout, Cout, Mpp, st))) return fail(r);

@@ -68,6 +68,14 @@ struct GemmArgs {
     // whose operand bytes per flop are twice as high on the per-CU L2->LDS path.  Needs bias == NULL, no residual, MAP_LINEAR.
     int nsplit, split_steps;
     size_t c_split_stride;
+    // ---- K-major operands (weight gradients, dW = dY^T X): A is [K, lda] with the M output rows contiguous, W is [K, ldw] with the N
+    // output columns contiguous -- the operands as they sit in memory, no transposed copies.  Rows k >= k_valid read as zero (the K-steps
+    // cover K = k_valid rounded up to 64).  128x128 tiles, fp32 split-K slabs (nsplit >= 1) as output; needs N % 128 == 0.
+    int kmajor, k_valid;
+    // ... of a 3x3 conv (kconv_cin > 0): W = the padded NHWC input [k_valid, kconv_cin], output column n = (tap, ci) reads W row
+    // k + (tap / 3 - 1) * kconv_wp + (tap % 3 - 1) (rows outside [0, k_valid) are zero); relu_in clamps the W operand (the RCU convs read
+    // ReLU(x)).  Needs kconv_cin % 128 == 0 (a 128-wide column tile lies inside one tap).
+    int kconv_cin, kconv_wp;
     int tile_hint;              // 0: the launcher's cost model picks the tile; 2 = 128x128, 6 = 256x256 (callers that plan tile and split-K together)
 };
 

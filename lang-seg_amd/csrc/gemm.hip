@@ -644,6 +644,21 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 }
 __device__ __forceinline__ void wait_lgkmcnt0() { __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | (0 << 8) | (3 << 14)); }
 
+// 16 bytes per lane, buffer -> LDS (wave-uniform LDS base + lane * 16), with the buffer's bounds check: offsets >= `bytes` read as zero
+__device__ __forceinline__ void buffer_load_lds16(const void* base, int bytes, char* lds, uint32_t voff, uint32_t soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc((void*)base, 0, bytes, 0x00020000),
+                                             (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+// two ds_read_b64_tr_b16 = the 8 consecutive k of one MFMA operand lane (k 0-3 from p0, k 4-7 from p1)
+__device__ __forceinline__ i32x4_t ds_read_tr16_pair(const char* p0, const char* p1) {
+    typedef short v4s_t __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4s_t* lds_v4s_t;
+    union { v4s_t h[2]; i32x4_t v; } u;
+    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)p0);
+    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s_t)p1);
+    return u.v;
+}
+
 template <typename T, typename CFG, bool CONV, bool RELU_IN, int EPI, int TAG>
 __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(const GemmArgs g) {
     constexpr int BM = CFG::BM, BN = CFG::BN, NS = CFG::NS, NW = CFG::NW;
@@ -656,6 +671,18 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform -> SALU addressing
     const int wm = w / CFG::WGN, wn = w % CFG::WGN;
+    // K-MAJOR operands (TAG == 2; weight gradients dW = dY^T X contract over the token axis, the SLOW axis of both operands as they sit
+    // in memory): A is [K, lda] with the M output rows contiguous, W is [K, ldw] with the N output columns contiguous.  An LDS stage
+    // holds [64 k][BM] (rows of BM * 2 bytes) instead of [BM][64 k]; it is filled by buffer_load ... lds (16 B / lane, out-of-range rows
+    // k >= k_valid come back as ZERO from the buffer's bounds check) and the MFMA fragments are gathered with ds_read_b64_tr_b16
+    // (tools/probes/tr_read_probe.py): a 16-lane group reads a [4 k][16 columns] block, lane i receives column i.  Swizzle: the 32-byte
+    // segment (16 columns) s of stage row r sits at s ^ gk(r), gk(r) = (r & 3) | ((r >> 3) & 1) << 2 -- the 8 rows a 32-lane read group
+    // touches land on 8 different segments = all 64 banks.
+    constexpr bool KMAJ = TAG == 2;
+    static_assert(!KMAJ || (BM == 128 && BN == 128 && !CONV), "the K-major path is built for 128 x 128 tiles");
+    auto gsw = [](int r) { return (r & 3) | (((r >> 3) & 1) << 2); };
+    // (the buffer / transpose-read builtins live in __device__ helpers: used directly inside a templated __global__ function they make
+    // hipcc drop that instantiation's HOST stub without a diagnostic -- the library then fails to load with an undefined symbol)
 
     // ---- persistent, XCD-aware tile schedule ------------------------------------------------------
     // Workgroup b lands on XCD b%8 (observed dispatch, used for L2 affinity only).  XCD x owns the
@@ -681,11 +708,21 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
     // ---- load side: two cursors (A runs one K-step ahead of W), both walk (tile, K-step) in order -----
     // per-lane BYTE offsets (32-bit) of this lane's source rows, incl. the swizzled 16-byte chunk
     uint32_t a_off[A_SPW], w_off[W_SPW];
+    int w_row[KMAJ ? W_SPW : 1];                          // K-major conv taps: this lane's stage row + the tap's row shift
     const int lrow = lane >> 3;                           // row inside an 8-row slab
     auto setup_a = [&](int t) {
         int mb, nb;
         tile_coords(t % per_split, tiles_m, tiles_n, mb, nb, g.group_m);
         const int m0 = mb * BM;
+        if constexpr (KMAJ) {
+#pragma unroll
+            for (int s = 0; s < A_SPW; ++s) {
+                const int rk = (s * NW + w) * 4 + (lane >> 4);            // stage row (k) of this lane; 4 rows of 256 B per wave instruction
+                const int c = (lane & 15) ^ (gsw(rk) << 1);                // source chunk of LDS chunk slot lane & 15
+                a_off[s] = ((uint32_t)rk * (uint32_t)g.lda + (uint32_t)(m0 + c * 8)) * 2u;
+            }
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < A_SPW; ++s) {
             const int r = (s * NW + w) * 8 + lrow;
@@ -707,6 +744,22 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
         int mb, nb;
         tile_coords(t % per_split, tiles_m, tiles_n, mb, nb, g.group_m);
         const int n0 = nb * BN;
+        if constexpr (KMAJ) {
+            const int tap = g.kconv_cin > 0 ? n0 / g.kconv_cin : 0;
+            const int shift = g.kconv_cin > 0 ? (tap / 3 - 1) * g.kconv_wp + (tap % 3 - 1) : 0;
+#pragma unroll
+            for (int s = 0; s < W_SPW; ++s) {
+                const int rk = (s * NW + w) * 4 + (lane >> 4);
+                const int c = (lane & 15) ^ (gsw(rk) << 1);
+                if (g.kconv_cin > 0) {      // conv taps: the row is resolved per load (it may fall outside the map: zero)
+                    w_row[s] = rk + shift;
+                    w_off[s] = (uint32_t)(n0 - tap * g.kconv_cin + c * 8) * 2u;
+                } else {
+                    w_off[s] = ((uint32_t)rk * (uint32_t)g.ldw + (uint32_t)(n0 + c * 8)) * 2u;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < W_SPW; ++s) {
             const int r = (s * NW + w) * 8 + lrow;
@@ -771,13 +824,29 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
     auto issue_q = [&](auto qc) {
         constexpr int q = decltype(qc)::value;
         if constexpr (q < W_SPW) {
-            if constexpr (q == 0) wbase = reinterpret_cast<const char*>(g.W + (wseg == 2 ? g.w_plane : 0) + (wkt << 6));
-            glds_slab_off(wbase, w_off[q], smem + W_RING_OFF + wslot * CFG::W_BYTES + (q * NW + w) * 1024);
+            if constexpr (KMAJ) {
+                if (g.kconv_cin > 0) {
+                    const int r = w_row[q] + (wkt << 6);
+                    const uint32_t vo = (r < 0 || r >= g.k_valid) ? 0xffffffffu : (uint32_t)r * (uint32_t)g.ldw * 2u + w_off[q];
+                    buffer_load_lds16(g.W, (int)((size_t)g.k_valid * g.ldw * 2), smem + W_RING_OFF + wslot * CFG::W_BYTES + (q * NW + w) * 1024, vo, 0u);
+                } else {
+                    buffer_load_lds16(g.W, (int)((size_t)g.k_valid * g.ldw * 2), smem + W_RING_OFF + wslot * CFG::W_BYTES + (q * NW + w) * 1024,
+                                      w_off[q], (uint32_t)wkt * 128u * (uint32_t)g.ldw);
+                }
+            } else {
+                if constexpr (q == 0) wbase = reinterpret_cast<const char*>(g.W + (wseg == 2 ? g.w_plane : 0) + (wkt << 6));
+                glds_slab_off(wbase, w_off[q], smem + W_RING_OFF + wslot * CFG::W_BYTES + (q * NW + w) * 1024);
+            }
             if constexpr (q == W_SPW - 1) advance_w();
         } else {
             constexpr int qa = q - W_SPW;
-            if constexpr (qa == 0) abase = a_src();
-            glds_slab_off(abase, a_off[qa], smem + aslot * A_BYTES + (qa * NW + w) * 1024);
+            if constexpr (KMAJ) {
+                buffer_load_lds16(g.A, (int)((size_t)g.k_valid * g.lda * 2), smem + aslot * A_BYTES + (qa * NW + w) * 1024,
+                                  a_off[qa], (uint32_t)akt * 128u * (uint32_t)g.lda);
+            } else {
+                if constexpr (qa == 0) abase = a_src();
+                glds_slab_off(abase, a_off[qa], smem + aslot * A_BYTES + (qa * NW + w) * 1024);
+            }
             if constexpr (qa == A_SPW - 1) advance_a();
         }
     };
@@ -808,10 +877,33 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
 #else
     auto mm = [&](i32x4_t a, i32x4_t b, f32x4_t c) { return mfma16<T>(a, b, c); };
 #endif
-    auto lda = [&](const char* st, int j, int foff) {
-        i32x4_t v = ldfrag(st + abase_off + j * 2048 + foff);
+    // K-major stages: per-lane offsets of the [4 k][16 col] transpose-read blocks of each 16-wide sub-tile (loop invariant); khalf and
+    // the two 4-row halves of an 8-k operand are immediates
+    int a_tr[KMAJ ? MI : 1], w_tr[KMAJ ? NI : 1];
+    if constexpr (KMAJ) {
+        const int ti = lane & 15, kg = lane >> 4, gl = (ti >> 2) | ((kg & 1) << 2);
+#pragma unroll
+        for (int j = 0; j < MI; ++j) a_tr[j] = (kg * 8 + (ti >> 2)) * (BM * 2) + ((((wm * WM) >> 4) + j) ^ gl) * 32 + (ti & 3) * 8;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) w_tr[i] = (kg * 8 + (ti >> 2)) * (BN * 2) + ((((wn * WN) >> 4) + i) ^ gl) * 32 + (ti & 3) * 8;
+    }
+    auto ldfrag_t = [&](const char* st, int off, int khalf, int pitch) {
+        return ds_read_tr16_pair(st + off + (khalf * 32) * pitch, st + off + (khalf * 32 + 4) * pitch);
+    };
+    // kh = K-half of the 64-deep stage (a literal 0 / 1 at every call site)
+    auto lda = [&](const char* st, int j, int kh) {
+        if constexpr (KMAJ) return ldfrag_t(st, a_tr[j], kh, BM * 2);
+        i32x4_t v = ldfrag(st + abase_off + j * 2048 + (kh ? foff1 : foff0));
         if (RELU_IN) v = relu_frag(v);
         return v;
+    };
+    auto ldw = [&](const char* st, int i, int kh) {
+        if constexpr (KMAJ) {
+            i32x4_t v = ldfrag_t(st, w_tr[i], kh, BN * 2);
+            if (RELU_IN) v = relu_frag(v);                    // K-major conv wgrad: the W operand is the conv input, read through a ReLU
+            return v;
+        }
+        return ldfrag(st + wbase_off + i * 2048 + (kh ? foff1 : foff0));
     };
 
     unsigned long long tmark[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // dbg&4: cycles in {vm wait, barrier, epilogue, MFMA blocks}
@@ -839,8 +931,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
                 acc[i][j] = mm(wf0[i], af0[j], acc[i][j]);
                 static_for<(t * OPS) / NMF, ((t + 1) * OPS) / NMF>([&](auto oc) {
                     constexpr int o = decltype(oc)::value;
-                    if constexpr (o < MI) af1[o] = lda(sa, o, foff1);
-                    else if constexpr (o < MI + NI) wf1[o - MI] = ldfrag(sw + wbase_off + (o - MI) * 2048 + foff1);
+                    if constexpr (o < MI) af1[o] = lda(sa, o, 1);
+                    else if constexpr (o < MI + NI) wf1[o - MI] = ldw(sw, o - MI, 1);
 #ifndef GEMM_ABL_NODMA
                     else issue_q(std::integral_constant<int, CFG::Q_B2 + o - MI - NI>{});
 #endif
@@ -878,8 +970,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
                 acc[i][j] = mm(wf1[i], af1[j], acc[i][j]);
                 static_for<(t * OPS) / NMF, ((t + 1) * OPS) / NMF>([&](auto oc) {
                     constexpr int o = decltype(oc)::value;
-                    if constexpr (o < MI) af0[o] = lda(nxa, o, foff0);
-                    else if constexpr (o < MI + NI) wf0[o - MI] = ldfrag(nxw + wbase_off + (o - MI) * 2048 + foff0);
+                    if constexpr (o < MI) af0[o] = lda(nxa, o, 0);
+                    else if constexpr (o < MI + NI) wf0[o - MI] = ldw(nxw, o - MI, 0);
 #ifndef GEMM_ABL_NODMA
                     else issue_q(std::integral_constant<int, o - MI - NI>{});
 #endif
@@ -901,9 +993,9 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int i = 0; i < NI; ++i) wf0[i] = ldfrag(smem + W_RING_OFF + wbase_off + i * 2048 + foff0);
+    for (int i = 0; i < NI; ++i) wf0[i] = ldw(smem + W_RING_OFF, i, 0);
 #pragma unroll
-    for (int j = 0; j < MI; ++j) af0[j] = lda(smem, j, foff0);
+    for (int j = 0; j < MI; ++j) af0[j] = lda(smem, j, 0);
     static_for<0, A_SPW>([&](auto qc) { issue_q(std::integral_constant<int, W_SPW + decltype(qc)::value>{}); });   // A(1)
     static_for<0, CFG::Q_B2>([&](auto qc) { issue_q(qc); });                               // head of {W(1), A(2)}
 
@@ -1087,7 +1179,7 @@ template <typename T>
 int select_epi(const GemmArgs& g) {
     constexpr int dt = std::is_same<T, BF16>::value ? DT_BF16 : DT_F16;
     static const bool off = getenv("LSEG_GEMM_GENERIC_EPI") != nullptr;       // A/B switch (tools)
-    if (!off && g.nsplit > 1 && !g.split && !(g.dbg & 3) && !g.bias && !g.round_mid && (g.N % 128) == 0 && g.map_mode == MAP_LINEAR &&
+    if (!off && (g.nsplit > 1 || g.kmajor) && !g.split && !(g.dbg & 3) && !g.bias && !g.round_mid && (g.N % 128) == 0 && g.map_mode == MAP_LINEAR &&
         g.res_mode == RES_NONE && g.act == ACT_NONE && g.out_dtype == DT_F32 && (g.ldc % 4) == 0 && (g.c_split_stride % 4) == 0 &&
         !(reinterpret_cast<uintptr_t>(g.C) & 15) && !(g.conv && g.relu_in))
         return EPI_PART32;
@@ -1122,6 +1214,13 @@ int select_epi(const GemmArgs& g) {
 
 template <typename T>
 int dispatch(const GemmArgs& g, hipStream_t stream) {
+    if (g.kmajor) {
+        if (select_epi<T>(g) != EPI_PART32 || g.conv || (g.relu_in && !g.kconv_cin) || (g.kconv_cin && ((g.kconv_cin % 128) || g.ldw != g.kconv_cin)) || g.k_valid < 1 || g.k_valid > g.K || g.K - g.k_valid >= 64 ||
+            (double)g.k_valid * g.lda * 2 >= 2.0e9 || (double)g.k_valid * g.ldw * 2 >= 2.0e9)
+            return set_error(LSEG_ERR_UNSUPPORTED, "K-major GEMM: needs fp32 slab output (MAP_LINEAR, no bias / residual), N %% 128 == 0, operands < 2 GB");
+        if (g.relu_in) return launch_one<T, CfgMid, false, true, EPI_PART32, 2>(g, stream);
+        return launch_one<T, CfgMid, false, false, EPI_PART32, 2>(g, stream);
+    }
     if (g.map_mode == MAP_ROWNORM) {
         if (g.split) return set_error(LSEG_ERR_UNSUPPORTED, "the fused head has no split-precision form (use the two-kernel path)");
         if (g.conv || g.relu_in || g.N != 512 || !g.bias)
@@ -1138,7 +1237,7 @@ int dispatch(const GemmArgs& g, hipStream_t stream) {
         if (g.relu_in) return pick_tile<T, true, true, EPI_GENERIC, 0>(g, stream);
         return pick_tile<T, true, false, EPI_GENERIC, 0>(g, stream);
     }
-    if (g.relu_in) return set_error(LSEG_ERR_UNSUPPORTED, "gemm: relu_in is only implemented for the conv path");
+    if (g.relu_in && !g.kmajor) return set_error(LSEG_ERR_UNSUPPORTED, "gemm: relu_in is only implemented for the conv path");
     if (g.split && !std::is_same<T, F16>::value) return set_error(LSEG_ERR_UNSUPPORTED, "split precision runs on fp16 (hi, lo) pairs");
     switch (epi) {
         case EPI_PAD16: return pick_tile<T, false, false, EPI_PAD16, 0>(g, stream);

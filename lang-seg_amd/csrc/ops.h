@@ -86,6 +86,18 @@ size_t attention_backward_ws_bytes(int B, int H, int npad);
 int launch_attention_backward_qkv(const void* q, const void* k, const void* vt, const void* o, const void* d_o, const float* lse2, void* dqkv,
                                   void* ws, int B, int H, int ntok, int npad, int dtype, float scale, hipStream_t stream);
 
+// dW [rows_out, cols_out] (+)= dY[:, :rows_out]^T X[:, :cols_out], contraction over the M rows of dY [M, ldy] / X [M, ldx] (16-bit), through the
+// K-major operand path of the GEMM (no transposed copies); `ws` = fp32 scratch for the split-K slabs (ws_floats >= rows_out * cols_out).
+// Returns LSEG_ERR_UNSUPPORTED (and launches nothing) when cols_out % 128 != 0: callers keep the transposing path for those.
+bool wgrad_kmajor_ok(int rows_out, int cols_out, size_t ws_floats);
+int launch_wgrad_kmajor(const void* dy, int ldy, const void* x, int ldx, int M, int rows_out, int cols_out, float* dw, int accumulate,
+                        float* ws, size_t ws_floats, int ab_dtype, hipStream_t st);
+
+// 3x3 conv weight gradient in the padded-NHWC layout through the same path: slabs [ns][Cout][9 * Cin] (tap-major) in `ws`; *ns_out = slab count
+// (the caller sums / re-layouts them: launch_conv_wgrad_unpack / launch_sum_partials).  Needs Cin % 128 == 0.
+int launch_conv_wgrad_kmajor(const void* dy_pad, const void* x_pad, int relu_x, int B, int H, int W, int Cin, int Cout, float* ws, size_t ws_floats,
+                             int ab_dtype, int* ns_out, hipStream_t st);
+
 // ---- engine-level training step (train.hip) --------------------------------------------------------------------------------
 int launch_attention_lse(const void* q, const void* k, const void* vt, void* out, float* lse2, int B, int H, int ntok, int npad, int dtype,
                          int causal, float scale, hipStream_t stream);

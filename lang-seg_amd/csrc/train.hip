@@ -422,6 +422,54 @@ int Engine::pick_split(int M, int N, int nk, GemmArgs& g) {
     return (int)ns;
 }
 
+// ---- weight gradient straight from the row-major operands (gemm.hip "K-MAJOR operands") ------------------------------------------------
+bool wgrad_kmajor_ok(int rows_out, int cols_out, size_t ws_floats) {
+    static const bool off = getenv("LSEG_WGRAD_TRANSPOSE") != nullptr;           // tools: A/B switch back to the transposing path
+    return !off && rows_out >= 1 && (cols_out % 128) == 0 && (size_t)rows_out * cols_out <= ws_floats;
+}
+int launch_wgrad_kmajor(const void* dy, int ldy, const void* x, int ldx, int M, int rows_out, int cols_out, float* dw, int accumulate,
+                        float* ws, size_t ws_floats, int ab_dtype, hipStream_t st) {
+    if (!wgrad_kmajor_ok(rows_out, cols_out, ws_floats)) return set_error(LSEG_ERR_UNSUPPORTED, "wgrad_kmajor: %d x %d", rows_out, cols_out);
+    GemmArgs g;
+    gemm_args_init(g);
+    const int Kp = (M + 63) / 64 * 64, nk = Kp / 64;
+    g.A = (const uint16_t*)dy; g.lda = ldy; g.W = (const uint16_t*)x; g.ldw = ldx;
+    g.M = rows_out; g.N = cols_out; g.K = Kp; g.kmajor = 1; g.k_valid = M;
+    g.C = ws; g.out_dtype = DT_F32; g.ldc = cols_out; g.map_mode = MAP_LINEAR;
+    // split plan: ~2 work items per CU with 128 x 128 tiles, >= 8 K-steps each, slabs within the scratch
+    const long tiles = (long)((rows_out + 127) / 128) * (cols_out / 128);
+    long ns = (2L * 256 + tiles - 1) / tiles;
+    if (ns > nk / 8) ns = nk / 8;
+    while (ns > 1 && (size_t)ns * rows_out * cols_out > ws_floats) --ns;
+    if (ns < 1) ns = 1;
+    const int steps = (int)((nk + ns - 1) / ns);
+    ns = (nk + steps - 1) / steps;
+    g.nsplit = (int)ns; g.split_steps = steps; g.c_split_stride = (size_t)rows_out * cols_out;
+    TRY(launch_gemm(g, ab_dtype, st));
+    return launch_sum_partials(ws, dw, (int)ns, (size_t)rows_out * cols_out, g.c_split_stride, accumulate, st);
+}
+
+int launch_conv_wgrad_kmajor(const void* dy_pad, const void* x_pad, int relu_x, int B, int H, int W, int Cin, int Cout, float* ws, size_t ws_floats,
+                             int ab_dtype, int* ns_out, hipStream_t st) {
+    if ((Cin % 128) != 0 || !wgrad_kmajor_ok(Cout, 9 * Cin, ws_floats)) return set_error(LSEG_ERR_UNSUPPORTED, "conv_wgrad_kmajor: Cin=%d Cout=%d", Cin, Cout);
+    const int Mp = B * (H + 2) * (W + 2), nk = (Mp + 63) / 64;
+    GemmArgs g;
+    gemm_args_init(g);
+    g.A = (const uint16_t*)dy_pad; g.lda = Cout; g.W = (const uint16_t*)x_pad; g.ldw = Cin; g.M = Cout; g.N = 9 * Cin; g.K = nk * 64;
+    g.kmajor = 1; g.k_valid = Mp; g.kconv_cin = Cin; g.kconv_wp = W + 2; g.relu_in = relu_x ? 1 : 0;
+    g.C = ws; g.out_dtype = DT_F32; g.ldc = 9 * Cin; g.map_mode = MAP_LINEAR;
+    const long tiles = (long)((Cout + 127) / 128) * (9 * Cin / 128);
+    long ns = (2L * 256 + tiles - 1) / tiles;
+    if (ns > nk / 8) ns = nk / 8;
+    while (ns > 1 && (size_t)ns * Cout * 9 * Cin > ws_floats) --ns;
+    if (ns < 1) ns = 1;
+    const int steps = (int)((nk + ns - 1) / ns);
+    ns = (nk + steps - 1) / steps;
+    g.nsplit = (int)ns; g.split_steps = steps; g.c_split_stride = (size_t)Cout * 9 * Cin;
+    if (ns_out) *ns_out = (int)ns;
+    return launch_gemm(g, ab_dtype, st);
+}
+
 // ---- Linear backward on the forward MFMA kernel (contraction dimension transposed onto the fast axis) ---------------------------
 //   dx [M,K] = dy [M,N] . W [N,K]     (A = dy, "weights" = wt = W^T [K,N])
 //   dw [N,K] = dy^T . x               (A = dy^T [N,Mp], "weights" = x^T [K,Mp]; fp32, written in the parameter's own layout)
@@ -435,7 +483,9 @@ int Engine::lin_bwd(const uint16_t* dy, int M, int N, int K, const uint16_t* x, 
         g.bias = zeros_; g.C = dx; g.out_dtype = img_dt_; g.ldc = K; g.map_mode = MAP_LINEAR;
         TRY(launch_gemm(g, img_dt_, st));
     }
-    if (dw) {
+    if (dw && wgrad_kmajor_ok(dw_rows > 0 ? dw_rows : N, K, ws_part_n_)) {
+        TRY(launch_wgrad_kmajor(dy, N, x, K, M, dw_rows > 0 ? dw_rows : N, K, dw, acc, ws_part_, ws_part_n_, img_dt_, st));
+    } else if (dw) {
         const int Mp = (int)up64(M);
         if ((size_t)N * Mp > ws_a_n_ || (size_t)K * Mp > ws_b_n_) return set_error(LSEG_ERR_STATE, "wgrad workspace too small (%d x %d x %d)", M, N, K);
         TRY(launch_transpose16(dy, ws_a_, M, N, N, Mp, st));
@@ -464,7 +514,12 @@ int Engine::conv_bwd(const uint16_t* dy_pad, const uint16_t* x_pad, int relu_x, 
         Lin d; d.w = w.wd; d.b = zeros_; d.n = Cin; d.k = 9 * Cout;
         TRY(conv3x3(dy_pad, d, nullptr, nullptr, dx_pad, B, H, W, 1, 0, 0, st));
     }
-    if (dw_dst) {
+    if (dw_dst && (Cin % 128) == 0 && wgrad_kmajor_ok(Cout, 9 * Cin, ws_part_n_)) {
+        // dW[co][tap][ci] = sum_m dY[m][co] * relu?(X)[m + shift(tap)][ci] straight from the padded NHWC maps (K-major GEMM operands)
+        int ns = 1;
+        TRY(launch_conv_wgrad_kmajor(dy_pad, x_pad, relu_x, B, H, W, Cin, Cout, ws_part_, ws_part_n_, img_dt_, &ns, st));
+        TRY(launch_conv_wgrad_unpack(ws_part_, dw_dst, Co_real, Ci_real, Cin, acc, st, ns, (size_t)Cout * 9 * Cin));
+    } else if (dw_dst) {
         const int Mp = B * (H + 2) * (W + 2), Mpp = (int)up64(Mp);
         if ((size_t)Cout * Mpp > ws_a_n_ || (size_t)9 * Cin * Mpp > ws_b_n_ || (size_t)Cout * 9 * Cin > ws_dw_n_)
             return set_error(LSEG_ERR_STATE, "conv wgrad workspace too small");

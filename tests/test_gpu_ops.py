@@ -229,7 +229,8 @@ def test_fused_head_features(lib, M, Fd):
 
 @pytest.mark.parametrize("dtype,M,N,K", [(torch.bfloat16, 901, 1024, 1024), (torch.float16, 300, 128, 256),
                                          (torch.bfloat16, 64, 64, 64), (torch.bfloat16, 1802, 4096, 1024),
-                                         (torch.bfloat16, 130, 192, 320)])
+                                         (torch.bfloat16, 130, 192, 320), (torch.bfloat16, 1000, 192, 256), (torch.float16, 37, 320, 128),
+                                         (torch.bfloat16, 7208, 1024, 4096)])
 def test_linear_backward(lib, dtype, M, N, K):
     """Backward of y = x W^T + b (first brick of the training step): dX = dY W, dW = dY^T X, db = sum_m dY -- against
     fp32 torch on the same 16-bit-rounded operands (what autograd computes under LSegmentationModule.training_step)."""
@@ -279,7 +280,7 @@ def test_layernorm_backward(lib, dy_dtype, M, D):
     assert (acc - (1.0 + xr.grad)).abs().max().item() <= 2e-5 * max(1.0, xr.grad.abs().max().item())
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 15, 15, 64, 64), (1, 30, 30, 128, 256), (1, 12, 20, 256, 64)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 15, 15, 64, 64), (1, 30, 30, 128, 256), (1, 12, 20, 256, 64), (2, 30, 30, 256, 256)])
 def test_conv3x3_backward(lib, B, H, W, Cin, Cout):
     """Backward of the padded-NHWC 3x3 conv (stride 1, no bias): dX through the forward implicit-GEMM kernel with
     flipped / channel-swapped weights, dW as one GEMM over nine row-shifted transposes -- against torch autograd."""
