@@ -121,6 +121,10 @@ int lseg_finalize_params(lseg_handle h, void* stream);
  * normalised fp16 features [K, out_c] in the engine.  lseg_forward re-runs it on every
  * call (reference semantics) unless text caching is switched on. */
 int lseg_set_text_tokens(lseg_handle h, const int64_t* host_tokens, int K, int ctx);
+/* Text features computed elsewhere -- the value of `self.clip_pretrained.encode_text(text)` (lseg_net.py:183), fp16 [K, out_c] in
+ * device memory, not necessarily normalised -- instead of tokens: the engine applies the fp16 L2 normalisation of :192 and never runs
+ * its text tower until the next lseg_set_text_tokens (label banks of an application, lseg_app.py:350-355). */
+int lseg_set_text_features(lseg_handle h, const void* dev_feat_f16, int K, void* stream);
 int lseg_encode_text(lseg_handle h, void* stream);
 int lseg_set_text_cache(lseg_handle h, int enabled);   /* 0 (default) = re-encode per forward */
 int lseg_get_text_features(lseg_handle h, void* dev_out_f16 /* [K,out_c] fp16 */, void* stream);

@@ -68,6 +68,10 @@ int lseg_set_text_tokens(lseg_handle h, const int64_t* host_tokens, int K, int c
     if (!host_tokens) return set_error(LSEG_ERR_INVALID, "tokens NULL");
     return h->e->set_tokens(host_tokens, K, ctx);
 }
+int lseg_set_text_features(lseg_handle h, const void* dev_feat_f16, int K, void* stream) {
+    GUARD(h);
+    return h->e->set_text_features(dev_feat_f16, K, (hipStream_t)stream);
+}
 int lseg_encode_text(lseg_handle h, void* stream) { GUARD(h); return h->e->encode_text((hipStream_t)stream); }
 int lseg_set_text_cache(lseg_handle h, int enabled) { GUARD(h); h->e->text_cache = enabled != 0; return LSEG_OK; }
 int lseg_set_text_grouping(lseg_handle h, int labels_per_image) {

@@ -53,6 +53,8 @@ public:
     int bind(const char* key, const void* p, int dtype, const int64_t* shape, int ndim);
     int finalize(hipStream_t st);
     int set_tokens(const int64_t* host_tok, int K, int ctx);
+    int set_text_features(const void* dev_feat_f16, int K, hipStream_t st);
+    bool text_external_ = false;   // the text features were handed in (lseg_set_text_features): forward never runs the text tower
     int encode_text(hipStream_t st);
     int forward(const float* x, int B, float* logits, uint8_t* argmax_out, hipStream_t st);
     int get_text_features(void* out_f16, hipStream_t st);

@@ -446,6 +446,23 @@ int Engine::set_tokens(const int64_t* tok, int K, int ctx) {
     for (int k = 0; k < K; ++k) lmax = std::max(lmax, eot[k] + 1);
     tl_ = (cfg.flags & 1) ? ctx : lmax;
     text_valid = false;
+    text_external_ = false;
+    return 0;
+}
+
+// text features computed elsewhere (`clip_pretrained.encode_text(text)` cached by the caller, a label bank of an application): fp16
+// [K, out_c], not necessarily normalised; the engine applies the fp16 L2 normalisation of lseg_net.py:192 and uses them until the
+// next lseg_set_text_tokens / lseg_set_text_features
+int Engine::set_text_features(const void* feat, int K, hipStream_t st) {
+    if (!inited_) return set_error(LSEG_ERR_STATE, "engine not initialised");
+    if (!feat || K < 1 || K > cfg.max_labels) return set_error(LSEG_ERR_INVALID, "set_text_features: K=%d outside [1, max_labels=%d]", K, cfg.max_labels);
+    LSEG_HIP_TRY(hipSetDevice(device));
+    if (text_pending_) { LSEG_HIP_TRY(hipEventSynchronize(ev_text_done_)); text_pending_ = false; }
+    LSEG_HIP_TRY(hipMemcpyAsync(tfeat_, feat, (size_t)K * cfg.out_c * 2, hipMemcpyDeviceToDevice, st));
+    TRY(launch_text_l2norm(tfeat_, tnorm_, K, cfg.out_c, st));
+    K_ = K;
+    text_valid = true;
+    text_external_ = true;
     return 0;
 }
 
@@ -701,7 +718,7 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
     // ---- text tower (lseg_net.py:181-183): re-run every call unless caching is on.  Its ~90 small
     // kernels are latency-bound, so they run on a side stream next to the image tower; fork/join
     // events keep everything ordered with respect to the caller's stream.
-    const bool run_text = !text_cache || !text_valid;
+    const bool run_text = !text_external_ && (!text_cache || !text_valid);
     if (run_text) {
         LSEG_HIP_TRY(hipEventRecord(ev_fork_, st));
         LSEG_HIP_TRY(hipStreamWaitEvent(text_stream_, ev_fork_, 0));

@@ -288,7 +288,7 @@ int Engine::forward_train(const float* x_in, int B, float* logits, hipStream_t s
     last_B_ = B;
     low_pending_ = false;
     eval_stale_ = true;             // the BatchNorm running statistics move: the eval-mode (BN-folded) packs are refreshed by the next eval forward
-    const bool run_text = !text_cache || !text_valid;
+    const bool run_text = !text_external_ && (!text_cache || !text_valid);
     if (run_text) {
         LSEG_HIP_TRY(hipEventRecord(ev_fork_, st));
         LSEG_HIP_TRY(hipStreamWaitEvent(text_stream_, ev_fork_, 0));

@@ -52,6 +52,7 @@ SIGNATURES = {
     "lseg_bind_param": (_i, [_vp, C.c_char_p, _vp, _i, C.POINTER(C.c_int64), _i]),
     "lseg_finalize_params": (_i, [_vp, _vp]),
     "lseg_set_text_tokens": (_i, [_vp, C.POINTER(C.c_int64), _i, _i]),
+    "lseg_set_text_features": (_i, [_vp, _vp, _i, _vp]),
     "lseg_encode_text": (_i, [_vp, _vp]),
     "lseg_set_text_cache": (_i, [_vp, _i]),
     "lseg_get_text_features": (_i, [_vp, _vp, _vp]),

@@ -139,6 +139,17 @@ class HipEngine:
         self._K = K
         self._group = int(labels_per_image)
 
+    def set_text_features(self, feat: torch.Tensor):
+        """fp16 [K, out_c] text features computed elsewhere (un-normalised `encode_text` output or already normalised): replaces the
+        tokens; the engine's text tower is not run until set_tokens is called again (lseg_set_text_features)."""
+        f = feat.detach().to(self.device, torch.float16).contiguous()
+        if f.dim() != 2 or f.shape[1] != self.cfg.out_c:
+            raise ValueError(f"text features must be [K, {self.cfg.out_c}], got {tuple(f.shape)}")
+        _lib.check(self.lib.lseg_set_text_features(self._h, C.c_void_p(f.data_ptr()), f.shape[0], C.c_void_p(_stream_ptr(self.device))))
+        self._keep = [f]
+        self._K = f.shape[0]
+        self._group = 0
+
     def encode_text(self) -> torch.Tensor:
         _lib.check(self.lib.lseg_encode_text(self._h, C.c_void_p(_stream_ptr(self.device))))
         out = torch.empty((self._K, self.cfg.out_c), dtype=torch.float16, device=self.device)

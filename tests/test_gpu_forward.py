@@ -535,3 +535,18 @@ def test_split_k_residual_gemms_at_small_batch_equal_the_unsplit_schedule(tmp_pa
         assert a.shape == b.shape and torch.isfinite(a).all()
         d = (a - b).abs().max().item()
         assert 0 < d <= 2e-2, d          # > 0: the split schedule really ran (101 tokens x 1024: 8 tiles -> 4 / 8 K-ranges); tiny: fp32 order + fp16 re-rounding
+
+
+def test_text_features_handed_in_replace_the_text_tower():
+    """lseg_set_text_features: features from `encode_text` handed back in give the same logits as the tokens did (the
+    fp16 L2 normalisation is idempotent up to one rounding), the text tower is no longer run, and set_tokens switches back."""
+    cfg, sd, tok, x, eng, logits, amax = run_engine(MG.CASES["tiny16_64x64_k5"], debug=False)
+    feat = eng.encode_text()                              # normalised fp16 [K, out_c]
+    eng2 = HipEngine(cfg, x.shape[2], x.shape[3], max_batch=x.shape[0], max_labels=tok.shape[0])
+    eng2.load_state_dict(sd)
+    eng2.set_text_features(feat * 3.0)                    # any scale: the engine normalises
+    out = eng2.forward(x.cuda())
+    torch.cuda.synchronize()
+    assert (out - logits).abs().max().item() <= 2e-2
+    eng2.set_tokens(tok)
+    assert torch.equal(eng2.forward(x.cuda()), logits)
