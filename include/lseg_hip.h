@@ -88,7 +88,10 @@ typedef struct {
                                * reference's HALF-precision backward of `logit_scale * image_features.half() @ text_features.t()`
                                * (lseg_net.py:194): there d(logits), dA = d(logits) @ text and logit_scale * dA are fp16 tensors, and with
                                * d(logits) ~ 1 / (valid pixels) ~ 1e-6 they sit in fp16's subnormal range (step 6e-8) -- softmax
-                               * probabilities below ~N * 3e-8 flush to zero.  Default (bit clear) = the reference's arithmetic. */
+                               * probabilities below ~N * 3e-8 flush to zero.  Default (bit clear) = the reference's arithmetic.
+                               * bit 2: batch-invariant schedule -- no split-K at small batches, so every GEMM accumulates K in one order
+                               * whatever the batch size and image b of a batch equals the same image run alone to fp32 round-off
+                               * (default: attn.proj / mlp.fc2 / the deep 3x3 convs split their contraction when B <= ~6) */
 } lseg_config;
 
 typedef struct lseg_engine* lseg_handle;

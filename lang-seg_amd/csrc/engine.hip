@@ -532,7 +532,7 @@ int Engine::conv3x3(const void* in, const Lin& w, const void* res, const void* r
     // Small batches: the deep levels of the pyramid are a handful of tiles with a 36..144-step contraction (layer3_rn at B = 1: 60 tiles of
     // 64 x 64, K = 9216, 95 us on a quarter of the chip).  Split-K work items into fp32 slabs + one streaming epilogue kernel.
     static const int split_on = getenv("LSEG_SPLITK") ? atoi(getenv("LSEG_SPLITK")) : 1;
-    if (split_on && !train_mode && !strict_ && !relu_in && (w.n % 64) == 0) {
+    if (split_on && !(cfg.flags & 4) && !train_mode && !strict_ && !relu_in && (w.n % 64) == 0) {
         const int nk = w.k / 64;
         const long tiles = (long)((g.M + 63) / 64) * (w.n / 64);
         long ns = 512 / tiles;
@@ -671,7 +671,7 @@ int Engine::get_profile(const char* family, double* ms, int64_t* launches, doubl
 // (launch_layernorm_reduce) -- no extra launch, no atomics, deterministic.  Returns ns (0: the GEMM was left as it is).
 int Engine::split_residual(GemmArgs& g, int M, int N, int K) {
     static const int enabled = getenv("LSEG_SPLITK") ? atoi(getenv("LSEG_SPLITK")) : 1;      // tools: 0 switches it off
-    if (strict_ || !enabled || (N % 256) != 0) return 0;
+    if (strict_ || !enabled || (cfg.flags & 4) || (N % 256) != 0) return 0;
     // Tile and split factor together, from measured per-K-step costs of the two tile shapes (us per 64-deep K-step of one work item on
     // one CU: 256x256 2.07, 128x128 0.87, 0.81 with two work items resident; ~4 K-steps of fixed cost per item; tools/step_probe.py
     // sweeps): a CU works through ceil(items / CUs) items; the slabs cost the LayerNorm ns * M * N * 4 bytes at ~4 TB/s.

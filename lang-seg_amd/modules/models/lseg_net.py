@@ -142,6 +142,8 @@ class LSeg(BaseModel):
         # the per-logit gradient of a mean over 1.8 M pixels is ~1e-7 and would flush to zero in fp16.
         self.image_dtype = kwargs.get("image_dtype", DEFAULT_IMAGE_DTYPE)
         self.cache_text = kwargs.get("cache_text", False)
+        # image b of a batch == the same image alone to fp32 round-off (no split-K at small batches): validation / regression runs
+        self.batch_invariant = kwargs.get("batch_invariant", False)
         # DDP-wrapper mode: hand the parameter gradients to autograd (DistributedDataParallel's hooks then reduce them) instead of
         # writing them behind .grad and exchanging the flat buckets ourselves
         self.autograd_grads = bool(kwargs.get("autograd_grads", os.environ.get("LSEG_AUTOGRAD_GRADS", "") not in ("", "0")))
@@ -178,7 +180,8 @@ class LSeg(BaseModel):
                 eng.close()
             eng = HipEngine(self.cfg, H, W, max_batch=max(B, eng.max_batch if eng else 1),
                             max_labels=max(K, eng.max_labels if eng else 1), device=device,
-                            image_dtype="bf16" if train else self.image_dtype)
+                            image_dtype="bf16" if train else self.image_dtype,
+                            batch_invariant=bool(getattr(self, "batch_invariant", False)))
             eng._stamp = None
             eng._tok = None
             eng._ts = None

@@ -286,7 +286,7 @@ def test_vitl16_batch_of_8_equals_single_image_runs():
     sd = synthetic_state_dict(cfg, seed=seed)
     tok = synthetic_tokens(read_labels(MG.LABELS)[:K], cfg.text.vocab, cfg.text.ctx)
     x = synthetic_images(8, H, W, seed=seed + 7).cuda()
-    eng = HipEngine(cfg, H, W, max_batch=8, max_labels=K)
+    eng = HipEngine(cfg, H, W, max_batch=8, max_labels=K, batch_invariant=True)     # (default engines split K at B = 1: other rounding)
     eng.load_state_dict(sd)
     eng.set_tokens(tok)
     batch = eng.forward(x, want_logits=False, want_argmax=True)
