@@ -45,8 +45,19 @@ __global__ __launch_bounds__(64 * NW, 3) void lseg_attention_kernel(const AttnAr
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform
     const int hi = lane >> 5, ql = lane & 31;
-    const int bh = blockIdx.y;
-    const int q0 = (blockIdx.x * NW + w) * 32;
+    // XCD-aware block -> (query block, head) map.  Workgroups are dealt to the 8 XCDs round-robin in linear order (x fastest), so with
+    // the plain map XCD c would run query block c of EVERY head and each of the 8 private L2s would stream every head's K / V^T
+    // (measured: L2 hit rate 27 %, 1.27 GB of fabric traffic per launch = 6.3 TB/s at B = 36 -- the kernel was fabric-bound).  Here all
+    // query blocks of a head run on ONE XCD, back to back: its K / V^T (256 KB) is fetched once into that XCD's 4 MB L2.
+    const int nqb = (a.ntok + 32 * NW - 1) / (32 * NW), BH = a.B * a.H;       // 1-D grid of nqb * BH workgroups
+    const int L = blockIdx.x;
+    int qb = L % nqb, bh = L / nqb;
+    if ((BH & 7) == 0) {
+        const int xcd = L & 7, idx = L >> 3;
+        qb = idx % nqb;
+        bh = (idx / nqb) * 8 + xcd;
+    }
+    const int q0 = (qb * NW + w) * 32;
     const uint16_t* Q = a.q + (size_t)bh * a.npad * 64;
     const uint16_t* K = a.k + (size_t)bh * a.npad * 64;
     const uint16_t* Vt = a.vt + (size_t)bh * 64 * a.npad;
@@ -63,7 +74,7 @@ __global__ __launch_bounds__(64 * NW, 3) void lseg_attention_kernel(const AttnAr
 
     int kv_end = a.ntok;
     if (a.causal) {
-        const int qend = (blockIdx.x + 1) * 32 * NW;
+        const int qend = (qb + 1) * 32 * NW;
         kv_end = qend < a.ntok ? qend : a.ntok;
     }
     const int n_tiles = (kv_end + 63) >> 6;
@@ -237,11 +248,11 @@ int launch_attention_lse(const void* q, const void* k, const void* vt, void* out
     static const int force_nw = getenv("LSEG_ATTN_WAVES") ? atoi(getenv("LSEG_ATTN_WAVES")) : 0;      // tools: 2 | 4
     const bool narrow = force_nw ? force_nw == 2 : ((long)((ntok + 127) / 128) * B * H < 2L * device_cu_count(dev) && !causal);
     if (narrow) {
-        dim3 grid((ntok + 63) / 64, B * H);
+        dim3 grid(((ntok + 63) / 64) * B * H);
         if (dtype == DT_BF16) hipLaunchKernelGGL((lseg_attention_kernel<BF16, 2>), grid, dim3(128), lds, stream, a);
         else hipLaunchKernelGGL((lseg_attention_kernel<F16, 2>), grid, dim3(128), lds, stream, a);
     } else {
-        dim3 grid((ntok + 127) / 128, B * H);
+        dim3 grid(((ntok + 127) / 128) * B * H);
         if (dtype == DT_BF16) hipLaunchKernelGGL((lseg_attention_kernel<BF16, 4>), grid, dim3(256), lds, stream, a);
         else hipLaunchKernelGGL((lseg_attention_kernel<F16, 4>), grid, dim3(256), lds, stream, a);
     }

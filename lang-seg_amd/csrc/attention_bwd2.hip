@@ -102,6 +102,18 @@ __device__ __forceinline__ void store_rows(const f32x16_t (&o)[2], uint16_t* row
         }
 }
 
+// XCD-aware block -> (row block, head) map (as in attention.hip): all row blocks of a head run on one XCD, back to back, so the head's
+// streamed operands are fetched into ONE private L2 instead of all eight.  1-D grid of nb * BH workgroups.
+__device__ __forceinline__ void xcd_head_map(int nb, int BH, int& blk, int& bh) {
+    const int L = blockIdx.x;
+    blk = L % nb; bh = L / nb;
+    if ((BH & 7) == 0) {
+        const int xcd = L & 7, idx = L >> 3;
+        blk = idx % nb;
+        bh = (idx / nb) * 8 + xcd;
+    }
+}
+
 // ---- dQ: lane = query (per-lane L2 and D), key tiles stream through LDS: K, V [64 keys][64 d] and K^T [64 d][64 keys] ------------------
 template <typename T>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnBwd2Args a) {
@@ -110,8 +122,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnBwd2Args 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, ql = lane & 31;
-    const int bh = blockIdx.y;
-    const int q0 = (blockIdx.x * 4 + w) * 32;
+    int blk, bh;
+    xcd_head_map((a.ntok + 127) / 128, a.B * a.H, blk, bh);
+    const int q0 = (blk * 4 + w) * 32;
     const size_t hb = (size_t)bh * a.npad * 64;
     int qr = q0 + ql;
     if (qr > a.npad - 1) qr = a.npad - 1;
@@ -209,8 +222,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwd2Args
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi = lane >> 5, ql = lane & 31;
-    const int bh = blockIdx.y;
-    const int k0 = (blockIdx.x * 4 + w) * 32;
+    int blk, bh;
+    xcd_head_map((a.ntok + 127) / 128, a.B * a.H, blk, bh);
+    const int k0 = (blk * 4 + w) * 32;
     const size_t hb = (size_t)bh * a.npad * 64;
     int kr = k0 + ql;
     if (kr > a.npad - 1) kr = a.npad - 1;
@@ -343,7 +357,7 @@ int launch_attention_backward_qkv(const void* q, const void* k, const void* vt, 
     a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.v = v; a.qT = qT; a.kT = kT; a.dO = dohm; a.dOT = doT;
     a.lse2 = lse2; a.dsum = dsum; a.dqkv = (uint16_t*)dqkv;
     a.B = B; a.H = H; a.ntok = ntok; a.npad = npad; a.scale = scale; a.scale_log2e = scale * 1.4426950408889634f;
-    dim3 gp(npad / 64, B * H), g((ntok + 127) / 128, B * H);
+    dim3 gp(npad / 64, B * H), g(((ntok + 127) / 128) * B * H);
     const size_t lds_dq = 2 * 3 * 8192, lds_dkv = 2 * (4 * 8192 + 512);
 #define RUN(TT)                                                                                                                              \
     do {                                                                                                                                     \
