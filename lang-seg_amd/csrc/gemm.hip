@@ -679,7 +679,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
     // segment (16 columns) s of stage row r sits at s ^ gk(r), gk(r) = (r & 3) | ((r >> 3) & 1) << 2 -- the 8 rows a 32-lane read group
     // touches land on 8 different segments = all 64 banks.
     constexpr bool KMAJ = TAG == 2;
-    static_assert(!KMAJ || (BM == 128 && BN == 128 && !CONV), "the K-major path is built for 128 x 128 tiles");
+    static_assert(!KMAJ || (((BM == 128 && BN == 128) || (BM == 256 && BN == 256)) && !CONV), "the K-major path is built for 128 x 128 and 256 x 256 tiles");
     auto gsw = [](int r) { return (r & 3) | (((r >> 3) & 1) << 2); };
     // (the buffer / transpose-read builtins live in __device__ helpers: used directly inside a templated __global__ function they make
     // hipcc drop that instantiation's HOST stub without a diagnostic -- the library then fails to load with an undefined symbol)
@@ -717,8 +717,9 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
         if constexpr (KMAJ) {
 #pragma unroll
             for (int s = 0; s < A_SPW; ++s) {
-                const int rk = (s * NW + w) * 4 + (lane >> 4);            // stage row (k) of this lane; 4 rows of 256 B per wave instruction
-                const int c = (lane & 15) ^ (gsw(rk) << 1);                // source chunk of LDS chunk slot lane & 15
+                constexpr int LPR = BM / 8, RPI = 64 / LPR;               // lanes (16-byte chunks) per stage row; rows per 1 KB wave instruction
+                const int rk = (s * NW + w) * RPI + lane / LPR;           // stage row (k) of this lane
+                const int c = (lane % LPR) ^ (gsw(rk) << 1);              // source chunk of LDS chunk slot lane % LPR
                 a_off[s] = ((uint32_t)rk * (uint32_t)g.lda + (uint32_t)(m0 + c * 8)) * 2u;
             }
             return;
@@ -749,8 +750,9 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
             const int shift = g.kconv_cin > 0 ? (tap / 3 - 1) * g.kconv_wp + (tap % 3 - 1) : 0;
 #pragma unroll
             for (int s = 0; s < W_SPW; ++s) {
-                const int rk = (s * NW + w) * 4 + (lane >> 4);
-                const int c = (lane & 15) ^ (gsw(rk) << 1);
+                constexpr int LPR = BN / 8, RPI = 64 / LPR;
+                const int rk = (s * NW + w) * RPI + lane / LPR;
+                const int c = (lane % LPR) ^ (gsw(rk) << 1);
                 if (g.kconv_cin > 0) {      // conv taps: the row is resolved per load (it may fall outside the map: zero)
                     w_row[s] = rk + shift;
                     w_off[s] = (uint32_t)(n0 - tap * g.kconv_cin + c * 8) * 2u;
@@ -1218,6 +1220,10 @@ int dispatch(const GemmArgs& g, hipStream_t stream) {
         if (select_epi<T>(g) != EPI_PART32 || g.conv || (g.relu_in && !g.kconv_cin) || (g.kconv_cin && ((g.kconv_cin % 128) || g.ldw != g.kconv_cin)) || g.k_valid < 1 || g.k_valid > g.K || g.K - g.k_valid >= 64 ||
             (double)g.k_valid * g.lda * 2 >= 2.0e9 || (double)g.k_valid * g.ldw * 2 >= 2.0e9)
             return set_error(LSEG_ERR_UNSUPPORTED, "K-major GEMM: needs fp32 slab output (MAP_LINEAR, no bias / residual), N %% 128 == 0, operands < 2 GB");
+        if (g.tile_hint == 6 && (g.N % 256) == 0) {
+            if (g.relu_in) return launch_one<T, CfgHuge, false, true, EPI_PART32, 2>(g, stream);
+            return launch_one<T, CfgHuge, false, false, EPI_PART32, 2>(g, stream);
+        }
         if (g.relu_in) return launch_one<T, CfgMid, false, true, EPI_PART32, 2>(g, stream);
         return launch_one<T, CfgMid, false, false, EPI_PART32, 2>(g, stream);
     }

@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 
 #include "engine.h"
 
@@ -423,6 +424,29 @@ int Engine::pick_split(int M, int N, int nk, GemmArgs& g) {
 }
 
 // ---- weight gradient straight from the row-major operands (gemm.hip "K-MAJOR operands") ------------------------------------------------
+// tile + split-K plan of a K-major wgrad [rows x cols] over nk K-steps: 128 x 128 tiles cut into ~2 work items per CU of >= 8 K-steps.
+// 256 x 256 tiles (LSEG_WGRAD_TILE=6; fewer LDS fragment reads per MFMA, one workgroup per CU) are built and parity-tested but measured
+// 2 % slower on the whole training step (45.4 vs 44.6 ms, profiles/r03_train_experiments.txt), so they stay a tool switch
+static void plan_kmajor(GemmArgs& g, int rows, int cols, int nk, size_t ws_floats) {
+    static const int force = getenv("LSEG_WGRAD_TILE") ? atoi(getenv("LSEG_WGRAD_TILE")) : 0;      // tools: 6 = 256 x 256 tiles
+    auto plan = [&](long tiles, long target) {
+        long ns = (target + tiles - 1) / tiles;
+        if (ns > nk / 8) ns = nk / 8;
+        while (ns > 1 && (size_t)ns * rows * cols > ws_floats) --ns;
+        if (ns < 1) ns = 1;
+        const int steps = (int)((nk + ns - 1) / ns);
+        return std::pair<int, int>((int)((nk + steps - 1) / steps), steps);
+    };
+    const long t_mid = (long)((rows + 127) / 128) * (cols / 128), t_huge = (long)((rows + 255) / 256) * ((cols + 255) / 256);
+    auto pm = plan(t_mid, 512), ph = plan(t_huge, 512);
+    const bool can_huge = (cols % 256) == 0 && (g.kconv_cin == 0 || (g.kconv_cin % 256) == 0);      // a tile's columns stay inside one conv tap
+    const bool huge = force == 6 && can_huge && rows >= 192;
+    g.tile_hint = huge ? 6 : 2;
+    g.nsplit = huge ? ph.first : pm.first;
+    g.split_steps = huge ? ph.second : pm.second;
+    g.c_split_stride = (size_t)rows * cols;
+}
+
 bool wgrad_kmajor_ok(int rows_out, int cols_out, size_t ws_floats) {
     static const bool off = getenv("LSEG_WGRAD_TRANSPOSE") != nullptr;           // tools: A/B switch back to the transposing path
     return !off && rows_out >= 1 && (cols_out % 128) == 0 && (size_t)rows_out * cols_out <= ws_floats;
@@ -436,17 +460,10 @@ int launch_wgrad_kmajor(const void* dy, int ldy, const void* x, int ldx, int M, 
     g.A = (const uint16_t*)dy; g.lda = ldy; g.W = (const uint16_t*)x; g.ldw = ldx;
     g.M = rows_out; g.N = cols_out; g.K = Kp; g.kmajor = 1; g.k_valid = M;
     g.C = ws; g.out_dtype = DT_F32; g.ldc = cols_out; g.map_mode = MAP_LINEAR;
-    // split plan: ~2 work items per CU with 128 x 128 tiles, >= 8 K-steps each, slabs within the scratch
-    const long tiles = (long)((rows_out + 127) / 128) * (cols_out / 128);
-    long ns = (2L * 256 + tiles - 1) / tiles;
-    if (ns > nk / 8) ns = nk / 8;
-    while (ns > 1 && (size_t)ns * rows_out * cols_out > ws_floats) --ns;
-    if (ns < 1) ns = 1;
-    const int steps = (int)((nk + ns - 1) / ns);
-    ns = (nk + steps - 1) / steps;
-    g.nsplit = (int)ns; g.split_steps = steps; g.c_split_stride = (size_t)rows_out * cols_out;
+    plan_kmajor(g, rows_out, cols_out, nk, ws_floats);
+    const int ns = g.nsplit;
     TRY(launch_gemm(g, ab_dtype, st));
-    return launch_sum_partials(ws, dw, (int)ns, (size_t)rows_out * cols_out, g.c_split_stride, accumulate, st);
+    return launch_sum_partials(ws, dw, ns, (size_t)rows_out * cols_out, g.c_split_stride, accumulate, st);
 }
 
 int launch_conv_wgrad_kmajor(const void* dy_pad, const void* x_pad, int relu_x, int B, int H, int W, int Cin, int Cout, float* ws, size_t ws_floats,
@@ -458,15 +475,9 @@ int launch_conv_wgrad_kmajor(const void* dy_pad, const void* x_pad, int relu_x, 
     g.A = (const uint16_t*)dy_pad; g.lda = Cout; g.W = (const uint16_t*)x_pad; g.ldw = Cin; g.M = Cout; g.N = 9 * Cin; g.K = nk * 64;
     g.kmajor = 1; g.k_valid = Mp; g.kconv_cin = Cin; g.kconv_wp = W + 2; g.relu_in = relu_x ? 1 : 0;
     g.C = ws; g.out_dtype = DT_F32; g.ldc = 9 * Cin; g.map_mode = MAP_LINEAR;
-    const long tiles = (long)((Cout + 127) / 128) * (9 * Cin / 128);
-    long ns = (2L * 256 + tiles - 1) / tiles;
-    if (ns > nk / 8) ns = nk / 8;
-    while (ns > 1 && (size_t)ns * Cout * 9 * Cin > ws_floats) --ns;
-    if (ns < 1) ns = 1;
-    const int steps = (int)((nk + ns - 1) / ns);
-    ns = (nk + steps - 1) / steps;
-    g.nsplit = (int)ns; g.split_steps = steps; g.c_split_stride = (size_t)Cout * 9 * Cin;
-    if (ns_out) *ns_out = (int)ns;
+    plan_kmajor(g, Cout, 9 * Cin, nk, ws_floats);
+    const int ns = g.nsplit;
+    if (ns_out) *ns_out = ns;
     return launch_gemm(g, ab_dtype, st);
 }
 
