@@ -102,8 +102,9 @@ private:
     int forward_train(const float* x, int B, float* logits, hipStream_t st);
     int rcu_train(const uint16_t* in, Rcu& U, const uint16_t* res2, uint16_t* out, int B, int H, int W, hipStream_t st);
     int rcu_backward(const uint16_t* dout, const uint16_t* in, Rcu& U, uint16_t* din, int lev, int B, int H, int W, int acc, hipStream_t st);
+    int linear_gelu_saved(GemmArgs& g, uint16_t* pre, uint16_t* out, hipStream_t st);
     int lin_bwd(const uint16_t* dy, int M, int N, int K, const uint16_t* x, const uint16_t* wt, uint16_t* dx, float* dw, float* db,
-                int acc, hipStream_t st, int dw_rows = -1);
+                int acc, hipStream_t st, int dw_rows = -1, const uint16_t* dgelu_pre = nullptr);
     int conv_bwd(const uint16_t* dy_pad, const uint16_t* x_pad, int relu_x, const Lin& w, uint16_t* dx_pad, float* dw_dst, int B, int H,
                  int W, int Cin, int Cout, int Ci_real, int Co_real, int acc, hipStream_t st);
     int pick_split(int M, int N, int nk, GemmArgs& g);

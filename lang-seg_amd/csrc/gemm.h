@@ -46,6 +46,10 @@ struct GemmArgs {
     void* C_relu;               // MAP_PADDED on the specialised epilogue only (gemm_epilogue_is_pad16): a second copy ReLU(C), same geometry --
                                 // the DPT residual units read ReLU(x) as conv input and x as skip (lseg_blocks.py:270-288): clamping the
                                 // A fragments in the K-loop instead costs the 3x3 convs a third of their MFMA rate
+    // training-step fusions of the MLP's GELU (plain MAP_LINEAR 16-bit GEMMs on the specialised epilogue only; gemm_fuses_gelu tells):
+    void* C_pre;                // with act = ACT_GELU: also store the 16-bit pre-activation z = T(acc + bias) here (same geometry as C); C gets
+                                // T(gelu(z)) of the ROUNDED z, so the pair equals a Linear followed by a GELU pass over its stored output
+    const void* dgelu_pre;      // C = T((acc + bias) * gelu'(z)), z read from here (16-bit, same geometry as C): dX of fc2 through the GELU
     int map_mode;
     int p_div, p_mul, p_off;    // MAP_PERIODIC / RES_PERIODIC / MAP_NCHW(P)
     int ps_s, ps_C;             // MAP_PIXSHUF
@@ -85,5 +89,7 @@ int device_cu_count(int dev);
 int launch_gemm(const GemmArgs& g, int ab_dtype, hipStream_t stream);
 // true when launch_gemm would run this problem on the specialised padded-NHWC epilogue (the one that honours C_relu)
 bool gemm_epilogue_is_pad16(const GemmArgs& g, int ab_dtype);
+// true when launch_gemm would honour g.C_pre / g.dgelu_pre (it refuses them otherwise)
+bool gemm_fuses_gelu(const GemmArgs& g, int ab_dtype);
 
 }  // namespace lseg

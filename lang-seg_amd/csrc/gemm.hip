@@ -63,6 +63,15 @@ __device__ __forceinline__ float erf_as(float x) {
     return x < 0.f ? -e : e;
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
+// d/dz of the erf GELU: Phi(z) + z * phi(z); the exponential of the erf approximation IS exp(-z^2 / 2)
+__device__ __forceinline__ float gelu_grad_as(float z) {
+    const float ax = fabsf(z) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float ex = __expf(-ax * ax);
+    const float e = 1.0f - poly * ex;
+    return 0.5f * (1.0f + (z < 0.f ? -e : e)) + z * 0.3989422804014327f * ex;
+}
 // The same GELU on two values at once: the polynomial runs on v_pk_fma_f32 / v_pk_mul_f32 (packed
 // fp32), only rcp and exp2 stay per-element: 21 VALU per pair instead of ~40.
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -381,6 +390,8 @@ enum Epi {
     EPI_PAD16 = 5,        // MAP_PADDED NHWC (1-pixel zero border), T(act(acc + bias) [+ res [+ res2]]): the DPT head's 3x3 convs
     EPI_LIN16_F16 = 6,    // MAP_LINEAR, C = fp16(acc + bias) from bf16 operands: the commuted head's g (the fp16 operand of the correlation)
     EPI_PIX16 = 7,        // MAP_PIXSHUF, T(acc + bias[n % C]): ConvTranspose2d(k = s) as a GEMM whose columns scatter to the s x s sub-pixels
+    EPI_LIN16_GELU2 = 9,  // C_pre[m*ldc+n] = z = T(acc + bias), C[m*ldc+n] = T(gelu(z))   (MLP fc1 of the training forward)
+    EPI_LIN16_DGELU = 10, // C[m*ldc+n] = T((acc + bias) * gelu'(pre[m*ldc+n]))            (dX of the MLP fc2, through the GELU)
     EPI_PART32 = 8,       // split-K partial slab: C[split * c_split_stride + m*ldc + n] = acc, fp32, no bias (weight gradients; the residual GEMMs
                           // of small batches, whose slabs the following LayerNorm sums into the fp32 residual stream)
 };
@@ -407,18 +418,44 @@ __device__ __forceinline__ void fast_epilogue(const GemmArgs& g, f32x4_t (&acc)[
         v[0] = acc[i][j][0] + bias[i].x; v[1] = acc[i][j][1] + bias[i].y;
         v[2] = acc[i][j][2] + bias[i].z; v[3] = acc[i][j][3] + bias[i].w;
     };
-    if constexpr (EPI == EPI_LIN16 || EPI == EPI_LIN16_GELU || EPI == EPI_LIN16_F16) {
+    if constexpr (EPI == EPI_LIN16 || EPI == EPI_LIN16_GELU || EPI == EPI_LIN16_F16 || EPI == EPI_LIN16_GELU2 || EPI == EPI_LIN16_DGELU) {
         using OT = typename std::conditional<EPI == EPI_LIN16_F16, F16, T>::type;
         uint16_t* cbase = (uint16_t*)g.C + ncol0 + cw;
         static_for<0, MI>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             const int m = mrow0 + j * 16 + ml;
             uint16_t* p = cbase + (size_t)m * g.ldc;
+            uint2 zv[EPI == EPI_LIN16_DGELU ? NI : 1];
+            if constexpr (EPI == EPI_LIN16_DGELU) {      // this lane's pre-activations of the row: all loads in flight before the math
+                const uint16_t* zp = (const uint16_t*)g.dgelu_pre + (size_t)(m < g.M ? m : g.M - 1) * g.ldc + ncol0 + r16 * 4;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) zv[i] = *reinterpret_cast<const uint2*>(zp + i * 16);
+            }
             static_for<0, NI / 2>([&](auto pc) {
                 constexpr int i = 2 * decltype(pc)::value;
                 float x[4], y[4];
                 biased(std::integral_constant<int, i>{}, jc, x);
                 biased(std::integral_constant<int, i + 1>{}, jc, y);
+                if constexpr (EPI == EPI_LIN16_DGELU) {
+                    const uint2 u = zv[i], v = zv[i + 1];
+                    x[0] *= gelu_grad_as(to_f32<T>((uint16_t)u.x)); x[1] *= gelu_grad_as(to_f32<T>((uint16_t)(u.x >> 16)));
+                    x[2] *= gelu_grad_as(to_f32<T>((uint16_t)u.y)); x[3] *= gelu_grad_as(to_f32<T>((uint16_t)(u.y >> 16)));
+                    y[0] *= gelu_grad_as(to_f32<T>((uint16_t)v.x)); y[1] *= gelu_grad_as(to_f32<T>((uint16_t)(v.x >> 16)));
+                    y[2] *= gelu_grad_as(to_f32<T>((uint16_t)v.y)); y[3] *= gelu_grad_as(to_f32<T>((uint16_t)(v.y >> 16)));
+                }
+                if constexpr (EPI == EPI_LIN16_GELU2) {
+                    // store the rounded pre-activation, then take the GELU of exactly those values
+                    const uint32_t a0 = pack2<T>(x[0], x[1]), a1 = pack2<T>(x[2], x[3]), b0 = pack2<T>(y[0], y[1]), b1 = pack2<T>(y[2], y[3]);
+                    const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                    if (m < g.M) *reinterpret_cast<uint4*>((uint16_t*)g.C_pre + (size_t)m * g.ldc + ncol0 + cw + i * 16) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    const f32x2_t a = gelu_erf2(f32x2_t{to_f32<T>((uint16_t)a0), to_f32<T>((uint16_t)(a0 >> 16))});
+                    const f32x2_t b = gelu_erf2(f32x2_t{to_f32<T>((uint16_t)a1), to_f32<T>((uint16_t)(a1 >> 16))});
+                    const f32x2_t c = gelu_erf2(f32x2_t{to_f32<T>((uint16_t)b0), to_f32<T>((uint16_t)(b0 >> 16))});
+                    const f32x2_t d = gelu_erf2(f32x2_t{to_f32<T>((uint16_t)b1), to_f32<T>((uint16_t)(b1 >> 16))});
+                    x[0] = a[0]; x[1] = a[1]; x[2] = b[0]; x[3] = b[1];
+                    y[0] = c[0]; y[1] = c[1]; y[2] = d[0]; y[3] = d[1];
+                }
                 if constexpr (EPI == EPI_LIN16_GELU) {
                     const f32x2_t a = gelu_erf2(f32x2_t{x[0], x[1]}), b = gelu_erf2(f32x2_t{x[2], x[3]});
                     const f32x2_t c = gelu_erf2(f32x2_t{y[0], y[1]}), d = gelu_erf2(f32x2_t{y[2], y[3]});
@@ -1198,6 +1235,10 @@ int select_epi(const GemmArgs& g) {
         return EPI_PAD16;
     if (g.conv) return EPI_GENERIC;
     if (g.map_mode == MAP_LINEAR && g.res_mode == RES_NONE && g.out_dtype == dt && (g.ldc % 8) == 0) {
+        const bool al = !((reinterpret_cast<uintptr_t>(g.C_pre) | reinterpret_cast<uintptr_t>(g.dgelu_pre)) & 15);
+        if (g.act == ACT_NONE && g.dgelu_pre && !g.C_pre && al) return EPI_LIN16_DGELU;
+        if (g.act == ACT_GELU && g.C_pre && !g.dgelu_pre && al) return EPI_LIN16_GELU2;
+        if (g.C_pre || g.dgelu_pre) return EPI_GENERIC;
         if (g.act == ACT_NONE) return EPI_LIN16;
         if (g.act == ACT_GELU) return EPI_LIN16_GELU;
         return EPI_GENERIC;
@@ -1253,6 +1294,8 @@ int dispatch(const GemmArgs& g, hipStream_t stream) {
             return pick_tile<T, false, false, EPI_LIN16_GELU, 0>(g, stream);
         case EPI_RES32: return pick_tile<T, false, false, EPI_RES32, 0>(g, stream);
         case EPI_LIN16_F16: return pick_tile<T, false, false, EPI_LIN16_F16, 0>(g, stream);
+        case EPI_LIN16_GELU2: return pick_tile<T, false, false, EPI_LIN16_GELU2, 0>(g, stream);
+        case EPI_LIN16_DGELU: return pick_tile<T, false, false, EPI_LIN16_DGELU, 0>(g, stream);
         case EPI_PIX16: return pick_tile<T, false, false, EPI_PIX16, 0>(g, stream);
         case EPI_QKV16: return pick_tile<T, false, false, EPI_QKV16, 0>(g, stream);
         case EPI_PART32: return pick_tile<T, false, false, EPI_PART32, 0>(g, stream);
@@ -1268,6 +1311,13 @@ bool gemm_epilogue_is_pad16(const GemmArgs& g, int ab_dtype) {
     return false;
 }
 
+bool gemm_fuses_gelu(const GemmArgs& g, int ab_dtype) {
+    static const bool off = getenv("LSEG_NO_GELU_FUSE") != nullptr;       // tools: A/B switch back to the separate GELU passes
+    if (off) return false;
+    const int e = ab_dtype == DT_BF16 ? select_epi<BF16>(g) : ab_dtype == DT_F16 ? select_epi<F16>(g) : EPI_GENERIC;
+    return !g.conv && !g.kmajor && g.map_mode != MAP_ROWNORM && (e == EPI_LIN16_GELU2 || e == EPI_LIN16_DGELU);
+}
+
 int launch_gemm(const GemmArgs& g_in, int ab_dtype, hipStream_t stream) {
     GemmArgs g = g_in;
     static const int dbg = getenv("LSEG_GEMM_DBG") ? atoi(getenv("LSEG_GEMM_DBG")) : 0;
@@ -1275,6 +1325,8 @@ int launch_gemm(const GemmArgs& g_in, int ab_dtype, hipStream_t stream) {
     static const int group_m = getenv("LSEG_GEMM_GROUP_M") ? atoi(getenv("LSEG_GEMM_GROUP_M")) : 8;   // tools: L2 locality sweeps
     g.group_m = group_m > 0 ? group_m : 8;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return set_error(LSEG_ERR_INVALID, "gemm: empty problem %dx%dx%d", g.M, g.N, g.K);
+    if ((g.C_pre || g.dgelu_pre) && !gemm_fuses_gelu(g, ab_dtype))
+        return set_error(LSEG_ERR_UNSUPPORTED, "gemm: C_pre / dgelu_pre need the specialised 16-bit MAP_LINEAR epilogue (N %% 128 == 0, a bias, 16-byte rows)");
     if (g.C_relu && !gemm_epilogue_is_pad16(g, ab_dtype)) return set_error(LSEG_ERR_UNSUPPORTED, "gemm: C_relu needs the padded-NHWC specialised epilogue");
     if (g.K % 64 != 0) return set_error(LSEG_ERR_UNSUPPORTED, "gemm: K=%d must be a multiple of 64", g.K);
     if (g.conv && (g.cin % 64 != 0)) return set_error(LSEG_ERR_UNSUPPORTED, "conv: Cin=%d must be a multiple of 64", g.cin);

@@ -324,9 +324,8 @@ int Engine::forward_train(const float* x_in, int B, float* logits, hipStream_t s
         TRY(launch_layernorm(s.xmid, DT_F32, b.g2, b.b2, s.ln2, img_dt_, M, D, 1e-6f, st));
         gemm_args_init(g);
         g.A = s.ln2; g.W = b.fc1.w; g.M = M; g.N = 4 * D; g.K = D; g.lda = D; g.ldw = D;
-        g.bias = b.fc1.b; g.C = s.pre; g.out_dtype = img_dt_; g.ldc = 4 * D; g.map_mode = MAP_LINEAR;
-        TRY(launch_gemm(g, img_dt_, st));
-        TRY(launch_gelu_forward(s.pre, s.mlp, (size_t)M * 4 * D, img_dt_, st));
+        g.bias = b.fc1.b; g.out_dtype = img_dt_; g.ldc = 4 * D; g.map_mode = MAP_LINEAR;
+        TRY(linear_gelu_saved(g, s.pre, s.mlp, st));
         gemm_args_init(g);
         g.A = s.mlp; g.W = b.fc2.w; g.M = M; g.N = D; g.K = 4 * D; g.lda = 4 * D; g.ldw = 4 * D;
         g.bias = b.fc2.b; g.res_mode = RES_DEST; g.res = s.xmid; g.res_dtype = DT_F32;
@@ -339,9 +338,8 @@ int Engine::forward_train(const float* x_in, int B, float* logits, hipStream_t s
             TRY(launch_readout_cat(xout, v.cat, B, ntok_, D, img_dt_, st));
             gemm_args_init(g);
             g.A = v.cat; g.W = readout_[l].w; g.M = B * np_; g.N = D; g.K = 2 * D; g.lda = 2 * D; g.ldw = 2 * D;
-            g.bias = readout_[l].b; g.C = v.ropre; g.out_dtype = img_dt_; g.ldc = D; g.map_mode = MAP_LINEAR;
-            TRY(launch_gemm(g, img_dt_, st));
-            TRY(launch_gelu_forward(v.ropre, v.ro, (size_t)B * np_ * D, img_dt_, st));
+            g.bias = readout_[l].b; g.out_dtype = img_dt_; g.ldc = D; g.map_mode = MAP_LINEAR;
+            TRY(linear_gelu_saved(g, v.ropre, v.ro, st));
             gemm_args_init(g);
             g.A = v.ro; g.W = r1x1_[l].w; g.M = B * np_; g.N = C; g.K = D; g.lda = D; g.ldw = D;
             g.bias = r1x1_[l].b; g.out_dtype = img_dt_; g.ldc = C;
@@ -481,18 +479,33 @@ int launch_conv_wgrad_kmajor(const void* dy_pad, const void* x_pad, int relu_x, 
     return launch_gemm(g, ab_dtype, st);
 }
 
+// Linear + GELU of the training forward: z = x W^T + b is kept for the backward, gelu(z) feeds the next Linear.  One launch where the
+// GEMM's specialised epilogue fits (both stores from the accumulators), else the GEMM and a GELU pass over its output.
+int Engine::linear_gelu_saved(GemmArgs& g, uint16_t* pre, uint16_t* out, hipStream_t st) {
+    g.act = ACT_GELU; g.C = out; g.C_pre = pre;
+    if (gemm_fuses_gelu(g, img_dt_)) return launch_gemm(g, img_dt_, st);
+    g.act = ACT_NONE; g.C = pre; g.C_pre = nullptr;
+    TRY(launch_gemm(g, img_dt_, st));
+    return launch_gelu_forward(pre, out, (size_t)g.M * g.N, img_dt_, st);
+}
+
 // ---- Linear backward on the forward MFMA kernel (contraction dimension transposed onto the fast axis) ---------------------------
 //   dx [M,K] = dy [M,N] . W [N,K]     (A = dy, "weights" = wt = W^T [K,N])
 //   dw [N,K] = dy^T . x               (A = dy^T [N,Mp], "weights" = x^T [K,Mp]; fp32, written in the parameter's own layout)
 //   db [N]   = column sums of dy
 int Engine::lin_bwd(const uint16_t* dy, int M, int N, int K, const uint16_t* x, const uint16_t* wt, uint16_t* dx, float* dw, float* db,
-                    int acc, hipStream_t st, int dw_rows) {
+                    int acc, hipStream_t st, int dw_rows, const uint16_t* dgelu_pre) {
     GemmArgs g;
     if (dx) {
         gemm_args_init(g);
         g.A = dy; g.W = wt; g.M = M; g.N = K; g.K = N; g.lda = N; g.ldw = N;
         g.bias = zeros_; g.C = dx; g.out_dtype = img_dt_; g.ldc = K; g.map_mode = MAP_LINEAR;
+        // dgelu_pre: x = gelu(z) came out of a GELU; dx leaves as d z = (dy . W) * gelu'(z), in the GEMM epilogue where it can
+        g.dgelu_pre = dgelu_pre;
+        const bool fused = dgelu_pre && gemm_fuses_gelu(g, img_dt_);
+        if (!fused) g.dgelu_pre = nullptr;
         TRY(launch_gemm(g, img_dt_, st));
+        if (dgelu_pre && !fused) TRY(launch_gelu_backward(dx, dgelu_pre, dx, (size_t)M * K, img_dt_, st));
     }
     if (dw && wgrad_kmajor_ok(dw_rows > 0 ? dw_rows : N, K, ws_part_n_)) {
         TRY(launch_wgrad_kmajor(dy, N, x, K, M, dw_rows > 0 ? dw_rows : N, K, dw, acc, ws_part_, ws_part_n_, img_dt_, st));
@@ -635,7 +648,7 @@ int Engine::reassemble_backward(int l, int B, int acc, hipStream_t st) {
         d_r1 = rowsB_;
     }
     // 1x1 conv: the weight gradient is written straight into [C, D] (the padded rows >= C are not computed)
-    TRY(lin_bwd(d_r1, Mr, Cp, D, v.ro, r1x1_[l].wt, v.dro, grad(a + "3.weight", (size_t)C * D), grad(a + "3.bias", C), acc, st, C));
+    TRY(lin_bwd(d_r1, Mr, Cp, D, v.ro, r1x1_[l].wt, v.dro, grad(a + "3.weight", (size_t)C * D), grad(a + "3.bias", C), acc, st, C, v.ropre));
     return 0;
 }
 
@@ -646,7 +659,6 @@ int Engine::readout_backward(int l, int B, int acc, hipStream_t st) {
     char buf[96];
     snprintf(buf, sizeof(buf), "pretrained.act_postprocess%d.0.project.0.", l + 1);
     const std::string a = buf;
-    TRY(launch_gelu_backward(v.dro, v.ropre, v.dro, (size_t)Mr * D, img_dt_, st));
     TRY(lin_bwd(v.dro, Mr, D, 2 * D, v.cat, readout_[l].wt, rowsA_, grad(a + "weight", (size_t)D * 2 * D), grad(a + "bias", D), acc, st));
     TRY(launch_readout_cat_bwd(rowsA_, gx_, B, ntok_, D, img_dt_, st));
     g16_valid_ = false;
@@ -666,8 +678,7 @@ int Engine::block_backward(int i, int B, int acc, hipStream_t st) {
     if (!dg1 || !db1 || !dg2 || !db2) return LSEG_ERR_INVALID;
     // x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
     if (!g16_valid_) TRY(launch_convert(gx_, DT_F32, g16_, img_dt_, (size_t)M * D, st));      // else: written by the previous LayerNorm backward
-    TRY(lin_bwd(g16_, M, D, 4 * D, s.mlp, b.fc2.wt, dmlp_, G("mlp.fc2.weight", (size_t)D * 4 * D), G("mlp.fc2.bias", D), acc, st));
-    TRY(launch_gelu_backward(dmlp_, s.pre, dmlp_, (size_t)M * 4 * D, img_dt_, st));
+    TRY(lin_bwd(g16_, M, D, 4 * D, s.mlp, b.fc2.wt, dmlp_, G("mlp.fc2.weight", (size_t)D * 4 * D), G("mlp.fc2.bias", D), acc, st, -1, s.pre));
     TRY(lin_bwd(dmlp_, M, 4 * D, D, s.ln2, b.fc1.wt, dln_, G("mlp.fc1.weight", (size_t)4 * D * D), G("mlp.fc1.bias", 4 * D), acc, st));
     TRY(launch_layernorm_backward(dln_, img_dt_, s.xmid, b.g2, gx_, dg2, db2, M, D, 1e-6f, 1, st, acc, ws_ln_, g16_));
     // x_mid = x_in + proj(attention(qkv(LN1(x_in))))
