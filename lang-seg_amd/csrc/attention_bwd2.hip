@@ -28,7 +28,9 @@ struct AttnBwd2Args {
 namespace {
 
 // q,k [BH,npad,64], vt [BH,64,npad], o / dO token-major [B,ntok,H*64]  ->  qT, kT [BH,64,npad]; v, dO_hm [BH,npad,64]; dOT [BH,64,npad];
-// dsum [BH,npad].  One workgroup per (64-token block, bh); 64x64 tiles through LDS.
+// dsum [BH,npad].  One workgroup per (64-token block, bh); 64x64 tiles through LDS, 16 bytes per lane on every global access (with 2-byte
+// accesses the kernel ran at 3 TB/s: 50 us of the 150 MB it moves per layer at B = 8).  LDS rows are 66 elements: the transposing reads
+// (8 two-byte reads down a column per 16-byte store) are bank-conflict free, the row writes go in as 4-byte words.
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ k, const uint16_t* __restrict__ vt,
                                                             const uint16_t* __restrict__ o, const uint16_t* __restrict__ d_o, uint16_t* __restrict__ qT,
@@ -37,35 +39,48 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const uint16_t* __re
     __shared__ uint16_t t0[64][66], t1[64][66], t2[64][66], t3[64][66];
     const int bh = blockIdx.y, r0 = blockIdx.x * 64, b = bh / H, h = bh - b * H;
     const size_t rs = (size_t)H * 64;
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        t0[r][c] = q[((size_t)bh * npad + r0 + r) * 64 + c];
-        t1[r][c] = k[((size_t)bh * npad + r0 + r) * 64 + c];
-        t2[r][c] = vt[((size_t)bh * 64 + r) * npad + r0 + c];                       // [d = r][key = c]
-        uint16_t g = 0;
-        if (r0 + r < ntok) g = d_o[((size_t)b * ntok + r0 + r) * rs + (size_t)h * 64 + c];
-        t3[r][c] = g;
-        dohm[((size_t)bh * npad + r0 + r) * 64 + c] = g;
-    }
-    {   // D[t] = sum_d dO[t,d] * O[t,d]: 4 threads per row
-        const int r = threadIdx.x >> 2, part = threadIdx.x & 3;
-        float s = 0.f;
-        if (r0 + r < ntok) {
-            const size_t base = ((size_t)b * ntok + r0 + r) * rs + (size_t)h * 64 + part * 16;
+    auto put = [](uint16_t (&t)[64][66], int r, int c, const uint4& u) {
+        uint32_t* d = reinterpret_cast<uint32_t*>(&t[r][c]);
+        d[0] = u.x; d[1] = u.y; d[2] = u.z; d[3] = u.w;
+    };
 #pragma unroll
-            for (int e = 0; e < 16; ++e) s += to_f32<T>(d_o[base + e]) * to_f32<T>(o[base + e]);
+    for (int it = 0; it < 2; ++it) {
+        const int i = threadIdx.x + it * 256, r = i >> 3, c = (i & 7) * 8;          // 16-byte chunk (r, c..c+7) of a 64 x 64 tile
+        const uint4 uq = *reinterpret_cast<const uint4*>(q + ((size_t)bh * npad + r0 + r) * 64 + c);
+        const uint4 uk = *reinterpret_cast<const uint4*>(k + ((size_t)bh * npad + r0 + r) * 64 + c);
+        const uint4 uv = *reinterpret_cast<const uint4*>(vt + ((size_t)bh * 64 + r) * npad + r0 + c);      // [d = r][key = c]
+        uint4 ug = make_uint4(0u, 0u, 0u, 0u), uo = ug;
+        if (r0 + r < ntok) {
+            const size_t base = ((size_t)b * ntok + r0 + r) * rs + (size_t)h * 64 + c;
+            ug = *reinterpret_cast<const uint4*>(d_o + base);
+            uo = *reinterpret_cast<const uint4*>(o + base);
         }
-        s += __shfl_xor(s, 1);
-        s += __shfl_xor(s, 2);
-        if (part == 0) dsum[(size_t)bh * npad + r0 + r] = s;
+        put(t0, r, c, uq); put(t1, r, c, uk); put(t2, r, c, uv); put(t3, r, c, ug);
+        *reinterpret_cast<uint4*>(dohm + ((size_t)bh * npad + r0 + r) * 64 + c) = ug;
+        // D[t] = sum_d dO[t,d] * O[t,d]: the 8 lanes holding a row
+        const uint16_t *eg = reinterpret_cast<const uint16_t*>(&ug), *eo = reinterpret_cast<const uint16_t*>(&uo);
+        float sd = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sd += to_f32<T>(eg[e]) * to_f32<T>(eo[e]);
+        sd += __shfl_xor(sd, 1);
+        sd += __shfl_xor(sd, 2);
+        sd += __shfl_xor(sd, 4);
+        if ((i & 7) == 0) dsum[(size_t)bh * npad + r0 + r] = sd;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
-        const int r = i >> 6, c = i & 63;                                           // output row r (= d or key), column c
-        qT[((size_t)bh * 64 + r) * npad + r0 + c] = t0[c][r];
-        kT[((size_t)bh * 64 + r) * npad + r0 + c] = t1[c][r];
-        doT[((size_t)bh * 64 + r) * npad + r0 + c] = t3[c][r];
-        v[((size_t)bh * npad + r0 + r) * 64 + c] = t2[c][r];                        // [key = r][d = c]
+    auto col = [](const uint16_t (&t)[64][66], int c0, int r) {                     // t[c0 .. c0+7][r] as one 16-byte vector
+        uint16_t e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = t[c0 + j][r];
+        return make_uint4(e[0] | ((uint32_t)e[1] << 16), e[2] | ((uint32_t)e[3] << 16), e[4] | ((uint32_t)e[5] << 16), e[6] | ((uint32_t)e[7] << 16));
+    };
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int i = threadIdx.x + it * 256, r = i >> 3, c = (i & 7) * 8;          // output row r (= d or key), columns c..c+7
+        *reinterpret_cast<uint4*>(qT + ((size_t)bh * 64 + r) * npad + r0 + c) = col(t0, c, r);
+        *reinterpret_cast<uint4*>(kT + ((size_t)bh * 64 + r) * npad + r0 + c) = col(t1, c, r);
+        *reinterpret_cast<uint4*>(doT + ((size_t)bh * 64 + r) * npad + r0 + c) = col(t3, c, r);
+        *reinterpret_cast<uint4*>(v + ((size_t)bh * npad + r0 + r) * 64 + c) = col(t2, c, r);                // [key = r][d = c]
     }
 }
 
@@ -349,6 +364,8 @@ size_t attention_backward_ws_bytes(int B, int H, int npad) {
 int launch_attention_backward_qkv(const void* q, const void* k, const void* vt, const void* o, const void* d_o, const float* lse2, void* dqkv,
                                   void* ws, int B, int H, int ntok, int npad, int dtype, float scale, hipStream_t stream) {
     if (npad % 128 != 0 || npad < ntok) return set_error(LSEG_ERR_INVALID, "attention backward: npad=%d must be a multiple of 128 and >= ntok=%d", npad, ntok);
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)o | (uintptr_t)d_o | (uintptr_t)ws) & 15)
+        return set_error(LSEG_ERR_INVALID, "attention backward: operands must be 16-byte aligned");
     const size_t pe = (size_t)B * H * npad * 64;
     uint16_t* base = (uint16_t*)ws;
     uint16_t *qT = base, *kT = base + pe, *v = base + 2 * pe, *dohm = base + 3 * pe, *doT = base + 4 * pe;
