@@ -148,7 +148,11 @@ __global__ __launch_bounds__(64 * NW, 3) void lseg_attention_kernel(const AttnAr
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[sub][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32)) * a.scale_log2e;               // scale > 0
+        {   // max over the two half-waves holding a query's keys: one v_permlane32_swap (VALU) instead of a ds_bpermute round trip
+            // on the critical path of every tile -- afterwards sw[0] = the lower half's value in both halves, sw[1] = the upper half's
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * a.scale_log2e;               // scale > 0
+        }
         const float m_new = fmaxf(m_run, mx);
         // exact "defer": when no row of this wave raised its running max the rescale factor is
         // exactly 1 for every lane, so the exp and the 32 accumulator multiplies are skipped
@@ -156,15 +160,21 @@ __global__ __launch_bounds__(64 * NW, 3) void lseg_attention_kernel(const AttnAr
         float alpha = 1.0f;
         if (grew) alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
-        float lsum = 0.f;
+        // the softmax is VALU-bound (per 64 keys and wave: 32 exp2 next to 16 MFMAs): the scale-and-shift and the row sums run two
+        // scores per instruction on the packed fp32 pipe (v_pk_fma_f32 / v_pk_add_f32)
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        const f32x2_t sc2 = {a.scale_log2e, a.scale_log2e}, mn2 = {-m_new, -m_new};
+        f32x2_t lsum2 = {0.f, 0.f};
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[sub][r], a.scale_log2e, -m_new));
-                s[sub][r] = p;
-                lsum += p;
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2_t x = __builtin_elementwise_fma(f32x2_t{s[sub][r], s[sub][r + 1]}, sc2, mn2);
+                const f32x2_t p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                s[sub][r] = p[0]; s[sub][r + 1] = p[1];
+                lsum2 += p;
             }
+        const float lsum = lsum2[0] + lsum2[1];
         l_run = l_run * alpha + lsum;
         if (grew) {
 #pragma unroll

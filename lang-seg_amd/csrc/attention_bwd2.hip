@@ -27,6 +27,8 @@ struct AttnBwd2Args {
 
 namespace {
 
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
 // q,k [BH,npad,64], vt [BH,64,npad], o / dO token-major [B,ntok,H*64]  ->  qT, kT [BH,64,npad]; v, dO_hm [BH,npad,64]; dOT [BH,64,npad];
 // dsum [BH,npad].  One workgroup per (64-token block, bh); 64x64 tiles through LDS, 16 bytes per lane on every global access (with 2-byte
 // accesses the kernel ran at 3 TB/s: 50 us of the 150 MB it moves per layer at B = 8).  LDS rows are 66 elements: the transposing reads
@@ -200,13 +202,30 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnBwd2Args 
             }
         }
         const bool tail = t * 64 + 64 > a.ntok;                  // wave-uniform: padded keys must not contribute
+        // two scores per instruction on the packed fp32 pipe (the loop is VALU-bound next to its MFMAs): x = s * c - L, t = (dP - D) * scale
+        const f32x2_t sc2 = {a.scale_log2e, a.scale_log2e}, nl2 = {-L, -L}, s2v = {a.scale, a.scale}, nd2 = {-Dq * a.scale, -Dq * a.scale};
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = __builtin_amdgcn_exp2f(fmaf(s[sub][r], a.scale_log2e, -L));
-                if (tail) { const int key = t * 64 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi; p = key < a.ntok ? p : 0.f; }
-                s[sub][r] = p * (dp[sub][r] - Dq) * a.scale;     // dS^T
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2_t x = __builtin_elementwise_fma(f32x2_t{s[sub][r], s[sub][r + 1]}, sc2, nl2);
+                s[sub][r] = __builtin_amdgcn_exp2f(x[0]); s[sub][r + 1] = __builtin_amdgcn_exp2f(x[1]);      // P^T
+            }
+        if (tail) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = t * 64 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    s[sub][r] = key < a.ntok ? s[sub][r] : 0.f;
+                }
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2_t ds2 = f32x2_t{s[sub][r], s[sub][r + 1]} * __builtin_elementwise_fma(f32x2_t{dp[sub][r], dp[sub][r + 1]}, s2v, nd2);
+                s[sub][r] = ds2[0]; s[sub][r + 1] = ds2[1];                                                   // dS^T
             }
         i32x4_t dsf[2][2];
         to_operand<T>(s, dsf);
@@ -310,6 +329,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwd2Args
             }
         }
         f32x16_t ds[2];
+        const f32x2_t sc2 = {a.scale_log2e, a.scale_log2e}, s2v = {a.scale, a.scale};
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -319,11 +339,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwd2Args
                 const float4 d4 = *reinterpret_cast<const float4*>(sD + sub * 32 + 8 * g + 4 * hi);
                 const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < 4; e += 2) {                 // packed fp32: two queries per instruction
                     const int r = 4 * g + e;
-                    const float p = __builtin_amdgcn_exp2f(fmaf(s[sub][r], a.scale_log2e, -lv[e]));
-                    s[sub][r] = p;                               // P (rows beyond ntok: dO = 0 and D = 0 there, they add nothing)
-                    ds[sub][r] = p * (dp[sub][r] - dvv[e]) * a.scale;
+                    const f32x2_t x = __builtin_elementwise_fma(f32x2_t{s[sub][r], s[sub][r + 1]}, sc2, f32x2_t{-lv[e], -lv[e + 1]});
+                    const f32x2_t p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                    s[sub][r] = p[0]; s[sub][r + 1] = p[1];       // P (rows beyond ntok: dO = 0 and D = 0 there, they add nothing)
+                    const f32x2_t ds2 = (p * s2v) * (f32x2_t{dp[sub][r], dp[sub][r + 1]} - f32x2_t{dvv[e], dvv[e + 1]});
+                    ds[sub][r] = ds2[0]; ds[sub][r + 1] = ds2[1];
                 }
             }
         i32x4_t pf[2][2], dsf[2][2];
