@@ -36,11 +36,19 @@ struct AttnArgs {
 
 namespace {
 
+// phase-probe hooks (tools/probes/attn_phase_probe.py compiles this file with them defined; empty in the library build)
+#ifndef ATTN_PROBE
+#define ATTN_PROBE(i)
+#define ATTN_PROBE_DECL
+#define ATTN_PROBE_DUMP
+#endif
+
 // NW waves per workgroup = 32 * NW query rows: 4 for the bulk shapes; 2 when the grid would not fill the chip (B = 1: 8 x 16 workgroups of
 // 4 waves on 256 CUs -> 15 x 16 of 2)
-template <typename T, int NW>
-__global__ __launch_bounds__(64 * NW, 3) void lseg_attention_kernel(const AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 x (K 8 KB + Vt 8 KB)
+// NS K / V^T stages in LDS: tile t + NS - 1 is requested while tile t is computed (NS = 3: a direct-to-LDS load has two tile times to land)
+template <typename T, int NW, int NS>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void lseg_attention_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // NS x (K 8 KB + Vt 8 KB)
     constexpr int TILE = 8192, STAGE = 2 * TILE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform
@@ -92,12 +100,17 @@ __global__ __launch_bounds__(64 * NW, 3) void lseg_attention_kernel(const AttnAr
     auto issue = [&](int t, int stage) {
         char* sk = smem + stage * STAGE;
         char* sv = sk + TILE;
-        const char* kb = reinterpret_cast<const char*>(K + (size_t)t * 64 * 64);     // wave-uniform bases
-        const char* vb = reinterpret_cast<const char*>(Vt + (size_t)t * 64);
+        // wave-uniform bases, pinned to SGPRs: otherwise the loop is strength-reduced into per-lane 64-bit pointers and every
+        // direct-to-LDS load of the loop costs a v_lshl_add_u64 pair (16 double-rate VALU instructions per tile) instead of the
+        // SGPR-base + 32-bit VGPR-offset form
+        const char* kb = uniform_ptr(reinterpret_cast<const char*>(K + (size_t)t * 64 * 64));
+        const char* vb = uniform_ptr(reinterpret_cast<const char*>(Vt + (size_t)t * 64));
 #pragma unroll
         for (int s = 0; s < SPW; ++s) {
-            glds_slab_off(kb, k_off[s], sk + (s * NW + w) * 1024);
-            glds_slab_off(vb, v_off[s], sv + (s * NW + w) * 1024);
+            uint32_t ko = k_off[s], vo = v_off[s];
+            asm volatile("" : "+v"(ko), "+v"(vo));         // keeps the 32-bit offsets from being hoisted as zero-extended 64-bit pairs
+            glds_slab_off(kb, ko, sk + (s * NW + w) * 1024);
+            glds_slab_off(vb, vo, sv + (s * NW + w) * 1024);
         }
     };
 
@@ -111,12 +124,22 @@ __global__ __launch_bounds__(64 * NW, 3) void lseg_attention_kernel(const AttnAr
     const bool live = q0 < a.ntok;      // wave-uniform (ntok = 901: 3 of the last block's 4 waves are padding only)
 
     issue(0, 0);
+    if (NS == 3 && n_tiles > 1) issue(1, 1);
+    ATTN_PROBE_DECL
+    int st_cur = 0, st_nxt = NS - 1;      // stage of tile t; stage the newly requested tile t + NS - 1 goes to
     for (int t = 0; t < n_tiles; ++t) {
-        __builtin_amdgcn_s_waitcnt(0);
+        // tile t has landed: with three stages the loads of tile t + 1 (the 2 * SPW most recent of this wave) may stay in flight
+        if (NS == 3 && t + 1 < n_tiles) __builtin_amdgcn_s_waitcnt((2 * SPW) | (7 << 4));      // vmcnt(2 SPW) expcnt(7) lgkmcnt(0)
+        else __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
-        if (t + 1 < n_tiles) issue(t + 1, (t + 1) & 1);
+        ATTN_PROBE(0)
+        if (t + NS - 1 < n_tiles) issue(t + NS - 1, st_nxt);
+        const int st_use = st_cur;
+        st_nxt = st_cur;                                  // the stage read now is the one refilled next
+        st_cur = st_cur + 1 == NS ? 0 : st_cur + 1;
         if (!live) continue;            // this wave's 32 query rows are all padding: it only streams K/V for the others
-        const char* sk = smem + (t & 1) * STAGE;
+        ATTN_PROBE(1)
+        const char* sk = smem + st_use * STAGE;
         const char* sv = sk + TILE;
 
         // ---- S^T[key][q] for 64 keys: 2 sub-tiles x 4 k-steps ---------------------------------
@@ -131,6 +154,7 @@ __global__ __launch_bounds__(64 * NW, 3) void lseg_attention_kernel(const AttnAr
                 s[sub] = mfma32<T>(kf, qf[ks], s[sub]);
             }
         }
+        ATTN_PROBE(2)
         // ---- mask, online softmax (scale folded into the exp2 argument) -------------------------
         const bool need_mask = a.causal || (t * 64 + 64 > a.ntok);        // wave-uniform
         if (need_mask) {
@@ -153,6 +177,7 @@ __global__ __launch_bounds__(64 * NW, 3) void lseg_attention_kernel(const AttnAr
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
             mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * a.scale_log2e;               // scale > 0
         }
+        ATTN_PROBE(3)
         const float m_new = fmaxf(m_run, mx);
         // exact "defer": when no row of this wave raised its running max the rescale factor is
         // exactly 1 for every lane, so the exp and the 32 accumulator multiplies are skipped
@@ -160,21 +185,17 @@ __global__ __launch_bounds__(64 * NW, 3) void lseg_attention_kernel(const AttnAr
         float alpha = 1.0f;
         if (grew) alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
-        // the softmax is VALU-bound (per 64 keys and wave: 32 exp2 next to 16 MFMAs): the scale-and-shift and the row sums run two
-        // scores per instruction on the packed fp32 pipe (v_pk_fma_f32 / v_pk_add_f32)
-        typedef float f32x2_t __attribute__((ext_vector_type(2)));
-        const f32x2_t sc2 = {a.scale_log2e, a.scale_log2e}, mn2 = {-m_new, -m_new};
-        f32x2_t lsum2 = {0.f, 0.f};
+        // (plain v_fma_f32 / v_add_f32 on purpose: on gfx950 the packed fp32 forms run at half rate AND do not overlap with another
+        // wave's MFMAs the way scalar-lane VALU does -- tools/probes/valu_mfma_probe.py)
+        float lsum = 0.f;
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2_t x = __builtin_elementwise_fma(f32x2_t{s[sub][r], s[sub][r + 1]}, sc2, mn2);
-                const f32x2_t p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
-                s[sub][r] = p[0]; s[sub][r + 1] = p[1];
-                lsum2 += p;
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[sub][r], a.scale_log2e, -m_new));
+                s[sub][r] = p;
+                lsum += p;
             }
-        const float lsum = lsum2[0] + lsum2[1];
         l_run = l_run * alpha + lsum;
         if (grew) {
 #pragma unroll
@@ -203,6 +224,7 @@ __global__ __launch_bounds__(64 * NW, 3) void lseg_attention_kernel(const AttnAr
                 pf[sub][s2][0] = (int)w0[0]; pf[sub][s2][1] = (int)w1[0];
                 pf[sub][s2][2] = (int)w0[1]; pf[sub][s2][3] = (int)w1[1];
             }
+        ATTN_PROBE(4)
         // ---- O^T[d][q] += V^T[d][keys] P^T[keys][q] -----------------------------------------------
 #pragma unroll
         for (int d = 0; d < 2; ++d) {
@@ -215,7 +237,9 @@ __global__ __launch_bounds__(64 * NW, 3) void lseg_attention_kernel(const AttnAr
                     o[d] = mfma32<T>(vf, pf[sub][s2], o[d]);
                 }
         }
+        ATTN_PROBE(5)
     }
+    ATTN_PROBE_DUMP
 
     // ---- normalise and store: lane holds O[q][d = dblk*32 + 8g + 4hi + 0..3] -------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -251,21 +275,28 @@ int launch_attention_lse(const void* q, const void* k, const void* vt, void* out
     a.lse2 = lse2;
     a.B = B; a.H = H; a.ntok = ntok; a.npad = npad; a.causal = causal;
     a.scale_log2e = scale * 1.4426950408889634f;
-    const size_t lds = 2 * 2 * 8192;
     if (dtype != DT_BF16 && dtype != DT_F16) return set_error(LSEG_ERR_INVALID, "attention: dtype %d", dtype);
     int dev = 0;
     LSEG_HIP_TRY(hipGetDevice(&dev));
-    static const int force_nw = getenv("LSEG_ATTN_WAVES") ? atoi(getenv("LSEG_ATTN_WAVES")) : 0;      // tools: 2 | 4
+    static const int force_nw = getenv("LSEG_ATTN_WAVES") ? atoi(getenv("LSEG_ATTN_WAVES")) : 0;      // tools: 2 | 4 | 8
+    static const int force_ns = getenv("LSEG_ATTN_STAGES") ? atoi(getenv("LSEG_ATTN_STAGES")) : 0;    // tools: 2 | 3
     const bool narrow = force_nw ? force_nw == 2 : ((long)((ntok + 127) / 128) * B * H < 2L * device_cu_count(dev) && !causal);
-    if (narrow) {
-        dim3 grid(((ntok + 63) / 64) * B * H);
-        if (dtype == DT_BF16) hipLaunchKernelGGL((lseg_attention_kernel<BF16, 2>), grid, dim3(128), lds, stream, a);
-        else hipLaunchKernelGGL((lseg_attention_kernel<F16, 2>), grid, dim3(128), lds, stream, a);
-    } else {
-        dim3 grid(((ntok + 127) / 128) * B * H);
-        if (dtype == DT_BF16) hipLaunchKernelGGL((lseg_attention_kernel<BF16, 4>), grid, dim3(256), lds, stream, a);
-        else hipLaunchKernelGGL((lseg_attention_kernel<F16, 4>), grid, dim3(256), lds, stream, a);
-    }
+    const int nw = (force_nw == 8 && !causal) ? 8 : narrow ? 2 : 4;
+    const int ns = force_ns == 3 ? 3 : 2;
+    const size_t lds = (size_t)ns * 2 * 8192;
+    dim3 grid(((ntok + 32 * nw - 1) / (32 * nw)) * B * H);
+#define ATT(TT, NWV, NSV)                                                                                                                  \
+    do {                                                                                                                                   \
+        if (lds > 48 * 1024)                                                                                                               \
+            LSEG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(lseg_attention_kernel<TT, NWV, NSV>),                           \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                       \
+        hipLaunchKernelGGL((lseg_attention_kernel<TT, NWV, NSV>), grid, dim3(64 * NWV), lds, stream, a);                                    \
+    } while (0)
+#define ATT_T(NWV, NSV) do { if (dtype == DT_BF16) ATT(BF16, NWV, NSV); else ATT(F16, NWV, NSV); } while (0)
+    if (ns == 3) { if (nw == 8) ATT_T(8, 3); else if (nw == 2) ATT_T(2, 3); else ATT_T(4, 3); }
+    else { if (nw == 8) ATT_T(8, 2); else if (nw == 2) ATT_T(2, 2); else ATT_T(4, 2); }
+#undef ATT_T
+#undef ATT
     LSEG_HIP_TRY(hipGetLastError());
     return 0;
 }

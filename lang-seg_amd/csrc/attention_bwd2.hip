@@ -27,8 +27,6 @@ struct AttnBwd2Args {
 
 namespace {
 
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-
 // q,k [BH,npad,64], vt [BH,64,npad], o / dO token-major [B,ntok,H*64]  ->  qT, kT [BH,64,npad]; v, dO_hm [BH,npad,64]; dOT [BH,64,npad];
 // dsum [BH,npad].  One workgroup per (64-token block, bh); 64x64 tiles through LDS, 16 bytes per lane on every global access (with 2-byte
 // accesses the kernel ran at 3 TB/s: 50 us of the 150 MB it moves per layer at B = 8).  LDS rows are 66 elements: the transposing reads
@@ -163,14 +161,17 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnBwd2Args 
     }
     auto issue = [&](int t, int stage) {
         char* sk = smem + stage * STAGE;
-        const char* kb = reinterpret_cast<const char*>(a.k + hb + (size_t)t * 64 * 64);
-        const char* vb = reinterpret_cast<const char*>(a.v + hb + (size_t)t * 64 * 64);
-        const char* tb = reinterpret_cast<const char*>(a.kT + hb + (size_t)t * 64);
+        // SGPR bases + 32-bit lane offsets (see attention.hip: keeps the loads on the saddr form, no 64-bit VALU adds per tile)
+        const char* kb = uniform_ptr(reinterpret_cast<const char*>(a.k + hb + (size_t)t * 64 * 64));
+        const char* vb = uniform_ptr(reinterpret_cast<const char*>(a.v + hb + (size_t)t * 64 * 64));
+        const char* tb = uniform_ptr(reinterpret_cast<const char*>(a.kT + hb + (size_t)t * 64));
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            glds_slab_off(kb, r_off[s], sk + (s * 4 + w) * 1024);
-            glds_slab_off(vb, r_off[s], sk + TILE + (s * 4 + w) * 1024);
-            glds_slab_off(tb, t_off[s], sk + 2 * TILE + (s * 4 + w) * 1024);
+            uint32_t ro = r_off[s], to = t_off[s];
+            asm volatile("" : "+v"(ro), "+v"(to));
+            glds_slab_off(kb, ro, sk + (s * 4 + w) * 1024);
+            glds_slab_off(vb, ro, sk + TILE + (s * 4 + w) * 1024);
+            glds_slab_off(tb, to, sk + 2 * TILE + (s * 4 + w) * 1024);
         }
     };
     f32x16_t o[2];
@@ -202,15 +203,12 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnBwd2Args 
             }
         }
         const bool tail = t * 64 + 64 > a.ntok;                  // wave-uniform: padded keys must not contribute
-        // two scores per instruction on the packed fp32 pipe (the loop is VALU-bound next to its MFMAs): x = s * c - L, t = (dP - D) * scale
-        const f32x2_t sc2 = {a.scale_log2e, a.scale_log2e}, nl2 = {-L, -L}, s2v = {a.scale, a.scale}, nd2 = {-Dq * a.scale, -Dq * a.scale};
+        // dS^T = P^T o (dP^T - D); the softmax scale is applied once to dQ at the end (4 VALU per score: fma, exp2, sub, mul -- plain
+        // fp32 forms: the packed ones run at half rate on gfx950 and do not overlap with other waves' MFMAs, tools/probes/valu_mfma_probe.py)
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2_t x = __builtin_elementwise_fma(f32x2_t{s[sub][r], s[sub][r + 1]}, sc2, nl2);
-                s[sub][r] = __builtin_amdgcn_exp2f(x[0]); s[sub][r + 1] = __builtin_amdgcn_exp2f(x[1]);      // P^T
-            }
+            for (int r = 0; r < 16; ++r) s[sub][r] = __builtin_amdgcn_exp2f(fmaf(s[sub][r], a.scale_log2e, -L));      // P^T
         if (tail) {
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
@@ -223,10 +221,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnBwd2Args 
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2_t ds2 = f32x2_t{s[sub][r], s[sub][r + 1]} * __builtin_elementwise_fma(f32x2_t{dp[sub][r], dp[sub][r + 1]}, s2v, nd2);
-                s[sub][r] = ds2[0]; s[sub][r + 1] = ds2[1];                                                   // dS^T
-            }
+            for (int r = 0; r < 16; ++r) s[sub][r] *= dp[sub][r] - Dq;
         i32x4_t dsf[2][2];
         to_operand<T>(s, dsf);
 #pragma unroll
@@ -244,6 +239,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const AttnBwd2Args 
     const int qrow = q0 + ql;
     if (qrow < a.ntok) {
         const int b = bh / a.H, h = bh - b * a.H;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= a.scale;
         store_rows<T>(o, a.dqkv + ((size_t)b * a.ntok + qrow) * (3 * a.H * 64) + h * 64, hi);
     }
 }
@@ -279,16 +278,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwd2Args
     }
     auto issue = [&](int t, int stage) {
         char* sq = smem + stage * STAGE;
-        const char* qb = reinterpret_cast<const char*>(a.q + hb + (size_t)t * 64 * 64);
-        const char* ob = reinterpret_cast<const char*>(a.dO + hb + (size_t)t * 64 * 64);
-        const char* qtb = reinterpret_cast<const char*>(a.qT + hb + (size_t)t * 64);
-        const char* otb = reinterpret_cast<const char*>(a.dOT + hb + (size_t)t * 64);
+        const char* qb = uniform_ptr(reinterpret_cast<const char*>(a.q + hb + (size_t)t * 64 * 64));
+        const char* ob = uniform_ptr(reinterpret_cast<const char*>(a.dO + hb + (size_t)t * 64 * 64));
+        const char* qtb = uniform_ptr(reinterpret_cast<const char*>(a.qT + hb + (size_t)t * 64));
+        const char* otb = uniform_ptr(reinterpret_cast<const char*>(a.dOT + hb + (size_t)t * 64));
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            glds_slab_off(qb, r_off[s], sq + (s * 4 + w) * 1024);
-            glds_slab_off(ob, r_off[s], sq + TILE + (s * 4 + w) * 1024);
-            glds_slab_off(qtb, t_off[s], sq + 2 * TILE + (s * 4 + w) * 1024);
-            glds_slab_off(otb, t_off[s], sq + 3 * TILE + (s * 4 + w) * 1024);
+            uint32_t ro = r_off[s], to = t_off[s];
+            asm volatile("" : "+v"(ro), "+v"(to));
+            glds_slab_off(qb, ro, sq + (s * 4 + w) * 1024);
+            glds_slab_off(ob, ro, sq + TILE + (s * 4 + w) * 1024);
+            glds_slab_off(qtb, to, sq + 2 * TILE + (s * 4 + w) * 1024);
+            glds_slab_off(otb, to, sq + 3 * TILE + (s * 4 + w) * 1024);
         }
         if (w == 0) {      // L2 and D of this tile's 64 queries: 4 bytes per lane, direct to LDS (lane-linear)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.lse2 + (size_t)bh * a.npad + t * 64 + lane),
@@ -329,7 +330,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwd2Args
             }
         }
         f32x16_t ds[2];
-        const f32x2_t sc2 = {a.scale_log2e, a.scale_log2e}, s2v = {a.scale, a.scale};
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -339,13 +339,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwd2Args
                 const float4 d4 = *reinterpret_cast<const float4*>(sD + sub * 32 + 8 * g + 4 * hi);
                 const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
-                for (int e = 0; e < 4; e += 2) {                 // packed fp32: two queries per instruction
+                for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g + e;
-                    const f32x2_t x = __builtin_elementwise_fma(f32x2_t{s[sub][r], s[sub][r + 1]}, sc2, f32x2_t{-lv[e], -lv[e + 1]});
-                    const f32x2_t p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
-                    s[sub][r] = p[0]; s[sub][r + 1] = p[1];       // P (rows beyond ntok: dO = 0 and D = 0 there, they add nothing)
-                    const f32x2_t ds2 = (p * s2v) * (f32x2_t{dp[sub][r], dp[sub][r + 1]} - f32x2_t{dvv[e], dvv[e + 1]});
-                    ds[sub][r] = ds2[0]; ds[sub][r + 1] = ds2[1];
+                    const float p = __builtin_amdgcn_exp2f(fmaf(s[sub][r], a.scale_log2e, -lv[e]));
+                    s[sub][r] = p;                               // P (rows beyond ntok: dO = 0 and D = 0 there, they add nothing)
+                    ds[sub][r] = p * (dp[sub][r] - dvv[e]);      // dS without the softmax scale: applied once to dK at the end
                 }
             }
         i32x4_t pf[2][2], dsf[2][2];
@@ -369,6 +367,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnBwd2Args
     if (krow < a.ntok) {
         const int b = bh / a.H, h = bh - b * a.H, D = a.H * 64;
         uint16_t* row = a.dqkv + ((size_t)b * a.ntok + krow) * (3 * D) + h * 64;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dk[d][r] *= a.scale;
         store_rows<T>(dk, row + D, hi);
         store_rows<T>(dv, row + 2 * D, hi);
     }

@@ -135,6 +135,13 @@ __device__ __forceinline__ void glds_slab_row(const uint16_t* src_row, int row_i
         (const __attribute__((address_space(1))) void*)(src_row + chunk * 8),
         (__attribute__((address_space(3))) void*)lds_slab, 16, 0, 0);
 }
+// A wave-uniform pointer forced into SGPRs (v_readfirstlane is free when the value already is scalar): keeps address arithmetic on it out
+// of the compiler's per-lane strength reduction.
+__device__ __forceinline__ const char* uniform_ptr(const char* p) {
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)u), hi = __builtin_amdgcn_readfirstlane((uint32_t)(u >> 32));
+    return reinterpret_cast<const char*>(((uint64_t)hi << 32) | lo);
+}
 // Same, with a wave-uniform base pointer and a 32-bit per-lane byte offset (lets the compiler use
 // the SGPR-base + VGPR-offset addressing form: no 64-bit VALU adds in the K-loop).
 __device__ __forceinline__ void glds_slab_off(const char* base_uniform, uint32_t lane_byte_off,
