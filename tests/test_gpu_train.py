@@ -304,3 +304,41 @@ def test_lsegnet_train_mode_backpropagates_through_the_engine():
     with torch.no_grad():
         ev = net(x.cuda())
     assert ev.shape == out.shape and torch.isfinite(ev).all()
+
+
+def test_gelu_epilogue_fusions_equal_the_separate_passes(tmp_path):
+    """The training step's MLP GELU lives in GEMM epilogues (fc1 stores z and gelu(z); the fc2 dX GEMM multiplies by gelu'(z): gemm.hip
+    EPI_LIN16_GELU2 / EPI_LIN16_DGELU).  Same loss, logits and gradients as the GEMMs followed by the streaming GELU / GELU' kernels
+    (LSEG_NO_GELU_FUSE=1, read once per process -> a second interpreter), up to the one bf16 rounding of d(mlp) the fused form skips
+    and the erf polynomial of the epilogue (|err| <= 1.5e-7) against erff."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from lseg_hip.config import get_config; from lseg_hip.engine import HipEngine\n"
+        "from lseg_hip.synth import synthetic_state_dict, synthetic_tokens, synthetic_images, read_labels\n"
+        "cfg = get_config('tiny16'); sd = {k: v.cuda() for k, v in synthetic_state_dict(cfg, seed=3).items()}\n"
+        "tok = synthetic_tokens(read_labels(%r)[:5], cfg.text.vocab, cfg.text.ctx)\n"
+        "eng = HipEngine(cfg, 96, 64, max_batch=2, max_labels=5); eng.load_state_dict(sd); eng.set_tokens(tok); eng.enable_training(sd)\n"
+        "x = synthetic_images(2, 96, 64, seed=4).cuda()\n"
+        "g = torch.Generator().manual_seed(9); t = torch.randint(0, 5, (2, 96, 64), generator=g); t[torch.rand((2, 96, 64), generator=g) < 0.2] = -1\n"
+        "out = eng.forward(x).clone(); loss = eng.backward(target=t.cuda(), ignore_index=-1); torch.cuda.synchronize()\n"
+        "torch.save({'out': out.cpu(), 'loss': float(loss), 'grads': {k: v.float().cpu() for k, v in eng.grads.items()}}, sys.argv[1])\n"
+    ) % (os.path.join(root, "lang-seg_amd"), root, MG.LABELS)
+    res = {}
+    for tag, off in (("fused", False), ("separate", True)):
+        env = dict(os.environ)
+        env.pop("LSEG_NO_GELU_FUSE", None)
+        if off:
+            env["LSEG_NO_GELU_FUSE"] = "1"
+        out = str(tmp_path / (tag + ".pt"))
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=600)
+        res[tag] = torch.load(out)
+    a, b = res["fused"], res["separate"]
+    assert (a["out"] - b["out"]).abs().max().item() <= 2e-2 and abs(a["loss"] - b["loss"]) <= 2e-3 * abs(b["loss"])
+    worst = {k: rel(a["grads"][k], b["grads"][k]) for k in b["grads"]}
+    mlp = [k for k in worst if ".mlp." in k or "project" in k]
+    assert mlp and any(not torch.equal(a["grads"][k], b["grads"][k]) for k in mlp)        # the two interpreters really ran different kernels
+    assert max(worst.values()) <= 3e-2, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    assert sorted(worst.values())[len(worst) // 2] <= 8e-3
