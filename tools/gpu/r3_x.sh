@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs tools/ab/liblseg_hip_prev.so [and _noslp.so]: libraries of the compared commits built with `make -C lang-seg_amd/csrc` from `git archive`)
 # attention kernels: previous build / scalar fp32 forms + saddr loads + scale folded out of the backward loops / the same without SLP-vectorised packed ops
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 timeout 600 python -m pytest tests/test_gpu_ops.py tests/test_gpu_train.py -x -q -m gpu -k "attention or fixture or gradient" > gpurun_out/r3x_tests.log 2>&1; tail -3 gpurun_out/r3x_tests.log
