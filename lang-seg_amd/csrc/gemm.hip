@@ -392,6 +392,7 @@ enum Epi {
     EPI_PIX16 = 7,        // MAP_PIXSHUF, T(acc + bias[n % C]): ConvTranspose2d(k = s) as a GEMM whose columns scatter to the s x s sub-pixels
     EPI_LIN16_GELU2 = 9,  // C_pre[m*ldc+n] = z = T(acc + bias), C[m*ldc+n] = T(gelu(z))   (MLP fc1 of the training forward)
     EPI_LIN16_DGELU = 10, // C[m*ldc+n] = T((acc + bias) * gelu'(pre[m*ldc+n]))            (dX of the MLP fc2, through the GELU)
+    EPI_LIN32 = 11,       // C[m*ldc+n] = acc + bias, fp32                       (training: head1's output feeds the fp32 L2 normalisation)
     EPI_PART32 = 8,       // split-K partial slab: C[split * c_split_stride + m*ldc + n] = acc, fp32, no bias (weight gradients; the residual GEMMs
                           // of small batches, whose slabs the following LayerNorm sums into the fp32 residual stream)
 };
@@ -494,6 +495,19 @@ __device__ __forceinline__ void fast_epilogue(const GemmArgs& g, f32x4_t (&acc)[
                         *reinterpret_cast<float4*>(p + i * 16) =
                             make_float4(v[0] + rv[jl][i].x, v[1] + rv[jl][i].y, v[2] + rv[jl][i].z, v[3] + rv[jl][i].w);
                 });
+            });
+        });
+    } else if constexpr (EPI == EPI_LIN32) {
+        float* cbase = (float*)g.C + ncol0 + r16 * 4;
+        static_for<0, MI>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int m = mrow0 + j * 16 + ml;
+            float* p = cbase + (size_t)m * g.ldc;
+            static_for<0, NI>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                float v[4];
+                biased(ic, jc, v);
+                if (m < g.M) *reinterpret_cast<float4*>(p + i * 16) = make_float4(v[0], v[1], v[2], v[3]);
             });
         });
     } else if constexpr (EPI == EPI_PART32) {
@@ -1245,6 +1259,8 @@ int select_epi(const GemmArgs& g) {
     }
     if (g.map_mode == MAP_LINEAR && g.res_mode == RES_NONE && dt == DT_BF16 && g.out_dtype == DT_F16 && (g.ldc % 8) == 0 && g.act == ACT_NONE)
         return EPI_LIN16_F16;
+    if (g.map_mode == MAP_LINEAR && g.res_mode == RES_NONE && g.out_dtype == DT_F32 && g.act == ACT_NONE && (g.ldc % 4) == 0 && !g.C_pre && !g.dgelu_pre)
+        return EPI_LIN32;
     if (g.map_mode == MAP_LINEAR && g.res_mode == RES_DEST && g.out_dtype == DT_F32 && g.res_dtype == DT_F32 &&
         g.act == ACT_NONE && (g.ldc % 4) == 0 && !(reinterpret_cast<uintptr_t>(g.res) & 15))
         return EPI_RES32;
@@ -1294,6 +1310,7 @@ int dispatch(const GemmArgs& g, hipStream_t stream) {
             return pick_tile<T, false, false, EPI_LIN16_GELU, 0>(g, stream);
         case EPI_RES32: return pick_tile<T, false, false, EPI_RES32, 0>(g, stream);
         case EPI_LIN16_F16: return pick_tile<T, false, false, EPI_LIN16_F16, 0>(g, stream);
+        case EPI_LIN32: return pick_tile<T, false, false, EPI_LIN32, 0>(g, stream);
         case EPI_LIN16_GELU2: return pick_tile<T, false, false, EPI_LIN16_GELU2, 0>(g, stream);
         case EPI_LIN16_DGELU: return pick_tile<T, false, false, EPI_LIN16_DGELU, 0>(g, stream);
         case EPI_PIX16: return pick_tile<T, false, false, EPI_PIX16, 0>(g, stream);
