@@ -1224,13 +1224,18 @@ __global__ void colsum16_scalar_kernel(const uint16_t* __restrict__ in, int dtyp
     for (int r = r0; r < r1; ++r) s += load_as_f32(in, (size_t)r * ld + c, dtype);
     atomicAdd(&out[c], s);
 }
+// 0xffff per 16-bit half of a packed pair that is > 0 (bf16 / fp16 alike: sign bit clear, not zero)
+__device__ __forceinline__ uint32_t relu_mask2(uint32_t x2) {
+    return (((x2 & 0xffffu) != 0 && !(x2 & 0x8000u)) ? 0xffffu : 0u) | (((x2 >> 16) != 0 && !(x2 & 0x80000000u)) ? 0xffff0000u : 0u);
+}
 // y = gamma * (x - mean) * rstd + beta on the interior pixels (the border stays zero); mean/var from the batch sums (biased var)
 // res1 / res2 (same geometry, may be NULL): y += res1 + res2 -- the RCU skip connection and the fusion add (lseg_blocks.py:288,347).
 // inv_n = 1 / (pixels the sums were taken over): B*H*W, times the world size once the sums are all-reduced (SyncBatchNorm).
 // 8 channels (16 bytes) per lane; C % 8 == 0.
 __global__ void bn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, const float* __restrict__ stats,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, int B, int H, int W, int C,
-                                float eps, int dtype, float inv_n, const uint16_t* __restrict__ res1, const uint16_t* __restrict__ res2) {
+                                float eps, int dtype, float inv_n, const uint16_t* __restrict__ res1, const uint16_t* __restrict__ res2,
+                                uint16_t* __restrict__ y_relu) {
     const int c8n = C >> 3;
     const size_t n = (size_t)B * H * W * c8n;
     // the grid stride is a multiple of C/8 for the power-of-two widths of the DPT head: a thread keeps ONE group of 8 channels, whose
@@ -1274,8 +1279,10 @@ __global__ void bn_apply_kernel(const uint16_t* __restrict__ x, uint16_t* __rest
             if (res1) v[k] += load_as_f32(e1, k, dtype);
             if (res2) v[k] += load_as_f32(e2, k, dtype);
         }
-        *reinterpret_cast<uint4*>(y + off) = make_uint4(pack2_dt(v[0], v[1], dtype), pack2_dt(v[2], v[3], dtype),
-                                                        pack2_dt(v[4], v[5], dtype), pack2_dt(v[6], v[7], dtype));
+        const uint4 o = make_uint4(pack2_dt(v[0], v[1], dtype), pack2_dt(v[2], v[3], dtype), pack2_dt(v[4], v[5], dtype), pack2_dt(v[6], v[7], dtype));
+        if (y) *reinterpret_cast<uint4*>(y + off) = o;
+        if (y_relu)      // ReLU(y) for the 3x3 conv that reads it (and for that conv's weight gradient): negative halves cleared
+            *reinterpret_cast<uint4*>(y_relu + off) = make_uint4(o.x & relu_mask2(o.x), o.y & relu_mask2(o.y), o.z & relu_mask2(o.z), o.w & relu_mask2(o.w));
     }
 }
 // dx = gamma * rstd * (dy - mean(dy) - xhat * mean(dy * xhat)) on the interior; bstats = [sum dy, sum dy * xhat]
@@ -1326,9 +1333,6 @@ __global__ void bn_bwd_apply_kernel(const uint16_t* __restrict__ dy, const uint1
     }
 }
 // ReLU backward: dx = dy where x > 0 (16-bit tensors of any shape); positive <=> sign bit clear and not zero (bf16 and fp16)
-__device__ __forceinline__ uint32_t relu_mask2(uint32_t x2) {
-    return (((x2 & 0xffffu) != 0 && !(x2 & 0x8000u)) ? 0xffffu : 0u) | (((x2 >> 16) != 0 && !(x2 & 0x80000000u)) ? 0xffff0000u : 0u);
-}
 __global__ void relu_backward_kernel(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ x, uint16_t* __restrict__ dx, size_t n) {
     const size_t n8 = n >> 3;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
@@ -2212,10 +2216,12 @@ int launch_bn_stats(const void* x, float* stats, int B, int H, int W, int C, int
     return 0;
 }
 int launch_bn_apply(const void* x, void* y, const float* stats, const float* gamma, const float* beta, const void* res1, const void* res2,
-                    int B, int H, int W, int C, float eps, double count, int dtype, hipStream_t st) {
+                    int B, int H, int W, int C, float eps, double count, int dtype, hipStream_t st, void* y_relu) {
     if (C % 8) return set_error(LSEG_ERR_UNSUPPORTED, "batch norm: C=%d must be a multiple of 8", C);
+    if (!y && !y_relu) return set_error(LSEG_ERR_INVALID, "batch norm: no output");
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for((size_t)B * H * W * (C / 8))), dim3(256), 0, st, (const uint16_t*)x, (uint16_t*)y,
-                       stats, gamma, beta, B, H, W, C, eps, dtype, (float)(1.0 / count), (const uint16_t*)res1, (const uint16_t*)res2);
+                       stats, gamma, beta, B, H, W, C, eps, dtype, (float)(1.0 / count), (const uint16_t*)res1, (const uint16_t*)res2,
+                       (uint16_t*)y_relu);
     CHECK_LAUNCH();
     return 0;
 }

@@ -28,7 +28,8 @@ struct Rcu {
     Lin r1, r2;
     float *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;
     std::string key;                                                       // "scratch.refinenetR.resConfUnitU."
-    uint16_t *cv1 = nullptr, *n1 = nullptr, *cv2 = nullptr;                // conv1 out, bn1 out, conv2 out (padded NHWC)
+    uint16_t *cv1 = nullptr, *n1 = nullptr, *cv2 = nullptr;                // conv1 out, ReLU(bn1 out), conv2 out (padded NHWC)
+    const uint16_t* in_relu = nullptr;                                     // ReLU(unit input) of the last train-mode forward (NULL: clamp in the K-loop)
     float *st1 = nullptr, *st2 = nullptr;                                  // [2C] batch sums of bn1 / bn2
 };
 struct Refine { Rcu u1, u2; Lin out_conv; bool has_u1 = false; };
@@ -100,7 +101,8 @@ private:
     int train_alloc();
     int finalize_train(hipStream_t st);
     int forward_train(const float* x, int B, float* logits, hipStream_t st);
-    int rcu_train(const uint16_t* in, Rcu& U, const uint16_t* res2, uint16_t* out, int B, int H, int W, hipStream_t st);
+    int rcu_train(const uint16_t* in, const uint16_t* in_relu, Rcu& U, const uint16_t* res2, uint16_t* out, uint16_t* out_relu, int B, int H, int W,
+                  hipStream_t st);
     int rcu_backward(const uint16_t* dout, const uint16_t* in, Rcu& U, uint16_t* din, int lev, int B, int H, int W, int acc, hipStream_t st);
     int linear_gelu_saved(GemmArgs& g, uint16_t* pre, uint16_t* out, hipStream_t st);
     int lin_bwd(const uint16_t* dy, int M, int N, int K, const uint16_t* x, const uint16_t* wt, uint16_t* dx, float* dw, float* db,

@@ -103,7 +103,8 @@ int launch_attention_lse(const void* q, const void* k, const void* vt, void* out
                          int causal, float scale, hipStream_t stream);
 int launch_bn_stats(const void* x, float* stats, int B, int H, int W, int C, int dtype, hipStream_t st, int pre_zeroed = 0);
 int launch_bn_apply(const void* x, void* y, const float* stats, const float* gamma, const float* beta, const void* res1, const void* res2,
-                    int B, int H, int W, int C, float eps, double count, int dtype, hipStream_t st);
+                    int B, int H, int W, int C, float eps, double count, int dtype, hipStream_t st,
+                    void* y_relu = nullptr);      // y_relu: ReLU(y), same geometry (y may then be NULL)
 int launch_bn_bwd_stats(const void* dy, const void* x, const float* stats, float* bstats, int B, int H, int W, int C, float eps,
                         double count, int dtype, hipStream_t st);
 int launch_bn_bwd_apply(const void* dy, const void* x, const float* stats, const float* bstats, const float* gamma, void* dx,

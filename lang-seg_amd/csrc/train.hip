@@ -256,20 +256,28 @@ int Engine::finalize_train(hipStream_t st) {
 }
 
 // ---- ResidualConvUnit_custom in train() mode (lseg_blocks.py:265-288): out = bn2(conv2(relu(bn1(conv1(relu(x)))))) + x [+ res2] ----
-int Engine::rcu_train(const uint16_t* in, Rcu& U, const uint16_t* res2, uint16_t* out, int B, int H, int W, hipStream_t st) {
+// ResidualConvUnit in train mode.  The 3x3 convs read ReLU(x): clamping the operand fragments inside the K-loop costs the forward conv a
+// third of its MFMA rate and the K-major weight-gradient GEMM more (15 % MFMA busy against 24 %, profiles/r03_train_pmc_summary.txt), so
+// the ReLU-ed maps are materialised by whoever produces them: `in_relu` = ReLU(in) from the producing conv's / BatchNorm's epilogue (NULL:
+// clamp in the K-loop), U.n1 holds ReLU(bn1(conv1)) only -- its sign pattern is all the backward needs --, `out_relu` (optional) receives
+// ReLU(out) for a following unit.
+int Engine::rcu_train(const uint16_t* in, const uint16_t* in_relu, Rcu& U, const uint16_t* res2, uint16_t* out, uint16_t* out_relu, int B, int H,
+                      int W, hipStream_t st) {
     const int F = cfg.features;
     const double cnt = (double)B * H * W * bn_world;
     BoundParam rm, rv;
     Lin c1 = U.r1; c1.b = zeros_;
     Lin c2 = U.r2; c2.b = zeros_;
-    TRY(conv3x3(in, c1, nullptr, nullptr, U.cv1, B, H, W, 1, 1, 0, st));
+    U.in_relu = in_relu;
+    if (in_relu) TRY(conv3x3(in_relu, c1, nullptr, nullptr, U.cv1, B, H, W, 1, 0, 0, st));
+    else TRY(conv3x3(in, c1, nullptr, nullptr, U.cv1, B, H, W, 1, 1, 0, st));
     TRY(launch_bn_stats(U.cv1, U.st1, B, H, W, F, img_dt_, st, zero_note(zero_fwd_, U.st1, (size_t)2 * F) ? 1 : 0));
     TRY(bn_sync(U.st1, 2 * F, st));
-    TRY(launch_bn_apply(U.cv1, U.n1, U.st1, U.g1, U.be1, nullptr, nullptr, B, H, W, F, 1e-5f, cnt, img_dt_, st));
-    TRY(conv3x3(U.n1, c2, nullptr, nullptr, U.cv2, B, H, W, 1, 1, 0, st));
+    TRY(launch_bn_apply(U.cv1, nullptr, U.st1, U.g1, U.be1, nullptr, nullptr, B, H, W, F, 1e-5f, cnt, img_dt_, st, U.n1));
+    TRY(conv3x3(U.n1, c2, nullptr, nullptr, U.cv2, B, H, W, 1, 0, 0, st));
     TRY(launch_bn_stats(U.cv2, U.st2, B, H, W, F, img_dt_, st, zero_note(zero_fwd_, U.st2, (size_t)2 * F) ? 1 : 0));
     TRY(bn_sync(U.st2, 2 * F, st));
-    TRY(launch_bn_apply(U.cv2, out, U.st2, U.g2, U.be2, in, res2, B, H, W, F, 1e-5f, cnt, img_dt_, st));
+    TRY(launch_bn_apply(U.cv2, out, U.st2, U.g2, U.be2, in, res2, B, H, W, F, 1e-5f, cnt, img_dt_, st, out_relu));
     // running statistics live in the caller's tensors (momentum 0.1, unbiased variance: nn.BatchNorm2d / SyncBatchNorm)
     for (int k = 1; k <= 2; ++k) {
         auto m = bound_.find(U.key + "bn" + std::to_string(k) + ".running_mean"), v = bound_.find(U.key + "bn" + std::to_string(k) + ".running_var");
@@ -357,16 +365,16 @@ int Engine::forward_train(const float* x_in, int B, float* logits, hipStream_t s
             } else if (c.resample_kind[l] == LSEG_RS_CONV_S2) {
                 TRY(conv3x3(v.tmp, rsmp_[l], nullptr, nullptr, L_[l], B, gh_, gw_, 2, 0, 0, st));
             }
-            TRY(conv3x3(L_[l], layer_rn_[l], nullptr, nullptr, rn_[l], B, lh_[l], lw_[l], 1, 0, 0, st));
+            TRY(conv3x3(L_[l], layer_rn_[l], nullptr, nullptr, rn_[l], B, lh_[l], lw_[l], 1, 0, 0, st, rnr_[l], &rn_relu_ok_[l]));
         }
     }
     // refinenet4..1 in train mode
     for (int r = 4; r >= 1; --r) {
         const int l = r - 1, Hh = lh_[l], Ww = lw_[l];
         Refine& R = refine_[l];
-        const uint16_t* in2 = rn_[l];
-        if (R.has_u1) { TRY(rcu_train(rn_[l], R.u1, path_[l + 1], sum_[l], B, Hh, Ww, st)); in2 = sum_[l]; }
-        TRY(rcu_train(in2, R.u2, nullptr, t2_[l], B, Hh, Ww, st));
+        const uint16_t *in2 = rn_[l], *in2r = rn_relu_ok_[l] ? rnr_[l] : nullptr;
+        if (R.has_u1) { TRY(rcu_train(rn_[l], in2r, R.u1, path_[l + 1], sum_[l], sumr_[l], B, Hh, Ww, st)); in2 = sum_[l]; in2r = sumr_[l]; }
+        TRY(rcu_train(in2, in2r, R.u2, nullptr, t2_[l], nullptr, B, Hh, Ww, st));
         TRY(launch_upsample2x_nhwc(t2_[l], up_[l], B, Hh, Ww, F, img_dt_, st));
         gemm_args_init(g);
         g.A = up_[l]; g.W = R.out_conv.w; g.M = B * 4 * Hh * Ww; g.N = F; g.K = F; g.lda = F; g.ldw = F;
@@ -578,8 +586,8 @@ int Engine::rcu_backward(const uint16_t* dout, const uint16_t* in, Rcu& U, uint1
     TRY(launch_fold_rows(bst + F, grad(U.key + "bn2.weight", F), 1, F, F, acc, st));
     TRY(bn_sync(bst, 2 * F, st));
     TRY(launch_bn_bwd_apply(dout, U.cv2, U.st2, bst, U.g2, dC, B, H, W, F, 1e-5f, cnt, img_dt_, st));
-    // conv2 (input relu(n1))
-    TRY(conv_bwd(dC, U.n1, 1, U.r2, dD, grad(U.key + "conv2.weight", (size_t)F * F * 9), B, H, W, F, F, F, F, acc, st));
+    // conv2 (input relu(n1): U.n1 holds the ReLU-ed map, whose sign pattern is n1's)
+    TRY(conv_bwd(dC, U.n1, 0, U.r2, dD, grad(U.key + "conv2.weight", (size_t)F * F * 9), B, H, W, F, F, F, F, acc, st));
     TRY(launch_relu_backward(dD, U.n1, dD, nmap, st));
     // bn1
     TRY(launch_bn_bwd_stats(dD, U.cv1, U.st1, bst, B, H, W, F, 1e-5f, cnt, img_dt_, st));
@@ -588,7 +596,7 @@ int Engine::rcu_backward(const uint16_t* dout, const uint16_t* in, Rcu& U, uint1
     TRY(bn_sync(bst, 2 * F, st));
     TRY(launch_bn_bwd_apply(dD, U.cv1, U.st1, bst, U.g1, dC, B, H, W, F, 1e-5f, cnt, img_dt_, st));
     // conv1 (input relu(in)); din = relu'(in) o d_a0 + dout
-    TRY(conv_bwd(dC, in, 1, U.r1, dD, grad(U.key + "conv1.weight", (size_t)F * F * 9), B, H, W, F, F, F, F, acc, st));
+    TRY(conv_bwd(dC, U.in_relu ? U.in_relu : in, U.in_relu ? 0 : 1, U.r1, dD, grad(U.key + "conv1.weight", (size_t)F * F * 9), B, H, W, F, F, F, F, acc, st));
     TRY(launch_relu_backward_add(dD, in, dout, din, nmap, img_dt_, st));
     return 0;
 }
