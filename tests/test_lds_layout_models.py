@@ -1,0 +1,103 @@
+"""CPU models of two LDS layouts of csrc/gemm.hip whose address arithmetic cannot be exercised without a GPU: they restate the kernel's
+formulas (cited below) on integer arrays and check what the kernel relies on -- every MFMA fragment gathers exactly the operand
+elements it stands for, and every wave-level read touches each LDS bank once.
+
+  * row-major stages (`tile_off`, common.h): `[rows][64 x 16 bit]` = 128-byte rows, 16-byte chunk c of row r stored at slot
+    c ^ ((r >> 1) & 7); fragments by `ds_read_b128` (16x16x32: lane (row = lane & 15, kgroup = lane >> 4) reads chunk kgroup of a k-half).
+  * K-major stages (gemm.hip "K-MAJOR operands", TAG == 2): `[64 k][BM]` rows of BM x 2 bytes, 32-byte segment g of stage row k stored at
+    slot g ^ gsw(k), gsw(k) = (k & 3) | ((k >> 3) & 1) << 2; fragments by two `ds_read_b64_tr_b16` per 8-k operand
+    (tools/probes/tr_read_probe.py pinned the instruction: a 16-lane group reads a [4][16] block, lane i supplies row i / 4, columns
+    4 (i % 4) .. + 3, and receives column i)."""
+import numpy as np
+import pytest
+
+
+def swz(r):                      # common.h swz(): the XOR term of a 128-byte row
+    return (r >> 1) & 7
+
+
+def test_row_major_stage_fragments_and_banks():
+    rows = 128
+    # logical tile T[r][k], k = 0..63, one 16-bit element = its own id
+    T = np.arange(rows * 64, dtype=np.int64).reshape(rows, 64)
+    lds = np.full(rows * 64, -1, dtype=np.int64)                       # element index inside the stage
+    # staging (glds_slab_off callers): lane (lane >> 3 = row in the 8-row slab, lane & 7 = LDS chunk slot) copies SOURCE chunk slot ^ swz(r)
+    for r in range(rows):
+        for slot in range(8):
+            c = slot ^ swz(r)
+            lds[r * 64 + slot * 8: r * 64 + slot * 8 + 8] = T[r, c * 8: c * 8 + 8]
+    assert (lds >= 0).all()
+    # fragment read of one 16-row sub-tile, k-half kh: lane reads 16 bytes at tile_off(row, kh * 4 + kgroup)
+    for sub in range(rows // 16):
+        for kh in range(2):
+            banks = []
+            for lane in range(64):
+                row, kg = sub * 16 + (lane & 15), lane >> 4
+                chunk = kh * 4 + kg
+                off = row * 128 + ((chunk ^ swz(row)) << 4)            # tile_off(), bytes
+                got = lds[off // 2: off // 2 + 8]
+                assert np.array_equal(got, T[row, chunk * 8: chunk * 8 + 8])      # the lane's 8 k-values of its row
+                banks.append(((off // 4) % 64, lane))
+            # ds_read_b128 is serviced 16 lanes at a time (MI355X_MICROARCH "LDS": 4 x 16-lane groups), each lane 4 banks wide
+            for grp in ([0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]):
+                for half in (0, 32):
+                    used = set()
+                    for lane in grp:
+                        b0 = banks[lane + half][0]
+                        for q in range(4):
+                            assert (b0 + q) % 64 not in used
+                            used.add((b0 + q) % 64)
+                    assert len(used) == 64
+
+
+def gsw(k):                      # gemm.hip: segment swizzle of a K-major stage row
+    return (k & 3) | (((k >> 3) & 1) << 2)
+
+
+@pytest.mark.parametrize("BM", [128, 256])
+def test_k_major_stage_fragments_and_banks(BM):
+    pitch = BM * 2                                                     # bytes per stage row (one k)
+    T = np.arange(64 * BM, dtype=np.int64).reshape(64, BM)             # logical operand T[k][m]
+    lds = np.full(64 * BM, -1, dtype=np.int64)
+    # staging (setup_a / setup_w): a wave instruction covers RPI stage rows of LPR 16-byte chunk slots; slot s receives SOURCE chunk
+    # s ^ (gsw(k) << 1)
+    LPR = BM // 8
+    for k in range(64):
+        for slot in range(LPR):
+            c = slot ^ (gsw(k) << 1)
+            assert 0 <= c < LPR
+            lds[k * BM + slot * 8: k * BM + slot * 8 + 8] = T[k, c * 8: c * 8 + 8]
+    assert (lds >= 0).all()
+    for seg in range(BM // 16):                                        # 16-column sub-tile (wm * WM / 16 + j in the kernel)
+        for kh in range(2):
+            frag = np.zeros((64, 8), dtype=np.int64)
+            for half in range(2):                                      # the two transpose reads of an 8-k operand (rows + 0 and + 4)
+                addr = []
+                for lane in range(64):
+                    ti, kg = lane & 15, lane >> 4
+                    gl = (ti >> 2) | ((kg & 1) << 2)
+                    off = (kg * 8 + (ti >> 2)) * pitch + ((seg ^ gl) * 32) + (ti & 3) * 8      # a_tr[j] / w_tr[i]
+                    off += (kh * 32 + half * 4) * pitch                                        # ldfrag_t()
+                    addr.append(off)
+                # the instruction: per 16-lane group a [4 rows][16 cols] block, lane i <- column i of the 4 rows the group's lanes address
+                for grp in range(4):
+                    blk = np.zeros((4, 16), dtype=np.int64)
+                    for i in range(16):
+                        a = addr[grp * 16 + i]
+                        blk[i >> 2, 4 * (i & 3): 4 * (i & 3) + 4] = lds[a // 2: a // 2 + 4]
+                    for i in range(16):
+                        frag[grp * 16 + i, half * 4: half * 4 + 4] = blk[:, i]
+                # banks: 8 bytes per lane, 32 lanes per LDS pass
+                for h32 in (0, 32):
+                    used = set()
+                    for lane in range(h32, h32 + 32):
+                        for q in range(2):
+                            b = (addr[lane] // 4 + q) % 64
+                            assert b not in used, (BM, seg, kh, half, lane)
+                            used.add(b)
+                    assert len(used) == 64
+            # MFMA 16x16x32 operand: lane (m = lane & 15, kg = lane >> 4) holds k = kh * 32 + kg * 8 .. + 7 of column seg * 16 + m
+            for lane in range(64):
+                m, kg = seg * 16 + (lane & 15), lane >> 4
+                want = T[kh * 32 + kg * 8: kh * 32 + kg * 8 + 8, m]
+                assert np.array_equal(frag[lane], want), (BM, seg, kh, lane)
