@@ -101,3 +101,49 @@ def test_k_major_stage_fragments_and_banks(BM):
                 m, kg = seg * 16 + (lane & 15), lane >> 4
                 want = T[kh * 32 + kg * 8: kh * 32 + kg * 8 + 8, m]
                 assert np.array_equal(frag[lane], want), (BM, seg, kh, lane)
+
+
+# ---- work-item maps (index arithmetic only) --------------------------------------------------------------------------------------
+def _tile_coords(t, tiles_m, tiles_n, group_m=8):       # gemm.hip tile_coords(): grouped rasterisation of the persistent schedule
+    per_group = group_m * tiles_n
+    gid = t // per_group
+    first_m = gid * group_m
+    gsz = min(tiles_m - first_m, group_m)
+    r = t - gid * per_group
+    return first_m + r % gsz, r // gsz
+
+
+@pytest.mark.parametrize("tiles_m,tiles_n,group_m", [(127, 16, 8), (57, 8, 8), (1, 9, 8), (29, 4, 8), (15, 4, 3), (8, 24, 8), (113, 1, 8)])
+def test_gemm_tile_rasterisation_is_a_bijection(tiles_m, tiles_n, group_m):
+    seen = set()
+    for t in range(tiles_m * tiles_n):
+        mb, nb = _tile_coords(t, tiles_m, tiles_n, group_m)
+        assert 0 <= mb < tiles_m and 0 <= nb < tiles_n
+        seen.add((mb, nb))
+    assert len(seen) == tiles_m * tiles_n
+    # consecutive work items of a group share the W panel (same nb) group_m at a time: what keeps the panel in one XCD's L2
+    mb0, nb0 = _tile_coords(0, tiles_m, tiles_n, group_m)
+    mb1, nb1 = _tile_coords(1, tiles_m, tiles_n, group_m) if tiles_m * tiles_n > 1 else (mb0, nb0)
+    assert nb1 == nb0 or min(tiles_m, group_m) == 1
+
+
+def _xcd_head_map(L, nb, BH):                           # attention.hip / attention_bwd2.hip: (block of a head, head) of linear workgroup L
+    blk, bh = L % nb, L // nb
+    if BH % 8 == 0:
+        xcd, idx = L & 7, L >> 3
+        blk, bh = idx % nb, (idx // nb) * 8 + xcd
+    return blk, bh
+
+
+@pytest.mark.parametrize("nb,BH", [(8, 576), (15, 16), (8, 16), (4, 128), (29, 8), (8, 12), (1, 24)])
+def test_attention_block_map_keeps_a_head_on_one_xcd(nb, BH):
+    seen = {}
+    for L in range(nb * BH):
+        blk, bh = _xcd_head_map(L, nb, BH)
+        assert 0 <= blk < nb and 0 <= bh < BH
+        assert (blk, bh) not in seen
+        seen[(blk, bh)] = L
+    assert len(seen) == nb * BH
+    if BH % 8 == 0:      # workgroups are dealt to the 8 XCDs round-robin by linear id: all blocks of a head must share L & 7
+        for bh in range(BH):
+            assert len({seen[(blk, bh)] & 7 for blk in range(nb)}) == 1
