@@ -71,34 +71,183 @@ def parse():
     ap.add_argument("--train-sync-bn", action="store_true",
                     help="multi-GPU training leg with SyncBatchNorm (the reference's utils.py:34: 56 tiny all-reduces per step); default "
                          "for N > 1 is per-GPU statistics = no collective besides the gradient all-reduce (BASELINE north_star)")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = min(32, cores))")
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads for the CPU baseline (0 = all host cores, os.cpu_count(); the 32-thread figure is timed next to it)")
+    ap.add_argument("--no-pmc-traffic", action="store_true",
+                    help="do not collect FETCH_SIZE / WRITE_SIZE of the dominant kernel in this run (two rocprofv3 --pmc child passes over 2 "
+                         "forwards each, N = 1 only, ~1 min, outside the timed region); roofline.traffic then replays profiles/rNN_traffic.json "
+                         "and says so")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)     # the workload of one counter pass: 1 + 2 forwards
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous check without a GPU (tests): every rank joins a gloo group, rank 0 prints {n_gpus, ranks} and leaves")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: re-exec under torch.distributed.run with N ranks on this
+    node (one per GPU, 127.0.0.1 rendezvous on a free port) -- a plain invocation must never time ONE GPU and call it N
+    (the reference launches its N replicas itself too: utils.py:20-22 DDP, additional_utils/models.py:229-238 threads).
+    Fails loudly when fewer than N devices are visible.  Returns the child's exit code."""
+    import socket
+    import subprocess
+    if not args.launch_check:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node -- refusing to measure fewer devices than asked for")
+    s_ = socket.socket()
+    s_.bind(("127.0.0.1", 0))
+    port = s_.getsockname()[1]
+    s_.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on these hosts (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def pmc_child(args):
+    """What one rocprofv3 --pmc pass profiles: the headline engine, one warm-up and two forwards of the bench batch."""
+    from lseg_hip.config import get_config
+    from lseg_hip.engine import HipEngine
+    from lseg_hip.synth import synthetic_state_dict, synthetic_tokens, synthetic_images, read_labels
+    torch.cuda.set_device(0)
+    cfg = get_config(args.backbone)
+    labels = read_labels(os.path.join(ROOT, "lang-seg_amd", "label_files", "ade20k_objectInfo150.txt"))[: args.labels]
+    eng = HipEngine(cfg, args.size, args.size, max_batch=args.batch, max_labels=len(labels), image_dtype=args.dtype)
+    eng.load_state_dict(synthetic_state_dict(cfg, seed=0))
+    eng.set_tokens(synthetic_tokens(labels, cfg.text.vocab, cfg.text.ctx))
+    x = synthetic_images(args.batch, args.size, args.size, seed=0).cuda()
+    for _ in range(3):
+        eng.forward(x)
+    torch.cuda.synchronize()
+    eng.close()
+
+
+def pmc_symbol_predicate(dom, dtype):
+    """Kernel-name test for the dominant symbol's bench-batch instance (256 x 256 tiles; the text tower and the B = 1 self-check
+    launch other instantiations)."""
+    T = "lseg::F16" if dtype == "fp16" else "lseg::BF16"
+    key = dom.split(" ")[0]
+    if key == "attention":
+        return lambda n: "lseg_attention_kernel<" + T + ", 4>" in n
+    epi, tag = {"gemm_res32": (3, 0), "gemm_fc1_gelu": (2, 1), "gemm_qkv": (4, 0)}[key]
+    return lambda n: ("lseg_gemm_kernel<" + T in n and "TileCfg<256, 256" in n and
+                      n.rstrip().endswith(f", false, false, {epi}, {tag}>(lseg::GemmArgs)"))
+
+
+def pmc_traffic_in_run(dom, dtype, args, alg_bytes):
+    """HBM-side traffic of the dominant kernel symbol measured IN THIS RUN: two rocprofv3 child passes (counters only + the kernel-trace
+    domain, FETCH_SIZE and WRITE_SIZE separately as MI355X_MICROARCH.md's HBM section prescribes: they do not fit one pass), each over
+    `pmc_child` (1 + 2 forwards of the bench batch).  FETCH_SIZE is doubled (gfx950 tallies the 128-byte requests of wide coalesced
+    reads at 64 bytes); the figure is L2->fabric bytes, Infinity-Cache hits included.  Returns (dict | None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    pred = pmc_symbol_predicate(dom, dtype)
+    tmp = tempfile.mkdtemp(prefix="lseg_pmc_", dir="/tmp")
+    per = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "-d", d, "-o", "pmc", "--output-format", "csv", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--dtype", dtype, "--batch", str(args.batch),
+                   "--labels", str(args.labels), "--size", str(args.size), "--backbone", args.backbone]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"}, timeout=200,
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {ctr} pass timed out"
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {ctr} pass failed (rc {r.returncode}): {r.stderr.decode(errors='replace')[-200:]}"
+            disp = {}
+            for row in csv.DictReader(open(files[0])):
+                if row.get("Counter_Name") == ctr and pred(row["Kernel_Name"]):
+                    k_ = row.get("Dispatch_Id") or str(len(disp))
+                    disp[k_] = disp.get(k_, 0.0) + float(row["Counter_Value"])
+            if not disp:
+                return None, f"no dispatch of the dominant symbol in the {ctr} pass"
+            per[ctr] = (sum(disp.values()) / len(disp), len(disp))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    b = (2.0 * per["FETCH_SIZE"][0] + per["WRITE_SIZE"][0]) * 1024.0
+    return ({"bytes_per_launch": round(b), "algorithmic_bytes": alg_bytes, "over_algorithmic": round(b / alg_bytes, 3) if alg_bytes else None,
+             "fetch_bytes_x2": round(2.0 * per["FETCH_SIZE"][0] * 1024.0), "write_bytes": round(per["WRITE_SIZE"][0] * 1024.0),
+             "launches_averaged": per["FETCH_SIZE"][1],
+             "source": "measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes (separate, counters + kernel-trace "
+                       "only) over 2 forwards of the bench batch; FETCH x2 gfx950 correction; L2->fabric bytes incl. Infinity-Cache hits"},
+            "ok")
+
+
+def algorithmic_bytes(dom, M, D, B, npad_tok):
+    """Bytes one launch of the dominant symbol must move once (16-bit operands, fp32 residual stream)."""
+    key = dom.split(" ")[0]
+    if key == "gemm_fc1_gelu":
+        return 2 * (M * D + 4 * D * D + M * 4 * D)
+    if key == "gemm_res32":         # attn.proj and mlp.fc2 share the symbol: the per-launch average of the two shapes
+        return (2 * (M * D + D * D) + 8 * M * D + 2 * (M * 4 * D + 4 * D * D) + 8 * M * D) // 2
+    if key == "gemm_qkv":
+        return 2 * (M * D + 3 * D * D + M * 3 * D)
+    return 2 * 4 * B * (D // 64) * npad_tok * 64
+
+
+def launch_check(args):
+    """--launch-check: the N-rank rendezvous and the reductions the bench line depends on, on gloo, no GPU touched."""
+    from lseg_hip import dist as D
+    rank, local_rank, world = D.init_from_env("gloo")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    slow = D.max_over_ranks(1.0 + rank)
+    rates = D.gather_floats(10.0 * (rank + 1))
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "max_over_ranks": slow, "per_rank": rates}), flush=True)
+    D.barrier()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 def cpu_baseline(cfg, sd, tok, size, threads, samples=3):
     """The CPU oracle (a port of the reference forward, oracle/lseg_oracle.py) timed on this
     box's host cores.  BOUNDED sample: `samples` B=1 forwards of the same workload (fp32 image tower +
-    fp16-emulated text tower recomputed, reference semantics), after a warm-up on the reduced
-    twin so library start-up is not timed; the median is reported.  torch CPU GEMMs stop scaling (and
-    thrash) far below the core count of a many-socket host, so the thread count is capped and reported as `cores`."""
+    fp16-emulated text tower recomputed, reference semantics) per thread count, after a warm-up on the reduced
+    twin so library start-up is not timed; the median is reported.  SURVEY.md §8d asks for os.cpu_count() threads; torch CPU
+    GEMMs often stop scaling far below the core count of a many-socket host, so 32 threads are timed NEXT to it and `value`
+    is the faster of the two with its own `cores` (both are listed under `by_threads`)."""
     from oracle.lseg_oracle import lseg_forward
     from lseg_hip.config import get_config
     from lseg_hip.synth import synthetic_images, synthetic_state_dict, synthetic_tokens
-    torch.set_num_threads(threads)
+    ncpu = os.cpu_count() or 1
+    counts = [threads] if threads else sorted({ncpu, min(32, ncpu)}, reverse=True)
     tiny = get_config("tiny16")
+    by = {}
     with torch.no_grad():
         lseg_forward(synthetic_state_dict(tiny), synthetic_images(1, 64, 64),
                      synthetic_tokens(["a", "b"], tiny.text.vocab, tiny.text.ctx), tiny)
         x = synthetic_images(1, size, size, seed=0)
-        times = []
-        for _ in range(max(1, samples)):
-            t0 = time.time()
-            lseg_forward(sd, x, tok, cfg)
-            times.append(time.time() - t0)
-    dt = sorted(times)[len(times) // 2]
-    return {"value": round(1.0 / dt, 4), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"median of {len(times)} timed B=1 forwards of the same workload (torch-CPU oracle, {threads} threads of "
-                      f"{os.cpu_count()} host cores, text tower recomputed): " + ", ".join(f"{t:.2f}" for t in times) + " s"}
+        budget_t0 = time.time()
+        for n in counts:
+            torch.set_num_threads(n)
+            times = []
+            for i in range(max(1, samples)):
+                t0 = time.time()
+                lseg_forward(sd, x, tok, cfg)
+                times.append(time.time() - t0)
+                if time.time() - budget_t0 > 40.0 and i >= 1:        # bounded: a slow host does not stall the bench line
+                    break
+            by[n] = times
+    med = {n: sorted(t)[len(t) // 2] for n, t in by.items()}
+    best = min(med, key=med.get)
+    return {"value": round(1.0 / med[best], 4), "unit": "images/sec", "cores": best, "kind": "port",
+            "by_threads": {str(n): {"images_per_sec": round(1.0 / med[n], 4), "seconds": [round(t, 2) for t in by[n]]} for n in by},
+            "host_cores": ncpu,
+            "sample": f"median of {len(by[best])} timed B=1 forwards of the same workload per thread count (torch-CPU oracle, text tower "
+                      f"recomputed) at {', '.join(str(n) for n in by)} threads of {ncpu} host cores; value = the faster count"}
 
 
 def time_forward(eng, x, steps, warmup, sync):
@@ -208,13 +357,21 @@ def latest_traffic_file():
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))          # N ranks, one per GPU; this process only waits for them
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: the line would mislabel the device count")
+    if args.launch_check:
+        return launch_check(args)
+    if args.pmc_child:
+        return pmc_child(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the LSeg HIP engine has no CPU fallback")
     from lseg_hip import dist as D
+    if torch.cuda.device_count() <= int(os.environ.get("LOCAL_RANK", "0")):
+        raise SystemExit(f"rank {os.environ.get('RANK')}: no device {os.environ.get('LOCAL_RANK')} on this node ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     rank, local_rank, world = D.init_from_env("nccl")        # "nccl" == RCCL on ROCm
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -299,6 +456,7 @@ def main():
         out = eng.forward(x)
     sync()
     dt = time.perf_counter() - t0
+    dt_local = dt
     prof = {f: eng.profile(f) for f in ["forward"] + dom_fams}
     eng.set_profiling(False)
     dt = D.max_over_ranks(dt, device="cuda")
@@ -319,6 +477,18 @@ def main():
         if dt_ != chosen:
             other[dt_] = B * world / D.max_over_ranks(time_forward(e, x, min(args.steps, 10), 2, sync), device="cuda")
 
+    # HBM-side traffic of the dominant symbol, collected in this run by two counter-only child passes (N = 1; outside the timed region)
+    pmc_now, pmc_note = None, "disabled (--no-pmc-traffic)" if args.no_pmc_traffic else "N > 1: not collected"
+    if rank == 0 and world == 1 and not args.no_pmc_traffic:
+        torch.cuda.synchronize()
+        Mtok_ = B * cfg.tokens(args.size, args.size)
+        npad = (cfg.tokens(args.size, args.size) + 127) // 128 * 128
+        try:
+            pmc_now, pmc_note = pmc_traffic_in_run(dom, chosen, args, algorithmic_bytes(dom, Mtok_, cfg.dim, B, npad))
+        except Exception as e:                                   # noqa: BLE001  (the line must survive a failing profiler)
+            pmc_now, pmc_note = None, f"{type(e).__name__}: {e}"
+
+    per_rank = D.gather_floats(B * args.steps / dt_local, device="cuda")
     if rank == 0:
         ms = dt / args.steps * 1e3
         ips = world * B * args.steps / dt
@@ -329,15 +499,16 @@ def main():
         roof = None
         if n_l:
             ach = fl / (t_ms * 1e-3) / 1e12
-            traffic = None
+            traffic = pmc_now                       # measured in this run (below the timed region), or the replayed profile
             tpath = latest_traffic_file()
-            if tpath:
+            if traffic is None and tpath:
                 tj = json.load(open(tpath))
                 key = {"gemm_res32": "res32_gemm", "gemm_fc1_gelu": "mlp_fc1_gemm", "gemm_qkv": "qkv_gemm", "attention": "attention"}[dom.split(" ")[0]]
                 t = tj.get(key, {})
                 if t.get("batch", B) == B and "traffic_bytes_per_launch" in t and t.get("dtype", "bf16") == chosen:
                     traffic = {"bytes_per_launch": round(t["traffic_bytes_per_launch"]), "algorithmic_bytes": t.get("algorithmic_bytes_per_launch"),
                                "replayed_from": os.path.relpath(tpath, ROOT), "collected_at_commit": tj.get("_meta", {}).get("commit"),
+                               "in_run_collection": pmc_note,
                                "source": "NOT measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/collect_profiles.sh), "
                                          "FETCH x2 gfx950 correction; L2->fabric bytes incl. Infinity-Cache hits"}
             roof = {"bound": "mfma", "kernel": f"lseg_gemm_kernel / lseg_attention_kernel family: {dom}; {chosen} operands; tile by problem size",
@@ -388,6 +559,7 @@ def main():
                                    f"K={K} ADE20K labels, text tower recomputed every call",
                        "per_gpu_batch": B, "global_batch": B * world, "labels": K,
                        "parallelism": f"dp{world} (batch sharded, no collectives)"},
+            "per_rank_images_per_sec": [round(v, 1) for v in per_rank],
             "parity": parity.get(chosen),
             "dtype_selection": sel,
             "path_tflops": round(world * gf_step / (ms * 1e-3) / 1e3, 2),
@@ -444,8 +616,7 @@ def main():
         line["config5_k1000"] = k1000
         line["train_step"] = train
         if world == 1 and not args.no_cpu_baseline:
-            threads = args.cpu_threads or min(32, os.cpu_count() or 1)
-            line["cpu_baseline"] = cpu_baseline(cfg, sd, tok, args.size, threads, args.cpu_samples)
+            line["cpu_baseline"] = cpu_baseline(cfg, sd, tok, args.size, args.cpu_threads, args.cpu_samples)
         dog.cancel()
         print(json.dumps(line), flush=True)
     dog.cancel()

@@ -63,6 +63,16 @@ def max_over_ranks(value: float, device: str = "cpu") -> float:
     return float(t.item())
 
 
+def gather_floats(value: float, device: str = "cpu") -> List[float]:
+    """Every rank's value, in rank order, on every rank (the bench line's per-rank images/s)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    outs = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, t)
+    return [float(o.item()) for o in outs]
+
+
 def sum_over_ranks(t: torch.Tensor) -> torch.Tensor:
     """Metric counters (pixAcc / intersection / union histograms) are additive across shards."""
     if dist.is_initialized() and dist.get_world_size() > 1:

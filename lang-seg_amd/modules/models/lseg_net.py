@@ -20,8 +20,13 @@ from lseg_hip.tokenizer import tokenize
 from .lseg_blocks import FeatureFusionBlock_custom, Interpolate, _make_encoder
 from .lseg_vit import _NoForward
 
-# MFMA operand type of inference engines unless the constructor says otherwise (image_dtype=...); see LSeg.__init__
-DEFAULT_IMAGE_DTYPE = os.environ.get("LSEG_IMAGE_DTYPE", "fp16")
+# MFMA operand type of inference engines unless the constructor says otherwise (image_dtype=...); see LSeg.__init__.
+# The environment is read when a network is CONSTRUCTED (not at import), so LSEG_IMAGE_DTYPE set after `import modules` still counts.
+DEFAULT_IMAGE_DTYPE = "fp16"
+
+
+def default_image_dtype():
+    return os.environ.get("LSEG_IMAGE_DTYPE", DEFAULT_IMAGE_DTYPE)
 
 
 class depthwise_conv(_NoForward):                      # lseg_net.py:29-40
@@ -140,7 +145,14 @@ class LSeg(BaseModel):
         # MFMA operand type of the image tower.  The reference's tower is fp32; of the two 16-bit types fp16 (11 significand bits) is 8x
         # closer to it than bf16 (8) at the same MFMA rate (DESIGN.md par. 4, bench.py `dtype_selection`).  Training engines are bf16:
         # the per-logit gradient of a mean over 1.8 M pixels is ~1e-7 and would flush to zero in fp16.
-        self.image_dtype = kwargs.get("image_dtype", DEFAULT_IMAGE_DTYPE)
+        self.image_dtype = kwargs.get("image_dtype", default_image_dtype())
+        # fp16 inference engines check their 16-bit activations for overflow (65504) on the first forward after every (re)pack and on
+        # demand (`check_overflow`): a network whose activations leave the fp16 range falls back to bf16 LOUDLY (warning + rebuild),
+        # never to inf / NaN masks (lseg_get_overflow)
+        self.overflow_fallback = kwargs.get("overflow_fallback", True)
+        # training: the reference's head gradient is fp16-subnormal arithmetic (DESIGN par. 3.6) and the engine reproduces it by
+        # default; exact_head_grad=True (or LSEG_EXACT_HEAD_GRAD=1) keeps the un-rounded gradient instead (lseg_config.flags bit 1)
+        self.exact_head_grad = bool(kwargs.get("exact_head_grad", os.environ.get("LSEG_EXACT_HEAD_GRAD", "") not in ("", "0")))
         self.cache_text = kwargs.get("cache_text", False)
         # image b of a batch == the same image alone to fp32 round-off (no split-K at small batches): validation / regression runs
         self.batch_invariant = kwargs.get("batch_invariant", False)
@@ -181,6 +193,7 @@ class LSeg(BaseModel):
             eng = HipEngine(self.cfg, H, W, max_batch=max(B, eng.max_batch if eng else 1),
                             max_labels=max(K, eng.max_labels if eng else 1), device=device,
                             image_dtype="bf16" if train else self.image_dtype,
+                            exact_head_grad=bool(getattr(self, "exact_head_grad", False)),
                             batch_invariant=bool(getattr(self, "batch_invariant", False)))
             eng._stamp = None
             eng._tok = None
@@ -246,10 +259,13 @@ class LSeg(BaseModel):
             if world > 1 and not self.autograd_grads:
                 ts.exchange = BucketExchange(eng.grad_buckets)
                 eng.set_bucket_callback(ts.exchange.ready)
-                if self.sync_batchnorm:
-                    from lseg_hip.train import BnSync
-                    ts.bn = BnSync(eng, world)
-                    ts.sync_bn = True
+            if world > 1 and self.sync_batchnorm:
+                # SyncBatchNorm (utils.py:34) belongs to the FORWARD/backward arithmetic, not to the gradient exchange: it is installed in
+                # DDP-wrapper mode (autograd_grads=True, Lightning accelerator='ddp' reducing the gradients itself) as well -- there the
+                # reference runs torch.nn.SyncBatchNorm under DistributedDataParallel
+                from lseg_hip.train import BnSync
+                ts.bn = BnSync(eng, world)
+                ts.sync_bn = True
             eng._ts = ts
             eng._named = [(k, p) for k, p in self.named_parameters() if k in eng.grads]
             eng._nbt = [b for k, b in self.named_buffers() if k.endswith("num_batches_tracked") and k.startswith("scratch.")

@@ -18,7 +18,7 @@ import torch.nn as nn
 from lseg_hip.config import get_config
 from lseg_hip.tokenizer import tokenize
 from .lseg_blocks import Interpolate, _make_encoder
-from .lseg_net import BaseModel, DEFAULT_IMAGE_DTYPE, LSeg as _LSegShared, _make_fusion_block
+from .lseg_net import BaseModel, default_image_dtype, LSeg as _LSegShared, _make_fusion_block
 
 
 class LSeg(_LSegShared):
@@ -47,7 +47,7 @@ class LSeg(_LSegShared):
         self.texts = [tokenize(["others", name], self.cfg.text.ctx, self.cfg.text.vocab) for name in self.label_list]
         self._engines = OrderedDict()
         self.max_engines = kwargs.get("max_engines", 4)
-        self.image_dtype = kwargs.get("image_dtype", DEFAULT_IMAGE_DTYPE)
+        self.image_dtype = kwargs.get("image_dtype", default_image_dtype())
         self.cache_text = kwargs.get("cache_text", False)
         self.autograd_grads = False
         self.sync_batchnorm = False

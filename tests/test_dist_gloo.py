@@ -142,3 +142,34 @@ def test_bucketed_gradient_allreduce_two_ranks():
         assert all(f".blocks.{3 - j}." in k or "0.project.0" in k or j == 3 for k in keys[1 + j]), keys[1 + j][:4]
         assert any(f".blocks.{3 - j}." in k for k in keys[1 + j])
     assert any("patch_embed" in k for k in keys[4]) and any("pos_embed" in k for k in keys[4])
+
+
+@pytest.mark.timeout(240)
+def test_bench_gpus_2_without_torchrun_env_spawns_two_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment must launch two ranks by itself (it used to time ONE
+    device and print n_gpus 1); --launch-check runs the rendezvous and the line's reductions on gloo without touching a GPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout            # rank 0 prints ONE line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["max_over_ranks"] == 2.0 and line["per_rank"] == [10.0, 20.0]
+
+
+@pytest.mark.timeout(120)
+def test_bench_refuses_to_measure_fewer_devices_than_asked():
+    """No silent one-GPU run labelled as N: with fewer than N visible devices the launcher exits non-zero with the reason; a mismatching
+    WORLD_SIZE is refused too."""
+    import subprocess
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    n = (torch.cuda.device_count() if torch.cuda.is_available() else 0) + 2
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], env=env, capture_output=True, text=True, timeout=100)
+    assert r.returncode != 0 and "refusing to measure fewer devices" in (r.stderr + r.stdout)
+    env["WORLD_SIZE"] = "3"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=env, capture_output=True, text=True, timeout=100)
+    assert r.returncode != 0

@@ -153,6 +153,86 @@ def test_data_parallel_trainer_two_ranks_on_one_gpu(sync_bn):
     assert both[0] == both[1], both                # bit-identical averaged gradients and weights on the two ranks
 
 
+def _ddp_mode_worker(rank, world, port, q):
+    try:
+        for p in (ROOT, os.path.join(ROOT, "lang-seg_amd")):
+            sys.path.insert(0, p)
+        os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        warnings.simplefilter("ignore")
+        import torch.distributed as dist
+        from lseg_hip.config import get_config
+        from lseg_hip.synth import synthetic_state_dict, read_labels
+        from modules.models.lseg_net import LSegNet
+        from oracle import make_golden as MG
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        cfg = get_config("tiny16")
+        sd = synthetic_state_dict(cfg, seed=9)
+        labels = read_labels(MG.LABELS)[:5]
+        H = W = 64
+        shards = [_data(2, H, W, 5, 40 + r) for r in range(world)]
+        net = LSegNet(labels=labels, backbone="tiny16", features=64, arch_option=0, block_depth=0, activation="lrelu", autograd_grads=True)
+        net.load_state_dict(sd)
+        net = net.cuda().train()
+        x, t = shards[rank]
+        loss = net.forward_loss(x.cuda(), t.cuda())
+        loss.backward()
+        torch.cuda.synchronize()
+        eng = next(e for k, e in net._engines.items() if k[3])
+        assert eng._ts.sync_bn and eng._ts.exchange is None       # SyncBatchNorm on, gradient exchange left to the (absent) DDP wrapper
+        bn = net.scratch.refinenet1.resConfUnit2.bn1
+        stats = torch.cat([bn.running_mean.flatten(), bn.running_var.flatten()]).cpu()
+        g_local = net.scratch.refinenet1.resConfUnit2.conv1.weight.grad.detach().clone()
+        both = [None] * world
+        dist.all_gather_object(both, stats.tolist())
+        if rank == 0:
+            # reference: ONE process on the concatenated batch sees the same BatchNorm statistics
+            one = LSegNet(labels=labels, backbone="tiny16", features=64, arch_option=0, block_depth=0, activation="lrelu")
+            one.load_state_dict(sd)
+            one = one.cuda().train()
+            xs, ts = torch.cat([s[0] for s in shards]), torch.cat([s[1] for s in shards])
+            one.forward_loss(xs.cuda(), ts.cuda()).backward()
+            torch.cuda.synchronize()
+            bo = one.scratch.refinenet1.resConfUnit2.bn1
+            ref = torch.cat([bo.running_mean.flatten(), bo.running_var.flatten()]).cpu()
+            q.put({"both": both, "ref": ref.tolist(), "init": torch.cat([sd["scratch.refinenet1.resConfUnit2.bn1.running_mean"].flatten(),
+                                                                          sd["scratch.refinenet1.resConfUnit2.bn1.running_var"].flatten()]).tolist(),
+                   "grad_finite": bool(torch.isfinite(g_local).all()), "grad_norm": float(g_local.norm())})
+        dist.barrier()
+        dist.destroy_process_group()
+    except BaseException as e:                 # noqa: BLE001
+        import traceback
+        q.put("ERROR rank %d: %s\n%s" % (rank, e, traceback.format_exc()))
+        raise
+
+
+@pytest.mark.timeout(600)
+def test_sync_batchnorm_is_installed_in_ddp_wrapper_mode():
+    """with autograd_grads=True (the mode INTEGRATION.md prescribes under Lightning accelerator='ddp', the
+    reference's own launch: utils.py:21 + sync_batchnorm=True at :34) train-mode BatchNorm used per-GPU statistics silently.  Two
+    ranks on one GPU over gloo: both must end with IDENTICAL running statistics, equal to one process on the concatenated batch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_mode_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        rep = q.get(timeout=300)
+        assert not (isinstance(rep, str) and rep.startswith("ERROR")), rep
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs)
+    a, b, ref, init = (torch.tensor(v) for v in (rep["both"][0], rep["both"][1], rep["ref"], rep["init"]))
+    assert torch.equal(a, b), (a - b).abs().max()                 # the two ranks normalised with the same (global) statistics
+    moved = (ref - init).abs().max().item()
+    assert moved > 1e-4 and (a - ref).abs().max().item() <= 0.02 * moved + 1e-6, ((a - ref).abs().max().item(), moved)
+    assert rep["grad_finite"] and rep["grad_norm"] > 0
+
+
 class _TinyModule:
     """LSegmentationModule with a tiny16 LSegNet (LSegModule builds the full-size backbones only)."""
 
