@@ -181,6 +181,13 @@ int lseg_get_profile(lseg_handle h, const char* family, double* total_ms, int64_
  * 1 GELU(erf), 2 QuickGELU, 3 ReLU.   (timm Linear / CLIP Linear / 1x1 conv) */
 int lseg_op_gemm(const void* d_A, const void* d_W, const float* d_bias, const float* d_residual,
                  void* d_C, int M, int N, int K, int ab_dtype, int out_dtype, int act, void* stream);
+/* The four GEMM forms of a timm Block (lseg_vit.py:196-197 -> [3P] timm Block / Attention / Mlp) on the engine's specialised epilogues,
+ * standalone: kind 0  C = T(A W^T + b)  (T = ab_dtype);  1  C = T(gelu(A W^T + b))  (mlp.fc1);  2  C += A W^T + b on an fp32 C (the residual
+ * stream: attn.proj, mlp.fc2; d_Cq is read and written);  3  the qkv Linear with timm's reshape/permute folded into the store: d_Cq = q and
+ * d_Ck = k as [B*heads, npad, 64], d_Cv = v TRANSPOSED [B*heads, 64, npad] (N = 3*heads*64, M = B*ntok, pad rows untouched).
+ * max_grid > 0 caps the persistent grid (tools/epilogue_table.py).  d_bias fp32 [N] is required. */
+int lseg_op_gemm_vit(const void* d_A, const void* d_W, const float* d_bias, void* d_Cq, void* d_Ck, void* d_Cv, int M, int N, int K,
+                     int ab_dtype, int kind, int ntok, int npad, int max_grid, void* stream);
 /* LayerNorm over the last dim: in fp32|fp16 [M,D] -> out bf16|fp16 [M,D] */
 int lseg_op_layernorm(const void* d_in, int in_dtype, const float* d_gamma, const float* d_beta,
                       void* d_out, int out_dtype, int M, int D, float eps, void* stream);
@@ -189,6 +196,11 @@ int lseg_op_layernorm(const void* d_in, int in_dtype, const float* d_gamma, cons
 int lseg_op_attention(const void* d_q, const void* d_k, const void* d_vt, void* d_out,
                       int B, int H, int Ntok, int Npad, int dtype, int causal, float scale,
                       void* stream);
+/* The same product for a q that already carries softmax scale * log2(e) (the inference engine folds it into the qkv Linear's epilogue,
+ * one rounding): out = softmax2(Q' K^T) V with softmax2 in base 2, no mask.  d_lse2 (optional, fp32 [B*H, Npad]) receives log2 sum_k
+ * 2^(q'.k).  Same layouts as lseg_op_attention. */
+int lseg_op_attention_prescaled(const void* d_q, const void* d_k, const void* d_vt, void* d_out, float* d_lse2,
+                                int B, int H, int Ntok, int Npad, int dtype, void* stream);
 /* 3x3 conv, NHWC, zero-padded borders: in [B,H+2,W+2,Cin] (bf16, border = 0) ->
  * out [B,Ho+2,Wo+2,Cout] interior written; w_packed [Cout, 9*Cin] bf16 (tap-major).
  * stride 1|2, relu_in / relu_out flags, bias fp32 [Cout] or NULL, residual (same

@@ -179,6 +179,25 @@ int lseg_op_gemm(const void* A, const void* W, const float* bias, const float* r
     return launch_gemm(g, ab, (hipStream_t)stream);
 }
 
+int lseg_op_gemm_vit(const void* A, const void* W, const float* bias, void* Cq, void* Ck, void* Cv, int M, int N, int K, int ab_dtype, int kind,
+                     int ntok, int npad, int max_grid, void* stream) {
+    int r = require_device(); if (r) return r;
+    int ab;
+    if ((r = op_dt(ab_dtype, &ab))) return r;
+    if (kind < 0 || kind > 3 || !bias) return set_error(LSEG_ERR_INVALID, "lseg_op_gemm_vit: kind 0..3 and a bias");
+    GemmArgs g;
+    gemm_args_init(g);
+    g.A = (const uint16_t*)A; g.W = (const uint16_t*)W; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K;
+    g.bias = bias; g.C = Cq; g.ldc = N; g.out_dtype = ab; g.map_mode = MAP_LINEAR; g.max_grid = max_grid;
+    if (kind == 1) { g.act = ACT_GELU; g.tag = 1; }
+    if (kind == 2) { g.res_mode = RES_DEST; g.res = Cq; g.res_dtype = DT_F32; g.out_dtype = DT_F32; }
+    if (kind == 3) {
+        if (N % 192 || ntok < 1 || npad < ntok || M % ntok) return set_error(LSEG_ERR_INVALID, "lseg_op_gemm_vit: qkv needs N = 3 * heads * 64, M = B * ntok");
+        g.map_mode = MAP_QKV; g.Ck = Ck; g.Cv = Cv; g.qkv_dim = N / 3; g.qkv_ntok = ntok; g.qkv_npad = npad; g.qkv_heads = N / 192;
+    }
+    return launch_gemm(g, ab, (hipStream_t)stream);
+}
+
 int lseg_op_layernorm(const void* in, int in_dtype, const float* gamma, const float* beta, void* out, int out_dtype,
                       int M, int D, float eps, void* stream) {
     int r = require_device(); if (r) return r;
@@ -193,6 +212,14 @@ int lseg_op_attention(const void* q, const void* k, const void* vt, void* out, i
     int dt;
     if ((r = op_dt(dtype, &dt))) return r;
     return launch_attention(q, k, vt, out, B, H, Ntok, Npad, dt, causal, scale, (hipStream_t)stream);
+}
+
+int lseg_op_attention_prescaled(const void* q, const void* k, const void* vt, void* out, float* lse2, int B, int H, int Ntok, int Npad,
+                                int dtype, void* stream) {
+    int r = require_device(); if (r) return r;
+    int dt;
+    if ((r = op_dt(dtype, &dt))) return r;
+    return launch_attention_ex(q, k, vt, out, lse2, B, H, Ntok, Npad, dt, 0, 1.0f, 1, (hipStream_t)stream);
 }
 
 int lseg_op_conv3x3(const void* in, const void* w_packed, const float* bias, const void* residual, void* out, int B,

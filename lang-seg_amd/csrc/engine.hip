@@ -751,12 +751,18 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
         g.A = ln_; g.W = b.qkv.w; g.M = M; g.N = 3 * D; g.K = D; g.lda = D; g.ldw = D;
         g.bias = b.qkv.b; g.out_dtype = img_dt_; g.map_mode = MAP_QKV;
         g.C = q_; g.Ck = k_; g.Cv = vt_; g.qkv_dim = D; g.qkv_ntok = ntok_; g.qkv_npad = npad_; g.qkv_heads = H;
+        // the softmax scale (head_dim^-0.5 = 0.125 for 64) * log2(e) rides on q through the QKV epilogue's single rounding: the attention
+        // kernel's matrix pipe then delivers exp2 arguments (attention.hip VER 2 / 3)
+        static const bool no_prescale = getenv("LSEG_ATTN_NO_PRESCALE") != nullptr;      // tools: A/B against the scale-in-the-softmax form
+        g.qkv_qscale = 0.125f * 1.4426950408889634f;
+        const bool prescaled = !strict_ && !no_prescale && gemm_qkv_scales_q(g, img_dt_);
+        if (!prescaled) g.qkv_qscale = 0.f;
         pe = prof_begin(PF_QKV, st);
         TRY(igemm(g, st));
         prof_end(PF_QKV, pe, 2.0 * M * 3.0 * D * D, st);
         pe = prof_begin(PF_ATTN, st);
         if (strict_) TRY(launch_attention_strict(q_, k_, vt_, att_, pl(q_), pl(vt_), pl(att_), B, H, ntok_, npad_, 0.125f, st));
-        else TRY(launch_attention(q_, k_, vt_, att_, B, H, ntok_, npad_, img_dt_, 0, 0.125f, st));
+        else TRY(launch_attention_ex(q_, k_, vt_, att_, nullptr, B, H, ntok_, npad_, img_dt_, 0, 0.125f, prescaled ? 1 : 0, st));
         prof_end(PF_ATTN, pe, 4.0 * B * ntok2 * D, st);          // QK^T + PV, SURVEY 8(d): 4 N^2 D per image and block
         gemm_args_init(g);
         g.A = att_; g.W = b.proj.w; g.M = M; g.N = D; g.K = D; g.lda = D; g.ldw = D;

@@ -55,6 +55,8 @@ struct GemmArgs {
     int ps_s, ps_C;             // MAP_PIXSHUF
     // MAP_QKV
     void* Ck; void* Cv; int qkv_dim, qkv_ntok, qkv_npad, qkv_heads;
+    float qkv_qscale;           // != 0: the q third is written as T((acc + bias) * qkv_qscale) -- the attention's softmax scale * log2(e) folded
+                                // into the epilogue's single rounding (specialised QKV epilogue only: gemm_qkv_scales_q tells)
     float rn_scale;             // MAP_ROWNORM: logit scale
     int tag;                    // 0 generic, 1 = the profiled dominant instance (distinct symbol)
     int dbg;                    // tools only: bits 0-1 ablation (1 = skip epilogue stores, 2 = skip the epilogue), 4 = phase timing, 8 = no stagger
@@ -80,6 +82,7 @@ struct GemmArgs {
     // k + (tap / 3 - 1) * kconv_wp + (tap % 3 - 1) (rows outside [0, k_valid) are zero); relu_in clamps the W operand (the RCU convs read
     // ReLU(x)).  Needs kconv_cin % 128 == 0 (a 128-wide column tile lies inside one tap).
     int kconv_cin, kconv_wp;
+    int max_grid;               // tools: cap of the persistent grid (workgroups, multiple of 8; 0 = the whole chip)
     int tile_hint;              // 0: the launcher's cost model picks the tile; 2 = 128x128, 6 = 256x256 (callers that plan tile and split-K together)
 };
 
@@ -89,6 +92,8 @@ int device_cu_count(int dev);
 int launch_gemm(const GemmArgs& g, int ab_dtype, hipStream_t stream);
 // true when launch_gemm would run this problem on the specialised padded-NHWC epilogue (the one that honours C_relu)
 bool gemm_epilogue_is_pad16(const GemmArgs& g, int ab_dtype);
+// true when launch_gemm would honour g.qkv_qscale (it refuses a non-zero scale otherwise)
+bool gemm_qkv_scales_q(const GemmArgs& g, int ab_dtype);
 // true when launch_gemm would honour g.C_pre / g.dgelu_pre (it refuses them otherwise)
 bool gemm_fuses_gelu(const GemmArgs& g, int ab_dtype);
 

@@ -397,6 +397,25 @@ enum Epi {
                           // of small batches, whose slabs the following LayerNorm sums into the fp32 residual stream)
 };
 
+// Epilogue stores of the specialised epilogues go through these three helpers so that the attribution builds (tools/epilogue_table.py,
+// make VARIANT=...: -DGEMM_EPI_ABL=1 keeps the loads and the arithmetic and drops the stores; 2 drops the whole epilogue, 3 drops the
+// residual loads of EPI_RES32, 4 writes V like K in EPI_QKV16) measure the K-loop and each epilogue part of the SAME kernel.
+#ifndef GEMM_EPI_ABL
+#define GEMM_EPI_ABL 0
+#endif
+__device__ __forceinline__ void st_u4(void* p, const uint4 v) {
+    if constexpr (GEMM_EPI_ABL == 1) asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(p));
+    else *reinterpret_cast<uint4*>(p) = v;
+}
+__device__ __forceinline__ void st_f4(float* p, const float4 v) {
+    if constexpr (GEMM_EPI_ABL == 1) asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(p));
+    else *reinterpret_cast<float4*>(p) = v;
+}
+__device__ __forceinline__ void st_h(uint16_t* p, const uint16_t v) {
+    if constexpr (GEMM_EPI_ABL == 1) asm volatile("" ::"v"(v), "v"(p));
+    else *p = v;
+}
+
 // two adjacent 16-column sub-tiles (4 columns per lane each) -> 8 contiguous columns (16 bytes) per lane
 template <typename T>
 __device__ __forceinline__ uint4 widen16(const float (&x)[4], const float (&y)[4]) {
@@ -464,7 +483,7 @@ __device__ __forceinline__ void fast_epilogue(const GemmArgs& g, f32x4_t (&acc)[
                     y[0] = c[0]; y[1] = c[1]; y[2] = d[0]; y[3] = d[1];
                 }
                 const uint4 o = widen16<OT>(x, y);
-                if (m < g.M) *reinterpret_cast<uint4*>(p + i * 16) = o;
+                if (m < g.M) st_u4(p + i * 16, o);
             });
         });
     } else if constexpr (EPI == EPI_RES32) {
@@ -481,7 +500,10 @@ __device__ __forceinline__ void fast_epilogue(const GemmArgs& g, f32x4_t (&acc)[
                 if (m > g.M - 1) m = g.M - 1;
                 const float* rp = rbase + (size_t)m * g.ldc;
 #pragma unroll
-                for (int i = 0; i < NI; ++i) rv[decltype(jc)::value][i] = *reinterpret_cast<const float4*>(rp + i * 16);
+                for (int i = 0; i < NI; ++i) {
+                    if constexpr (GEMM_EPI_ABL == 3) rv[decltype(jc)::value][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    else rv[decltype(jc)::value][i] = *reinterpret_cast<const float4*>(rp + i * 16);
+                }
             });
             static_for<0, JC>([&](auto jc) {
                 constexpr int jl = decltype(jc)::value, j = jb + jl;
@@ -492,8 +514,7 @@ __device__ __forceinline__ void fast_epilogue(const GemmArgs& g, f32x4_t (&acc)[
                     float v[4];
                     biased(ic, std::integral_constant<int, j>{}, v);
                     if (m < g.M)
-                        *reinterpret_cast<float4*>(p + i * 16) =
-                            make_float4(v[0] + rv[jl][i].x, v[1] + rv[jl][i].y, v[2] + rv[jl][i].z, v[3] + rv[jl][i].w);
+                        st_f4(p + i * 16, make_float4(v[0] + rv[jl][i].x, v[1] + rv[jl][i].y, v[2] + rv[jl][i].z, v[3] + rv[jl][i].w));
                 });
             });
         });
@@ -615,17 +636,21 @@ __device__ __forceinline__ void fast_epilogue(const GemmArgs& g, f32x4_t (&acc)[
                 float x[4], y[4];
                 biased(std::integral_constant<int, i>{}, jc, x);
                 biased(std::integral_constant<int, i + 1>{}, jc, y);
-                if (which < 2) {
-                    uint16_t* p = (uint16_t*)(which ? g.Ck : g.C) + (bh * g.qkv_npad + t) * 64 + d0 + cw;
+                if (which == 0 && g.qkv_qscale != 0.f) {          // q carries the softmax scale (wave-uniform branch)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { x[r] *= g.qkv_qscale; y[r] *= g.qkv_qscale; }
+                }
+                if (which < 2 || GEMM_EPI_ABL == 4) {
+                    uint16_t* p = (uint16_t*)(which == 2 ? g.Cv : which ? g.Ck : g.C) + (bh * g.qkv_npad + t) * 64 + d0 + cw;
                     const uint4 o = widen16<T>(x, y);
-                    if (m < g.M) *reinterpret_cast<uint4*>(p) = o;
+                    if (m < g.M) st_u4(p, o);
                 } else if (m < g.M) {
                     // V^T [b, head, d, t]: t is the contiguous axis; 16 lanes write 16 consecutive tokens
                     uint16_t* p = (uint16_t*)g.Cv + (bh * 64 + d0 + r16 * 4) * g.qkv_npad + t;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        p[(size_t)r * g.qkv_npad] = from_f32<T>(x[r]);
-                        p[(size_t)(16 + r) * g.qkv_npad] = from_f32<T>(y[r]);
+                        st_h(p + (size_t)r * g.qkv_npad, from_f32<T>(x[r]));
+                        st_h(p + (size_t)(16 + r) * g.qkv_npad, from_f32<T>(y[r]));
                     }
                 }
             });
@@ -1133,8 +1158,15 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
                 for (int i = 0; i < NI; ++i)
                     biasv[i] = *reinterpret_cast<const float4*>(g.bias + (EPI == EPI_PIX16 ? (n0c + wn * WN + i * 16) % g.ps_C : n0c + wn * WN + i * 16) + (lane >> 4) * 4);
             }
-            fast_epilogue<T, EPI, MI, NI>(g, acc, m0c + wm * WM, n0c + wn * WN, lane, biasv,
-                                          nsplit > 1 ? (size_t)(tile / per_split) * g.c_split_stride : 0);
+            if constexpr (GEMM_EPI_ABL == 2) {          // attribution build: the K-loop alone (accumulators kept live)
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(acc[i][j][0]), "v"(acc[i][j][1]), "v"(acc[i][j][2]), "v"(acc[i][j][3]));
+            } else {
+                fast_epilogue<T, EPI, MI, NI>(g, acc, m0c + wm * WM, n0c + wn * WN, lane, biasv,
+                                              nsplit > 1 ? (size_t)(tile / per_split) * g.c_split_stride : 0);
+            }
         } else {
         int ncol[NI];
         ColPart cp[NI], cpw[NI / 2];
@@ -1181,6 +1213,7 @@ int launch_one(const GemmArgs& g, hipStream_t stream) {
     const int slots = device_cu_count(dev) * per_cu;
     int grid = ((tiles + 7) / 8) * 8;
     if (grid > slots) grid = slots;
+    if (g.max_grid >= 8 && grid > g.max_grid) grid = g.max_grid & ~7;      // tools: part of the chip (tools/epilogue_table.py)
     auto kern = lseg_gemm_kernel<T, CFG, CONV, RELU_IN, EPI, TAG>;
     // the dynamic-LDS opt-in is a per-DEVICE function attribute: one bit per device (a process may drive several GPUs, one
     // engine and one host thread each: additional_utils/models.py:229-238), set with an atomic so concurrent threads are safe
@@ -1328,6 +1361,11 @@ bool gemm_epilogue_is_pad16(const GemmArgs& g, int ab_dtype) {
     return false;
 }
 
+bool gemm_qkv_scales_q(const GemmArgs& g, int ab_dtype) {
+    const int e = ab_dtype == DT_BF16 ? select_epi<BF16>(g) : ab_dtype == DT_F16 ? select_epi<F16>(g) : EPI_GENERIC;
+    return !g.conv && !g.kmajor && g.map_mode == MAP_QKV && e == EPI_QKV16;
+}
+
 bool gemm_fuses_gelu(const GemmArgs& g, int ab_dtype) {
     static const bool off = getenv("LSEG_NO_GELU_FUSE") != nullptr;       // tools: A/B switch back to the separate GELU passes
     if (off) return false;
@@ -1344,6 +1382,8 @@ int launch_gemm(const GemmArgs& g_in, int ab_dtype, hipStream_t stream) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return set_error(LSEG_ERR_INVALID, "gemm: empty problem %dx%dx%d", g.M, g.N, g.K);
     if ((g.C_pre || g.dgelu_pre) && !gemm_fuses_gelu(g, ab_dtype))
         return set_error(LSEG_ERR_UNSUPPORTED, "gemm: C_pre / dgelu_pre need the specialised 16-bit MAP_LINEAR epilogue (N %% 128 == 0, a bias, 16-byte rows)");
+    if (g.qkv_qscale != 0.f && !gemm_qkv_scales_q(g, ab_dtype))
+        return set_error(LSEG_ERR_UNSUPPORTED, "gemm: qkv_qscale needs the specialised QKV epilogue");
     if (g.C_relu && !gemm_epilogue_is_pad16(g, ab_dtype)) return set_error(LSEG_ERR_UNSUPPORTED, "gemm: C_relu needs the padded-NHWC specialised epilogue");
     if (g.K % 64 != 0) return set_error(LSEG_ERR_UNSUPPORTED, "gemm: K=%d must be a multiple of 64", g.K);
     if (g.conv && (g.cin % 64 != 0)) return set_error(LSEG_ERR_UNSUPPORTED, "conv: Cin=%d must be a multiple of 64", g.cin);

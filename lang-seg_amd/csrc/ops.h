@@ -101,6 +101,8 @@ int launch_conv_wgrad_kmajor(const void* dy_pad, const void* x_pad, int relu_x, 
 // ---- engine-level training step (train.hip) --------------------------------------------------------------------------------
 int launch_attention_lse(const void* q, const void* k, const void* vt, void* out, float* lse2, int B, int H, int ntok, int npad, int dtype,
                          int causal, float scale, hipStream_t stream);
+int launch_attention_ex(const void* q, const void* k, const void* vt, void* out, float* lse2, int B, int H, int ntok, int npad, int dtype,
+                        int causal, float scale, int prescaled, hipStream_t stream);
 int launch_bn_stats(const void* x, float* stats, int B, int H, int W, int C, int dtype, hipStream_t st, int pre_zeroed = 0);
 int launch_bn_apply(const void* x, void* y, const float* stats, const float* gamma, const float* beta, const void* res1, const void* res2,
                     int B, int H, int W, int C, float eps, double count, int dtype, hipStream_t st,

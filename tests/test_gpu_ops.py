@@ -72,6 +72,47 @@ def test_gemm_epilogues(lib, act):
         assert err < tol * max(1.0, ref.abs().max().item()), (od, err)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,ntok,max_grid", [(2, 901, 0), (9, 901, 0), (3, 197, 0), (9, 901, 16)])
+def test_vit_block_gemm_forms(lib, dtype, B, ntok, max_grid):
+    """The four GEMMs of a timm Block on their specialised epilogues (lseg_op_gemm_vit): Linear, Linear + GELU(erf), the fp32 residual
+    read-modify-write, and the qkv Linear with timm's reshape(B,N,3,H,D/H).permute folded into the store (q, k head-major, v
+    transposed) -- against fp32 torch on the rounded operands.  B = 9 runs the 256 x 256 tile configuration (8109 rows), max_grid = 16
+    the persistent schedule with many tiles per workgroup."""
+    D, H = 1024, 16
+    M, npad = B * ntok, (ntok + 127) // 128 * 128
+    A = rnd((M, D), dtype, 11)
+    tol = 2.5e-2 if dtype == torch.bfloat16 else 4e-3
+
+    def run(kind, N, K, Ain, Cq, Ck=None, Cv=None, seed=12):
+        W = rnd((N, K), dtype, seed, 1 / math.sqrt(K))
+        bias = rnd((N,), torch.float32, seed + 1)
+        _lib.check(lib.lseg_op_gemm_vit(P(Ain), P(W), P(bias), P(Cq), P(Ck), P(Cv), M, N, K, DT[dtype], kind, ntok, npad, max_grid, stream()))
+        torch.cuda.synchronize()
+        return Ain.float() @ W.float().t() + bias
+
+    out = torch.zeros((M, D), dtype=dtype).cuda()
+    ref = run(0, D, D, A, out)
+    assert (out.float() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+    hid = torch.zeros((M, 4 * D), dtype=dtype).cuda()
+    ref = F.gelu(run(1, 4 * D, D, A, hid, seed=14))
+    assert (hid.float() - ref).abs().max().item() < tol * max(1.0, ref.abs().max().item())
+    x0 = rnd((M, D), torch.float32, 16, 3.0)
+    x = x0.clone()
+    ref = x0 + run(2, D, 4 * D, hid, x, seed=18)
+    assert (x - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
+    q = torch.full((B * H, npad, 64), 7.0, dtype=dtype).cuda()
+    k = torch.full((B * H, npad, 64), 7.0, dtype=dtype).cuda()
+    vt = torch.full((B * H, 64, npad), 7.0, dtype=dtype).cuda()
+    ref = run(3, 3 * D, D, A, q, k, vt, seed=20).reshape(B, ntok, 3, H, 64).permute(2, 0, 3, 1, 4).reshape(3, B * H, ntok, 64)
+    big = max(1.0, ref.abs().max().item())
+    assert (q[:, :ntok].float() - ref[0]).abs().max().item() < tol * big
+    assert (k[:, :ntok].float() - ref[1]).abs().max().item() < tol * big
+    assert (vt[:, :, :ntok].float() - ref[2].transpose(1, 2)).abs().max().item() < tol * big
+    # pad rows / columns are not written
+    assert (q[:, ntok:] == 7).all() and (k[:, ntok:] == 7).all() and (vt[:, :, ntok:] == 7).all()
+
+
 def test_gemm_transpose_detecting(lib):
     """A = I (padded), asymmetric W: catches a swapped C layout (cdna guide G9)."""
     M = N = K = 64
@@ -132,6 +173,48 @@ def test_attention(lib, dtype, B, H, N, causal):
 def test_attention_rescale_branch(lib):
     _attention_case(lib, torch.bfloat16, 1, 2, 901, False, 30, spike=True)
     _attention_case(lib, torch.float16, 1, 2, 77, True, 31, spike=True)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,N,mode", [(1, 2, 901, "plain"), (3, 16, 226, "plain"), (1, 2, 901, "spike"), (1, 2, 901, "ramp"),
+                                        (1, 2, 901, "low"), (40, 16, 197, "plain")])
+def test_attention_prescaled(lib, dtype, B, H, N, mode):
+    """The inference engine's attention: q arrives as T(q * scale * log2 e) and the kernel bakes the reference max into the QK^T
+    accumulator (attention.hip VER 2 / 3; the reference max moves only when a tile exceeds it by 2^8).  Against fp32 torch on the same
+    rounded operands.  spike: one key dominates one query late in the sequence (the refresh branch fires mid-sequence); ramp: scores
+    grow steadily along the keys (refresh after refresh); low: every score far BELOW zero (the first-tile reference must be the tile's
+    own max, not 0, or every probability underflows); B = 40 runs the 4-wave kernel on a shape whose last query block is mostly padding."""
+    Npad = ((N + 127) // 128) * 128
+    c = 0.125 * 1.4426950408889634
+    q32 = torch.randn((B, H, N, 64), generator=torch.Generator().manual_seed(60)).cuda()
+    k = rnd((B, H, N, 64), dtype, 61)
+    v = rnd((B, H, N, 64), dtype, 62)
+    if mode == "spike":
+        k[:, :, N - 3] = (q32[:, :, 5] * 6.0).to(dtype)
+    elif mode == "ramp":
+        k = (k.float() + q32.mean(dim=2, keepdim=True) * torch.linspace(0, 24, N, device="cuda").view(1, 1, N, 1)).to(dtype)
+        q32 = q32 + q32.mean(dim=2, keepdim=True) * 3
+    elif mode == "low":
+        k = (k.float() * 0.05 - q32.mean(dim=2, keepdim=True) * 30).to(dtype)
+        q32 = q32 * 0.05 + q32.mean(dim=2, keepdim=True) * 8
+    q = (q32 * c).to(dtype)                                        # ONE rounding, as the QKV epilogue does it
+    qp = torch.zeros((B * H, Npad, 64), dtype=dtype).cuda(); qp[:, :N] = q.reshape(B * H, N, 64)
+    kp = torch.zeros((B * H, Npad, 64), dtype=dtype).cuda(); kp[:, :N] = k.reshape(B * H, N, 64)
+    vt = torch.zeros((B * H, 64, Npad), dtype=dtype).cuda(); vt[:, :, :N] = v.reshape(B * H, N, 64).transpose(1, 2)
+    out = torch.full((B, N, H * 64), float("nan"), dtype=dtype).cuda()
+    lse2 = torch.full((B * H, Npad), float("nan"), dtype=torch.float32).cuda()
+    _lib.check(lib.lseg_op_attention_prescaled(P(qp), P(kp), P(vt), P(out), P(lse2), B, H, N, Npad, DT[dtype], stream()))
+    torch.cuda.synchronize()
+    s2 = q.double() @ k.double().transpose(-1, -2)                 # log2 units
+    m = s2.amax(-1, keepdim=True)
+    p = torch.exp2(s2 - m)
+    ref = ((p / p.sum(-1, keepdim=True)) @ v.double()).transpose(1, 2).reshape(B, N, H * 64).float()
+    ref_lse = (m.squeeze(-1) + torch.log2(p.sum(-1))).reshape(B * H, N).float()
+    err = (out.float() - ref).abs().max().item()
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    assert math.isfinite(err) and err < tol * max(1.0, ref.abs().max().item()), (mode, err)
+    lerr = (lse2[:, :N] - ref_lse).abs().max().item()
+    assert math.isfinite(lerr) and lerr < (3e-2 if dtype == torch.bfloat16 else 5e-3), (mode, lerr)
 
 
 def _pad_nhwc(x_nchw, dtype):

@@ -184,7 +184,7 @@ def test_engine_cache_is_bounded_and_keeps_replicas_on_their_own_device(monkeypa
     made, closed = [], []
 
     class FakeEngine:
-        def __init__(self, cfg, H, W, max_batch, max_labels, device=None, image_dtype="bf16", batch_invariant=False):
+        def __init__(self, cfg, H, W, max_batch, max_labels, device=None, image_dtype="bf16", batch_invariant=False, **kw):
             self.key = (H, W, device.index)
             self.max_batch, self.max_labels, self.training = max_batch, max_labels, False
             self.image_dtype = image_dtype
