@@ -170,6 +170,11 @@ int lseg_set_debug(lseg_handle h, int enabled);
  * mlp_fc1; any other non-zero value is a bit mask over the families; 0 switches the events off.  Events for 64 forwards are created
  * by the call, outside any timed region.  flops_per_launch = 2MNK of the family's GEMM (4 N^2 D per image for attention). */
 int lseg_set_profiling(lseg_handle h, int enabled);
+/* Range check of the image tower's 16-bit activations (every 16-bit activation buffer of the plan, as the forwards so far left them):
+ * host_out4[0] = non-finite values (fp16 operands overflow at 65504 -- the reference's tower is fp32, lseg_vit.py:196-197, and cannot),
+ * [1] = finite values with |x| >= 2^15, [2] = the largest finite |x| (fp32 bit pattern), [3] = elements scanned.  Synchronises the
+ * stream.  The Python mirror runs it once after every (re)pack of an fp16 engine and falls back to bf16 loudly when [0] > 0. */
+int lseg_check_range(lseg_handle h, uint64_t* host_out4, void* stream);
 int lseg_get_profile(lseg_handle h, const char* family, double* total_ms, int64_t* launches,
                      double* flops_per_launch);
 

@@ -104,6 +104,15 @@ int lseg_get_intermediate(lseg_handle h, const char* name, float* dev_out, size_
     return h->e->get_intermediate(name, dev_out, cap, n, (hipStream_t)stream);
 }
 
+int lseg_check_range(lseg_handle h, uint64_t* out4, void* stream) {
+    GUARD(h);
+    if (!out4) return set_error(LSEG_ERR_INVALID, "NULL argument");
+    unsigned long long tmp[4] = {0, 0, 0, 0};
+    const int r = h->e->check_range(tmp, (hipStream_t)stream);
+    for (int i = 0; i < 4; ++i) out4[i] = tmp[i];
+    return r;
+}
+
 int lseg_set_profiling(lseg_handle h, int enabled) {
     GUARD(h);
     // 1 = the whole forward + the MLP fc1 GEMM (rounds 1-2); otherwise a mask, bit f = family f in lseg_get_profile's order

@@ -731,6 +731,48 @@ __global__ void convert_kernel(const void* in, int in_dtype, void* out, int out_
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         store_from_f32(out, i, out_dtype, load_as_f32(in, i, in_dtype));
 }
+// Range scan of a 16-bit buffer (Engine::check_range): counts non-finite values and finite values with |x| >= 2^15, tracks the largest
+// finite |x|.  16 bytes per lane; one atomic per workgroup and counter.
+__global__ void range16_kernel(const uint16_t* p, size_t n, int dtype, unsigned long long* out) {
+    unsigned long long bad = 0, near = 0;
+    float mx = 0.f;
+    const size_t n8 = n >> 3;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8 + (n & 7); i += (size_t)gridDim.x * blockDim.x) {
+        uint16_t v[8];
+        int cnt = 8;
+        if (i < n8) {
+            *reinterpret_cast<uint4*>(v) = *reinterpret_cast<const uint4*>(p + i * 8);
+        } else {
+            cnt = 1;
+            v[0] = p[n8 * 8 + (i - n8)];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j >= cnt) break;
+            const float f = dtype == DT_F16 ? f16_to_f32(v[j]) : bf16_to_f32(v[j]);
+            const float a = fabsf(f);
+            if (!(a <= 3.0e38f)) ++bad;                 // inf or NaN
+            else {
+                if (a >= 32768.f) ++near;
+                mx = fmaxf(mx, a);
+            }
+        }
+    }
+    __shared__ unsigned long long sb[2];
+    __shared__ unsigned int sm;
+    if (threadIdx.x == 0) { sb[0] = sb[1] = 0; sm = 0; }
+    __syncthreads();
+    if (bad) atomicAdd(&sb[0], bad);
+    if (near) atomicAdd(&sb[1], near);
+    atomicMax(&sm, __float_as_uint(mx));                // non-negative floats order like their bit patterns
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (sb[0]) atomicAdd(&out[0], sb[0]);
+        if (sb[1]) atomicAdd(&out[1], sb[1]);
+        atomicMax(&out[2], (unsigned long long)sm);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&out[3], (unsigned long long)n);
+}
 // 2-D convert with a padded output row stride: in [R, C] -> out [R, ld] (columns >= C untouched)
 __global__ void convert2d_kernel(const void* in, int in_dtype, void* out, int out_dtype, int R, int C, int ld) {
     const size_t n = (size_t)R * C;
@@ -2082,6 +2124,15 @@ int launch_text_l2norm(const void* t, void* out, int K, int C, hipStream_t st) {
     CHECK_LAUNCH();
     return 0;
 }
+int launch_range16(const void* p, size_t n, int dtype, unsigned long long* out4, hipStream_t st) {
+    if (!n) return 0;
+    const size_t work = (n >> 3) + (n & 7);
+    unsigned blocks = (unsigned)std::min<size_t>((work + 255) / 256, 4096);
+    hipLaunchKernelGGL(range16_kernel, dim3(blocks), dim3(256), 0, st, (const uint16_t*)p, n, dtype, out4);
+    LSEG_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int launch_convert(const void* in, int in_dtype, void* out, int out_dtype, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(convert_kernel, dim3(grid_for(n)), dim3(256), 0, st, in, in_dtype, out, out_dtype, n);
     CHECK_LAUNCH();

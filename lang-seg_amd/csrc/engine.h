@@ -62,6 +62,8 @@ public:
     int forward_stats(const int64_t* target, int ignore_index, int64_t* counts, double* nll, hipStream_t st);
     int get_intermediate(const char* name, float* out, size_t cap, size_t* n, hipStream_t st);
     int get_profile(const char* family, double* ms, int64_t* launches, double* flops);
+    // 16-bit range check of the image tower (fp16 operands saturate at 65504): scans every 16-bit activation buffer of the plan
+    int check_range(unsigned long long* host_out4, hipStream_t st);
     // ---- training step (train.hip; modules/lsegmentation_module.py:66-81) ----
     int set_train(bool on);
     int bind_grad(const char* key, float* dev_ptr);
@@ -120,6 +122,8 @@ private:
 
     std::map<std::string, BoundParam> bound_;
     std::vector<void*> allocs_;
+    std::vector<std::pair<const uint16_t*, size_t>> act16_;     // every 16-bit image-tower activation buffer (check_range)
+    unsigned long long* range_out_ = nullptr;
     bool finalized_ = false, inited_ = false;
     int last_B_ = 0, last_kout_ = 0;
     const float* last_low_ = nullptr;

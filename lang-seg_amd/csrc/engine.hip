@@ -71,6 +71,7 @@ void* Engine::dalloc(size_t bytes, bool zero) {
     do {                                                                                         \
         ALLOC(ptr, uint16_t, (size_t)(count) * (strict_ ? 2 : 1));                                \
         if (strict_) plane_[ptr] = (size_t)(count);                                              \
+        act16_.emplace_back(ptr, (size_t)(count) * (strict_ ? 2 : 1));                            \
     } while (0)
 
 int Engine::init() {
@@ -140,6 +141,8 @@ int Engine::init() {
     ALLOC(gpad_, float, B * (lh_[0] + 2) * (lw_[0] + 2) * c.out_c);
     // commuted correlation: g in fp16, the label planes R = T g^T at the quarter resolution, cell dot products, per-pixel scale
     ALLOC(g16pad_, uint16_t, B * (lh_[0] + 2) * (lw_[0] + 2) * c.out_c);
+    act16_.emplace_back(g16pad_, B * (lh_[0] + 2) * (lw_[0] + 2) * c.out_c);       // fp16 whatever the operand type: the correlation's operand
+    ALLOC(range_out_, unsigned long long, 4);
     ALLOC(rpl_, float, B * c.max_labels * (lh_[0] + 2) * (lw_[0] + 2));
     ALLOC(gram_, float, B * lh_[0] * lw_[0] * 5);
     ALLOC(nscale_, float, B * hw1);
@@ -648,6 +651,22 @@ int Engine::flush_events() {
     }
     for (auto e : ev_pool_) ev_free_.push_back(e);       // recycled, not destroyed
     ev_pool_.clear();
+    return 0;
+}
+
+// Range check of the 16-bit image-tower activations of the forwards run so far (every buffer ALLOC16 made + the fp16 head map):
+// out[0] = non-finite values (inf / NaN: an fp16 operand tower overflows at 65504), out[1] = finite values with |x| >= 2^15 (within a
+// factor 2 of the fp16 limit), out[2] = largest finite |x| as fp32 bits, out[3] = elements scanned.  Synchronises `st`.
+int Engine::check_range(unsigned long long* host_out4, hipStream_t st) {
+    if (!inited_) return set_error(LSEG_ERR_STATE, "engine not initialised");
+    LSEG_HIP_TRY(hipMemsetAsync(range_out_, 0, 4 * sizeof(unsigned long long), st));
+    const int dt = img_dt_ == DT_BF16 ? DT_BF16 : DT_F16;
+    for (auto& b : act16_) {
+        const int d = b.first == g16pad_ ? DT_F16 : dt;
+        TRY(launch_range16(b.first, b.second, d, range_out_, st));
+    }
+    LSEG_HIP_TRY(hipMemcpyAsync(host_out4, range_out_, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    LSEG_HIP_TRY(hipStreamSynchronize(st));
     return 0;
 }
 

@@ -34,6 +34,7 @@ int launch_text_embed(const int64_t* tok, const float* emb, const float* pos, vo
 int launch_text_pool(const void* x, const int* eot, void* pooled, int K, int L, int W, hipStream_t st);
 int launch_text_l2norm(const void* t, void* out, int K, int C, hipStream_t st);
 int launch_convert(const void* in, int in_dtype, void* out, int out_dtype, size_t n, hipStream_t st);
+int launch_range16(const void* p, size_t n, int dtype, unsigned long long* out4, hipStream_t st);
 int launch_convert2d(const void* in, int in_dtype, void* out, int out_dtype, int R, int C, int ld, hipStream_t st);
 int launch_transpose_convert(const void* in, int in_dtype, void* out, int out_dtype, int R, int C, hipStream_t st);
 int launch_pack_conv3x3(const float* w, const float* bn_w, const float* bn_b, const float* bn_m, const float* bn_v,

@@ -62,6 +62,7 @@ SIGNATURES = {
     "lseg_get_intermediate": (_i, [_vp, C.c_char_p, _vp, _sz, C.POINTER(_sz), _vp]),
     "lseg_set_debug": (_i, [_vp, _i]),
     "lseg_set_profiling": (_i, [_vp, _i]),
+    "lseg_check_range": (_i, [_vp, C.POINTER(C.c_uint64), _vp]),
     "lseg_get_profile": (_i, [_vp, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "lseg_set_train": (_i, [_vp, _i]),
     "lseg_bind_grad": (_i, [_vp, C.c_char_p, _vp]),

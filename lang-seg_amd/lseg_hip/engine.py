@@ -352,6 +352,15 @@ class HipEngine:
             raise ValueError(f"intermediate '{name}' has {n.value} elements, expected {out.numel()} {tuple(shape)}")
         return out
 
+    def check_range(self) -> dict:
+        """16-bit range check of the image tower (lseg_check_range): non-finite values, values within a factor 2 of the fp16 limit and
+        the largest finite magnitude over every 16-bit activation buffer, as the forwards so far left them.  Synchronises."""
+        import struct
+        out = (C.c_uint64 * 4)()
+        _lib.check(self.lib.lseg_check_range(self._h, out, C.c_void_p(_stream_ptr(self.device))))
+        return {"nonfinite": int(out[0]), "near_fp16_limit": int(out[1]),
+                "max_abs": struct.unpack("f", struct.pack("I", int(out[2]) & 0xffffffff))[0], "scanned": int(out[3])}
+
     PROFILE_FAMILIES = ("forward", "mlp_fc1", "mlp_fc2", "attn_proj", "attn_qkv", "attention", "layernorm")
 
     def set_profiling(self, enabled):

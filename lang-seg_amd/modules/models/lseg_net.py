@@ -358,7 +358,25 @@ class LSeg(BaseModel):
             eng.set_train(False)
         self._set_tokens(eng, text, labelset)
         self._last_engine = eng
-        return eng.forward(x.float(), want_logits=_want_logits)
+        out = eng.forward(x.float(), want_logits=_want_logits)
+        mode = getattr(self, "overflow_fallback", True)
+        if eng.image_dtype == "fp16" and mode and (mode == "always" or getattr(eng, "_range_stamp", None) != eng._stamp):
+            # fp16 MFMA operands saturate at 65504 where the reference's fp32 tower cannot (lseg_vit.py:196-197).  Checked on the first
+            # forward after every (re)pack of the weights ("always": on every forward, one synchronising ~1 ms scan): any inf / NaN in
+            # a 16-bit activation buffer -> this network switches to bf16 operands (same speed, fp32 range), LOUDLY, and re-runs.
+            eng._range_stamp = eng._stamp
+            r = eng.check_range()
+            if r["nonfinite"] > 0:
+                warnings.warn(f"LSeg: {r['nonfinite']} non-finite values in the fp16 image tower's activations (largest finite |x| "
+                              f"{r['max_abs']:.3g}; fp16 saturates at 65504): this network's activations leave the fp16 range -- "
+                              "falling back to bf16 MFMA operands for all further forwards (image_dtype='bf16')", RuntimeWarning, stacklevel=2)
+                self.image_dtype = "bf16"
+                for key in [k_ for k_ in self._engines if not k_[3]]:
+                    self._engines.pop(key).close()
+                self._last_engine = None
+                return self.forward(x, labelset, _want_logits)
+            self.last_range_check = r
+        return out
 
 
 class LSegNet(LSeg):

@@ -138,9 +138,32 @@ def save_full_case(name, spec, gd):
     print(name, tuple(out.shape), float(out.abs().mean()), "median margin", float((top2[:, 0] - top2[:, 1]).median()))
 
 
+def save_full480_case(name, spec, gd):
+    """The reference's FULL-RESOLUTION decision surface (lseg_net.py:203: the x2 bilinear runs before anyone takes an arg-max):
+    arg-max label and top-2 margin of every one of the 480 x 480 output pixels, + the top-2 values, as a small side fixture
+    `<name>_out480.pt` (the sub-sampled fixture above is left byte-identical)."""
+    cfg, sd, x, text, out, taps, acts = run_ref_case(spec)
+    top2, top2_idx = out.topk(2, dim=1)                 # [1,2,480,480]
+    K = spec[4]
+    torch.save({"spec": spec, "tokens": text.clone(),
+                "argmax": top2_idx[:, 0].to(torch.uint8 if K <= 256 else torch.int16).clone(),
+                "second": top2_idx[:, 1].to(torch.uint8 if K <= 256 else torch.int16).clone(),
+                "margin": (top2[:, 0] - top2[:, 1]).to(torch.float16).clone(),
+                "top1_val": top2[:, 0].to(torch.float16).clone(),
+                "absmax": float(out.abs().max())},
+               os.path.join(gd, name + "_out480.pt"))
+    print(name + "_out480", tuple(out.shape), "median margin", float((top2[:, 0] - top2[:, 1]).median()))
+
+
 def main():
     gd = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gd, exist_ok=True)
+    if "--full480" in sys.argv[1:]:
+        for name, spec in REF_FULL_CASES.items():
+            if "--only" in sys.argv[1:] and name not in sys.argv[1:]:
+                continue
+            save_full480_case(name, spec, gd)
+        return
     if "--full" in sys.argv[1:]:
         for name, spec in REF_FULL_CASES.items():
             if "--only" in sys.argv[1:] and name not in sys.argv[1:]:

@@ -1,5 +1,7 @@
 """Stand-in for timm==0.4.12 (requirements.txt:102 of the reference): only what modules/models/lseg_vit.py touches.
 timm/models/vision_transformer.py semantics restated from SURVEY.md App. A.1.  TEST INFRASTRUCTURE."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -62,9 +64,18 @@ class Block(nn.Module):
         self.norm2 = nn.LayerNorm(dim, eps=1e-6)
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
-    def forward(self, x):
+    def _body(self, x):
         x = x + self.drop_path(self.attn(self.norm1(x)))
         return x + self.drop_path(self.mlp(self.norm2(x)))
+
+    def forward(self, x):
+        # LSEG_STUB_CHECKPOINT=1 (oracle/make_ref_train_golden.py --full8: per-GPU batch 8 at 480 x 480 needs ~50 GB of saved fp32
+        # activations otherwise): re-run the block in the backward instead of saving its inside.  Same arithmetic, same gradients;
+        # the module's forward hooks (the reference's activation taps) still see the block output.
+        if os.environ.get("LSEG_STUB_CHECKPOINT") == "1" and torch.is_grad_enabled() and x.requires_grad:
+            from torch.utils.checkpoint import checkpoint
+            return checkpoint(self._body, x, use_reentrant=False)
+        return self._body(x)
 
 
 class VisionTransformer(nn.Module):

@@ -419,6 +419,133 @@ def test_engine_matches_the_reference_at_the_baseline_configs(name, dtype, golde
     assert (tf - tr).abs().max().item() <= 4e-3
 
 
+# absolute bars of the 480 x 480 mask test (the "ties" statement above scales with the measured error; these do not): fraction of the
+# output pixels whose label may differ from the reference's, and the largest reference top-2 margin at such a pixel.  Measured at
+# 240 x 240 in round 3: K = 150 bf16 1.62 % / 0.099, fp16 0.27 % / 0.0092, strict 0.16 % / 0.0024; K = 1000 10.8 % / 0.101, 1.85 % / 0.013,
+# 0.91 % / 0.0039 (1000 synthetic prompts on a random text tower: median top-2 margin 0.055)
+MASK480_CAPS = {150: {"bf16": (0.025, 0.15), "fp16": (0.005, 0.02), "strict": (0.003, 0.006)},
+                1000: {"bf16": (0.14, 0.15), "fp16": (0.026, 0.025), "strict": (0.013, 0.008)}}
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "strict"])
+@pytest.mark.parametrize("name", _REF_FULL)
+def test_engine_masks_match_the_reference_at_480x480(name, dtype, golden_dir):
+    """The reference upsamples BEFORE anyone takes an arg-max (lseg_net.py:203): the decision surface that counts is the 480 x 480 one.
+    `<name>_out480.pt` holds the reference's own label and top-2 margin for every output pixel (oracle/make_ref_golden.py --full480).
+    Held to it: the arg-max of the engine's materialised [1,K,480,480] logits, and (K <= 256) the uint8 mask the engine produces WITHOUT
+    the logits, through the x2 bilinear on the fly (lseg_forward masks) -- which must equal the arg-max of its own logits except at
+    exact fp32 ties."""
+    path = os.path.join(golden_dir, name + "_out480.pt")
+    if not os.path.exists(path):
+        pytest.skip("no 480x480 side fixture")
+    g = torch.load(path)
+    bb, H, W, B, K, seed, arch, depth = g["spec"]
+    cfg = get_config(bb, arch_option=arch, block_depth=depth, activation="lrelu")
+    eng = HipEngine(cfg, H, W, max_batch=B, max_labels=K, image_dtype=dtype)
+    eng.load_state_dict(synthetic_state_dict(cfg, seed=seed))
+    eng.set_tokens(g["tokens"])
+    x = synthetic_images(B, H, W, seed=seed).cuda()
+    out = eng.forward(x)
+    torch.cuda.synchronize()
+    ref_am, ref_margin = g["argmax"].long().cuda(), g["margin"].float().cuda()
+    am = out.argmax(1)
+    # logit error at the reference's decision: the engine's value at the reference's best label vs the reference's own
+    err = (out.gather(1, ref_am.unsqueeze(1)).squeeze(1) - g["top1_val"].float().cuda()).abs().max().item()
+    mism = am != ref_am
+    frac = mism.float().mean().item()
+    worst = ref_margin[mism].max().item() if mism.any() else 0.0
+    cap_frac, cap_margin = MASK480_CAPS[K][dtype]
+    print(f"{name}[{dtype}] 480x480: argmax mismatch fraction {frac:.5f} (cap {cap_frac}), max reference margin at a mismatch {worst:.4f} "
+          f"(cap {cap_margin}), max|dlogit| at the reference's label {err:.4f}")
+    out_dir = os.path.join(os.path.dirname(golden_dir), "..", "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "parity_table.txt"), "a") as f:
+            f.write(f"{name} {dtype} 480x480: max|dlogit| {err:.5f}  argmax mismatch fraction {frac:.6f}  max reference margin at a mismatch {worst:.5f}\n")
+    assert err <= REF_TOL[dtype], (name, dtype, err)
+    assert worst <= 2 * err + 1e-6 and worst <= cap_margin and frac <= cap_frac, (name, dtype, frac, worst, err)
+    if K <= 256:
+        only = eng.forward(x, want_logits=False, want_argmax=True)
+        top2 = out.topk(2, dim=1).values
+        decisive = (top2[:, 0] - top2[:, 1]) > 1e-6
+        assert torch.equal(only.long()[decisive], am[decisive])
+        m2 = only.long() != ref_am
+        assert m2.float().mean().item() <= cap_frac and (ref_margin[m2].max().item() if m2.any() else 0.0) <= cap_margin
+    eng.close()
+
+
+def _outlier_state_dict(cfg, seed, level):
+    """A synthetic state dict with the statistics real ViT / DPT checkpoints are known for and N(0, 0.02)-style random weights are not:
+    a few residual-stream OUTLIER CHANNELS carried by mlp.fc2 / attn.proj rows (x level), LayerNorm gains up to 10 on them, BatchNorm
+    layers with small running variances (large effective scales).  level 1e2: fp16 must survive."""
+    sd = synthetic_state_dict(cfg, seed=seed)
+    g = torch.Generator().manual_seed(seed + 99)
+    ch = torch.randperm(cfg.dim, generator=g)[:3]
+    for k in sd:
+        if k.endswith(("mlp.fc2.weight", "attn.proj.weight")) and k.startswith("pretrained.model.blocks."):
+            sd[k][ch] *= level ** 0.5
+        if k.endswith(("norm1.weight", "norm2.weight")) and k.startswith("pretrained.model.blocks."):
+            sd[k][ch] = 10.0
+        if k.endswith("mlp.fc1.weight") and k.startswith("pretrained.model.blocks."):
+            sd[k][:, ch] *= level ** 0.5
+        if k.endswith("running_var") and ".bn1." in k:
+            sd[k][::17] *= 0.01                       # x10 effective scale on every 17th channel
+    return sd
+
+
+def test_fp16_range_check_and_loud_bf16_fallback():
+    """VERDICT r3 item 3a / ADVICE: the inference default is fp16 MFMA operands, whose range (65504) the reference's fp32 tower does
+    not have.  (1) lseg_check_range counts non-finite 16-bit activations; (2) with outlier statistics at the 1e2 level an fp16 engine
+    stays finite and close to the fp32 oracle; (3) at a level that overflows fp16 the check reports it, a bf16 engine stays finite,
+    and the drop-in network falls back to bf16 LOUDLY (RuntimeWarning) and returns the bf16 result instead of inf / NaN masks."""
+    import warnings
+    from modules.models.lseg_net import LSegNet
+    cfg = get_config("tiny16")
+    labels = read_labels(MG.LABELS)[:5]
+    tok = synthetic_tokens(labels, cfg.text.vocab, cfg.text.ctx)
+    x = synthetic_images(2, 64, 64, seed=3)
+
+    def run(sd, dtype):
+        eng = HipEngine(cfg, 64, 64, max_batch=2, max_labels=5, image_dtype=dtype)
+        eng.load_state_dict(sd)
+        eng.set_tokens(tok)
+        out = eng.forward(x.cuda()).cpu()
+        r = eng.check_range()
+        eng.close()
+        return out, r
+
+    sd = _outlier_state_dict(cfg, 5, 1e2)
+    out16, r16 = run(sd, "fp16")
+    with torch.no_grad():
+        ref = lseg_forward(sd, x, tok, cfg)
+    print("outliers 1e2: fp16 range", r16, "max|dlogit| vs oracle", (out16 - ref).abs().max().item())
+    assert r16["nonfinite"] == 0 and r16["scanned"] > 1e5 and 50.0 < r16["max_abs"] < 65504.0
+    assert torch.isfinite(out16).all() and (out16 - ref).abs().max().item() <= 0.30
+
+    # one MLP whose hidden activations leave the fp16 range (|z| ~ 3e5 > 65504; bf16 and fp32 hold it, the LayerNorm behind it rescales)
+    sd = _outlier_state_dict(cfg, 5, 1e2)
+    sd["pretrained.model.blocks.1.mlp.fc1.weight"] *= 3e5
+    out16, r16 = run(sd, "fp16")
+    outbf, rbf = run(sd, "bf16")
+    print("overflowing MLP: fp16 range", r16, "bf16 range", rbf)
+    assert r16["nonfinite"] > 0                                  # the fp16 tower overflowed and the check saw it
+    assert rbf["nonfinite"] == 0 and torch.isfinite(outbf).all() and rbf["max_abs"] > 65504.0
+    net = LSegNet(labels=labels, backbone="tiny16", features=64, arch_option=0, block_depth=0, activation="lrelu", image_dtype="fp16")
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        with torch.no_grad():
+            got = net(x.cuda()).cpu()
+    assert any(issubclass(m.category, RuntimeWarning) and "falling back to bf16" in str(m.message) for m in w), [str(m.message) for m in w]
+    assert net.image_dtype == "bf16" and torch.isfinite(got).all()
+    assert (got - outbf).abs().max().item() <= 1e-3               # the bf16 engine's result, not a patched-up fp16 one
+    with warnings.catch_warnings(record=True) as w2:              # and it stays on bf16 without further warnings
+        warnings.simplefilter("always")
+        with torch.no_grad():
+            again = net(x.cuda()).cpu()
+    assert not any("falling back" in str(m.message) for m in w2) and torch.equal(again, got)
+
+
 def test_masks_and_metrics_without_the_full_resolution_logits():
     """lseg_forward(logits = NULL, masks) and lseg_op_seg_stats_lowres read the low-resolution logits through the x2 bilinear on the
     fly: same masks as argmax of the materialised output (except exact fp32 ties), same integer metric counts, same loss."""

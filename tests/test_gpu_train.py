@@ -160,6 +160,9 @@ def test_training_step_loss_and_gradients_match_the_oracle(bb, H, W, B, K, seed)
     assert not torch.equal(sd_dev[k0].cpu(), sd[k0])
 
 
+COS_MEDIAN, COS_WORST = 0.90, 0.30      # provisional until the first measured run
+
+
 def _sample_index(numel, n=64):                       # == oracle/make_ref_train_golden.sample_index
     n = min(n, numel)
     return (torch.arange(n, dtype=torch.int64) * (numel - 1)) // max(n - 1, 1)
@@ -181,7 +184,7 @@ def test_training_step_matches_fixtures_made_by_reference_autograd(name):
     assert abs(loss.item() - g["loss"]) <= 1e-2 * abs(g["loss"]), (loss.item(), g["loss"])
     names = {n for n in g["grads"] if not n.startswith("clip_pretrained.")}
     assert set(eng.grads) == names, sorted(set(eng.grads) ^ names)[:10]
-    nerr, herr, serr, sumerr = {}, {}, {}, {}
+    nerr, herr, serr, sumerr, cosv = {}, {}, {}, {}, {}
     for n in sorted(names):
         r = g["grads"][n]
         mine = eng.grads[n].float().cpu()
@@ -191,8 +194,15 @@ def test_training_step_matches_fixtures_made_by_reference_autograd(name):
         herr[n] = (mine.flatten()[:16] - r["head"]).abs().max().item() / scale
         if "sample" in r:
             sscale = max(float(r["sample"].abs().max()), rms, 1e-20)
-            serr[n] = (mine.flatten()[_sample_index(mine.numel())] - r["sample"]).abs().max().item() / sscale
+            got = mine.flatten()[_sample_index(mine.numel(), r["sample"].numel())]
+            serr[n] = (got - r["sample"]).abs().max().item() / sscale
             sumerr[n] = abs(float(mine.double().sum()) - r["sum"]) / max(r["norm"] * mine.numel() ** 0.5, 1e-20)
+            # direction: cosine between the engine's and the reference's gradient over the stored elements (first 16 + the strided
+            # sample: 80 per tensor in the B = 1 / 2 fixtures, 1040 in the B = 8 one) -- a permuted or mis-signed gradient with the
+            # right norm has cosine ~ 0
+            a, b = torch.cat([mine.flatten()[:16], got]).double(), torch.cat([r["head"], r["sample"]]).double()
+            if float(b.norm()) > 0 and b.numel() >= 32:
+                cosv[n] = float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-300))
     med = lambda d: sorted(d.values())[len(d) // 2]
     wn = sorted(nerr.items(), key=lambda kv: -kv[1])[:5]
     wh = sorted(herr.items(), key=lambda kv: -kv[1])[:5]
@@ -201,6 +211,9 @@ def test_training_step_matches_fixtures_made_by_reference_autograd(name):
             f"{[(k, round(v, 4)) for k, v in wn[:3]]}; first-16 error median {med(herr):.3f} worst {wh[0][1]:.3f}; "
             f"strided-64 error median {med(serr) if serr else -1:.3f} worst {ws[0][1] if ws else -1:.3f}; "
             f"sum error worst {max(sumerr.values()) if sumerr else -1:.4f}")
+    if cosv:
+        wc = sorted(cosv.items(), key=lambda kv: kv[1])[:3]
+        line += f"; cosine over the stored elements median {med(cosv):.4f} worst {[(k, round(v, 3)) for k, v in wc]}"
     print(line)
     out_dir = os.path.join(os.path.dirname(GOLD), "..", "gpurun_out")
     if os.path.isdir(out_dir):
@@ -213,6 +226,9 @@ def test_training_step_matches_fixtures_made_by_reference_autograd(name):
     assert wn[0][1] <= 0.10 and med(nerr) <= (0.02 if full else 0.05) and wh[0][1] <= 1.5 and med(herr) <= 0.35, (wn, wh)
     if serr:
         assert ws[0][1] <= 1.5 and med(serr) <= 0.35 and max(sumerr.values()) <= 0.25, (ws, max(sumerr.values()))
+    if cosv:
+        # per-tensor direction next to the norm bars.  (bars set from the measured run, profiles/r04_train_parity_table.txt)
+        assert med(cosv) >= COS_MEDIAN and min(cosv.values()) >= COS_WORST, (med(cosv), sorted(cosv.items(), key=lambda kv: kv[1])[:5])
 
 
 def test_fused_sgd_matches_torch_sgd():
