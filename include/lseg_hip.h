@@ -218,6 +218,12 @@ int lseg_op_upsample2x_nhwc(const void* d_in, void* d_out, int B, int H, int W, 
 /* bilinear x2, align_corners=True, NCHW fp32 planes: in [P,H,W] -> out [P,2H,2W]
  * (scratch.output_conv, lseg_net.py:203,219-221) */
 int lseg_op_upsample2x_planes(const float* d_in, float* d_out, int P, int H, int W, void* stream);
+/* The tail of the commuted head (DESIGN.md par. 3.4) in one pass: label planes R at the quarter resolution, d_in_padded fp32 [B*K, H+2, W+2]
+ * (1-pixel border), per-pixel scale s/||u|| d_scale fp32 [B, 2H, 2W] -> logits d_out fp32 [B, K, 4H, 4W] =
+ * output_conv(fp16(scale * bilinear_x2(R))) (lseg_net.py:194-196 rounding, :203 upsample).  two_stage != 0 runs the two materialising
+ * kernels instead (d_low_scratch fp32 [B,K,2H,2W]): same bits. */
+int lseg_op_upsample4x_planes_scaled(const float* d_in_padded, const float* d_scale, float* d_out, int B, int K, int H, int W, int two_stage,
+                                     float* d_low_scratch, void* stream);
 /* pixel x text correlation (lseg_net.py:187-196): feat fp32 [M,C]; text fp16 [K,C]
  * (already L2-normalised); logits fp32 [B,K,P] with M = B*P.  Internally:
  * a = fp16(scale * fp16(feat/||feat||)); logits = fp16(a @ text^T). */

@@ -256,6 +256,17 @@ int lseg_op_upsample2x_planes(const float* in, float* out, int P, int H, int W, 
     return launch_upsample2x_planes(in, out, P, H, W, (hipStream_t)stream);
 }
 
+int lseg_op_upsample4x_planes_scaled(const float* in_padded, const float* scale, float* out, int B, int K, int H, int W, int two_stage,
+                                     float* low_scratch, void* stream) {
+    int r = require_device(); if (r) return r;
+    if (!in_padded || !scale || !out || B < 1 || K < 1 || H < 2 || W < 2) return set_error(LSEG_ERR_INVALID, "upsample4x_planes_scaled: bad arguments");
+    if (!two_stage) return launch_upsample4x_planes_scaled(in_padded, scale, out, B * K, K, H, W, (hipStream_t)stream);
+    if (!low_scratch) return set_error(LSEG_ERR_INVALID, "upsample4x_planes_scaled: the two-stage form needs the [B,K,2H,2W] scratch");
+    r = launch_upsample2x_planes_scaled(in_padded, scale, low_scratch, B * K, K, H, W, (hipStream_t)stream);
+    if (r) return r;
+    return launch_upsample2x_planes(low_scratch, out, B * K, 2 * H, 2 * W, (hipStream_t)stream);
+}
+
 int lseg_op_correlation(const float* feat, const void* text_f16, float* logits, int B, int P, int C, int K,
                         float logit_scale, void* stream) {
     int r = require_device(); if (r) return r;

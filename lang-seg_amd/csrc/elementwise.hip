@@ -84,23 +84,51 @@ __global__ __launch_bounds__(256) void layernorm_reduce_kernel(float* __restrict
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const int nv = D >> 2;
+    // All loads of a round are in flight together: x + bias, then the slabs FOUR at a time (16 independent 16-byte loads per lane).  The
+    // round-3 form walked the slabs in a run-time loop inside the per-chunk loop -- ~20 dependent memory round trips per row, 10.7 us per
+    // launch at B = 1 where the data volume is worth 3.  Same sums in the same order (x + bias + slab 0 + slab 1 + ...): same bits.
     float4 v[MAXV];
+    int gi[MAXV];                                  // this lane's chunk index, clamped into the row (loads stay unconditional)
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) gi[i] = lane + 64 * i < nv ? lane + 64 * i : nv - 1;
+    {
+        float4 b[MAXV];
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            v[i] = reinterpret_cast<const float4*>(x + (size_t)row * D)[gi[i]];
+            b[i] = reinterpret_cast<const float4*>(bias)[gi[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) { v[i].x += b[i].x; v[i].y += b[i].y; v[i].z += b[i].z; v[i].w += b[i].w; }
+    }
+    for (int s0 = 0; s0 < nsplit; s0 += 4) {
+        float4 p[4][MAXV];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int sp = s0 + c < nsplit ? s0 + c : nsplit - 1;
+            const float4* src = reinterpret_cast<const float4*>(part + (size_t)sp * stride + (size_t)row * D);
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) p[c][i] = src[gi[i]];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool on = s0 + c < nsplit;               // wave-uniform
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                v[i].x += on ? p[c][i].x : 0.f; v[i].y += on ? p[c][i].y : 0.f;
+                v[i].z += on ? p[c][i].z : 0.f; v[i].w += on ? p[c][i].w : 0.f;
+            }
+        }
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int g = lane + 64 * i;
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (g < nv) {
-            float4 a = reinterpret_cast<const float4*>(x + (size_t)row * D)[g];
-            const float4 b = reinterpret_cast<const float4*>(bias)[g];
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-            for (int sp = 0; sp < nsplit; ++sp) {
-                const float4 p = reinterpret_cast<const float4*>(part + (size_t)sp * stride + (size_t)row * D)[g];
-                a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
-            }
-            reinterpret_cast<float4*>(x + (size_t)row * D)[g] = a;
-            v[i] = a;
-            s += a.x + a.y + a.z + a.w;
+            reinterpret_cast<float4*>(x + (size_t)row * D)[g] = v[i];
+            s += v[i].x + v[i].y + v[i].z + v[i].w;
+        } else {
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     if (!gamma) return;
@@ -639,14 +667,22 @@ __global__ __launch_bounds__(256) void upsample2x_planes_scaled_kernel(const flo
 // The same followed by scratch.output_conv's x2 bilinear (lseg_net.py:203) in one pass: R [P, H+2, W+2] -> logits [P, 4H, 4W], the
 // (2H, 2W) logits only ever exist as a band in LDS.  Bit-identical to upsample2x_planes_scaled + upsample2x_planes (bilerp).
 // A block = one plane x the output rows whose upper source row lies in a band of LB low rows.
+// LDS image of the low-resolution band: each row DE-INTERLEAVED -- even columns in the first half, odd columns in the second.  The
+// output pass reads, for output column group x4, the low columns {2 x4 - 1 .. 2 x4 + 2}: with plain rows consecutive lanes read floats
+// two apart (every ds_read_b32 a 2-way bank conflict: SQ_LDS_BANK_CONFLICT = 2.1e8 per launch in round 3); in this image consecutive
+// lanes read consecutive floats.  lofs(i) = offset of low column i inside a row.
+template <int DEINT>
+__device__ __forceinline__ int lofs(int i, int half) { return DEINT ? ((i & 1) ? half : 0) + (i >> 1) : i; }
+
+template <int LB, int DEINT>
 __global__ __launch_bounds__(256) void upsample4x_planes_scaled_kernel(const float* __restrict__ in, const float* __restrict__ scale,
                                                                        float* __restrict__ out, int P, int K, int H, int W) {
-    extern __shared__ float sm[];             // Rr [<= UPS_LB/2 + 4][W] | Lr [UPS_LB + 1][2W]
-    const int Hl = 2 * H, Wl = 2 * W, Ho = 2 * Hl, Wo = 2 * Wl, w4 = Wo / 4, wl4 = Wl / 4, bands = (Hl + UPS_LB - 1) / UPS_LB;
-    const int pl = blockIdx.x / bands, ya = (blockIdx.x - pl * bands) * UPS_LB;
-    const int yb = ya + UPS_LB < Hl - 1 ? ya + UPS_LB : Hl - 1;        // last low row read (the band's rows + the next one)
+    extern __shared__ float sm[];             // Rr [<= LB/2 + 4][W] | Lr [LB + 1][2W]
+    const int Hl = 2 * H, Wl = 2 * W, Ho = 2 * Hl, Wo = 2 * Wl, w4 = Wo / 4, wl4 = Wl / 4, bands = (Hl + LB - 1) / LB;
+    const int pl = blockIdx.x / bands, ya = (blockIdx.x - pl * bands) * LB;
+    const int yb = ya + LB < Hl - 1 ? ya + LB : Hl - 1;        // last low row read (the band's rows + the next one)
     float* Rr = sm;
-    float* Lr = sm + (UPS_LB / 2 + 4) * W;
+    float* Lr = sm + (LB / 2 + 4) * W;
     const float ry1 = (float)(H - 1) / (float)(Hl - 1), rx1 = (float)(W - 1) / (float)(Wl - 1);
     const int r_lo = ups_stage_r(in, Rr, pl, H, W, ry1, ya, yb);
     __syncthreads();
@@ -660,7 +696,12 @@ __global__ __launch_bounds__(256) void upsample4x_planes_scaled_kernel(const flo
             for (int Y = ya + sub; Y <= yb; Y += nsub) {
                 float o[4];
                 ups_low4(Rr, sc, H, W, ry1, r_lo, Y, x4, t, o);
-                *reinterpret_cast<float4*>(Lr + (Y - ya) * Wl + x4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+                if (DEINT) {
+                    *reinterpret_cast<float2*>(Lr + (Y - ya) * Wl + x4 * 2) = make_float2(o[0], o[2]);
+                    *reinterpret_cast<float2*>(Lr + (Y - ya) * Wl + W + x4 * 2) = make_float2(o[1], o[3]);
+                } else {
+                    *reinterpret_cast<float4*>(Lr + (Y - ya) * Wl + x4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+                }
             }
         }
     }
@@ -671,12 +712,15 @@ __global__ __launch_bounds__(256) void upsample4x_planes_scaled_kernel(const flo
     while (yo_first > 0 && (int)(ry * (float)(yo_first - 1)) >= ya) --yo_first;
     while ((int)(ry * (float)yo_first) < ya) ++yo_first;
     int yo_end = yo_first;
-    while (yo_end < Ho && (int)(ry * (float)yo_end) < ya + UPS_LB) ++yo_end;
+    while (yo_end < Ho && (int)(ry * (float)yo_end) < ya + LB) ++yo_end;
     const int nsub = w4 < 256 ? 256 / w4 : 1;
     for (int x4 = threadIdx.x % (w4 < 256 ? w4 : 256); x4 < w4; x4 += 256) {
         const int sub = w4 < 256 ? threadIdx.x / w4 : 0;
         if (sub >= nsub) break;
         const ColTerms t = col_terms4(rx, x4, Wl);
+        int a0[4], a1[4];                           // LDS offsets of the two source columns of each output column (loop invariant)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a0[e] = lofs<DEINT>(t.x0[e], W); a1[e] = lofs<DEINT>(t.x1[e], W); }
         for (int yo = yo_first + sub; yo < yo_end; yo += nsub) {
             int y0, y1;
             float ly;
@@ -685,7 +729,7 @@ __global__ __launch_bounds__(256) void upsample4x_planes_scaled_kernel(const flo
             const float* q1 = Lr + (y1 - ya) * Wl;
             float o[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = bilerp(q0[t.x0[e]], q0[t.x1[e]], q1[t.x0[e]], q1[t.x1[e]], t.lx[e], ly);
+            for (int e = 0; e < 4; ++e) o[e] = bilerp(q0[a0[e]], q0[a1[e]], q1[a0[e]], q1[a1[e]], t.lx[e], ly);
             const f32x4_t ov = {o[0], o[1], o[2], o[3]};     // written once, never re-read by the engine
             __builtin_nontemporal_store(ov, reinterpret_cast<f32x4_t*>(out + ((size_t)pl * Ho + yo) * Wo) + x4);
         }
@@ -2507,9 +2551,15 @@ int launch_upsample2x_planes_scaled(const float* in_padded, const float* scale, 
 // R planes -> the full-resolution logits in one pass (x2 with the per-pixel scale and fp16 rounding, then output_conv's x2)
 int launch_upsample4x_planes_scaled(const float* in_padded, const float* scale, float* out, int P, int K, int H, int W, hipStream_t st) {
     if (W % 2 != 0) return set_error(LSEG_ERR_UNSUPPORTED, "scaled upsample: W=%d must be even", W);
-    const int bands = (2 * H + UPS_LB - 1) / UPS_LB;
-    const size_t lds = ((size_t)(UPS_LB / 2 + 4) * W + (size_t)(UPS_LB + 1) * 2 * W) * sizeof(float);
-    hipLaunchKernelGGL(upsample4x_planes_scaled_kernel, dim3((unsigned)P * bands), dim3(256), lds, st, in_padded, scale, out, P, K, H, W);
+    static const int variant = getenv("LSEG_UPS4_VARIANT") ? atoi(getenv("LSEG_UPS4_VARIANT")) : 1;    // tools: 0 = round 3's plain LDS rows, band 8
+#define UPS4(LBV, DV)                                                                                                                      \
+    do {                                                                                                                                   \
+        const int bands = (2 * H + LBV - 1) / LBV;                                                                                         \
+        const size_t lds = ((size_t)(LBV / 2 + 4) * W + (size_t)(LBV + 1) * 2 * W) * sizeof(float);                                        \
+        hipLaunchKernelGGL((upsample4x_planes_scaled_kernel<LBV, DV>), dim3((unsigned)P * bands), dim3(256), lds, st, in_padded, scale, out, P, K, H, W); \
+    } while (0)
+    if (variant == 0) UPS4(8, 0); else if (variant == 2) UPS4(16, 1); else if (variant == 3) UPS4(16, 0); else UPS4(8, 1);
+#undef UPS4
     CHECK_LAUNCH();
     return 0;
 }

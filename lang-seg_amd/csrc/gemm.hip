@@ -755,7 +755,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
     // segment (16 columns) s of stage row r sits at s ^ gk(r), gk(r) = (r & 3) | ((r >> 3) & 1) << 2 -- the 8 rows a 32-lane read group
     // touches land on 8 different segments = all 64 banks.
     constexpr bool KMAJ = TAG == 2;
-    static_assert(!KMAJ || (((BM == 128 && BN == 128) || (BM == 256 && BN == 256)) && !CONV), "the K-major path is built for 128 x 128 and 256 x 256 tiles");
+    static_assert(!KMAJ || (BM == 128 && BN == 128 && !CONV), "the K-major path is built for 128 x 128 tiles");
     auto gsw = [](int r) { return (r & 3) | (((r >> 3) & 1) << 2); };
     // (the buffer / transpose-read builtins live in __device__ helpers: used directly inside a templated __global__ function they make
     // hipcc drop that instantiation's HOST stub without a diagnostic -- the library then fails to load with an undefined symbol)
@@ -1244,10 +1244,6 @@ int pick_tile(const GemmArgs& g, hipStream_t stream) {
         const double time_huge = (double)((t_huge + 255) / 256) * 4.0 / 1.12;
         const double time_mid = (double)((t_mid + 511) / 512) * 2.0;
         if (time_huge < time_mid) pick = 6;
-        // tools: A/B switch -- residual-epilogue GEMMs with a short K-loop (attention proj, K = 1024) on 128x128 tiles, where a
-        // second workgroup on the CU computes under the first one's fp32 read-modify-write epilogue
-        static const int res32_mid = getenv("LSEG_RES32_MID") ? atoi(getenv("LSEG_RES32_MID")) : 0;
-        if (res32_mid && EPI == EPI_RES32 && g.K <= res32_mid) pick = 2;
     }
     if (g.tile_hint == 2 || g.tile_hint == 6) pick = g.tile_hint;
     if (force) pick = force;
@@ -1310,10 +1306,6 @@ int dispatch(const GemmArgs& g, hipStream_t stream) {
         if (select_epi<T>(g) != EPI_PART32 || g.conv || (g.relu_in && !g.kconv_cin) || (g.kconv_cin && ((g.kconv_cin % 128) || g.ldw != g.kconv_cin)) || g.k_valid < 1 || g.k_valid > g.K || g.K - g.k_valid >= 64 ||
             (double)g.k_valid * g.lda * 2 >= 2.0e9 || (double)g.k_valid * g.ldw * 2 >= 2.0e9)
             return set_error(LSEG_ERR_UNSUPPORTED, "K-major GEMM: needs fp32 slab output (MAP_LINEAR, no bias / residual), N %% 128 == 0, operands < 2 GB");
-        if (g.tile_hint == 6 && (g.N % 256) == 0) {
-            if (g.relu_in) return launch_one<T, CfgHuge, false, true, EPI_PART32, 2>(g, stream);
-            return launch_one<T, CfgHuge, false, false, EPI_PART32, 2>(g, stream);
-        }
         if (g.relu_in) return launch_one<T, CfgMid, false, true, EPI_PART32, 2>(g, stream);
         return launch_one<T, CfgMid, false, false, EPI_PART32, 2>(g, stream);
     }
@@ -1377,8 +1369,7 @@ int launch_gemm(const GemmArgs& g_in, int ab_dtype, hipStream_t stream) {
     GemmArgs g = g_in;
     static const int dbg = getenv("LSEG_GEMM_DBG") ? atoi(getenv("LSEG_GEMM_DBG")) : 0;
     g.dbg = dbg;
-    static const int group_m = getenv("LSEG_GEMM_GROUP_M") ? atoi(getenv("LSEG_GEMM_GROUP_M")) : 8;   // tools: L2 locality sweeps
-    g.group_m = group_m > 0 ? group_m : 8;
+    g.group_m = 8;                            // row-blocks per rasterisation group (2 .. 32 measured within noise in round 2)
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return set_error(LSEG_ERR_INVALID, "gemm: empty problem %dx%dx%d", g.M, g.N, g.K);
     if ((g.C_pre || g.dgelu_pre) && !gemm_fuses_gelu(g, ab_dtype))
         return set_error(LSEG_ERR_UNSUPPORTED, "gemm: C_pre / dgelu_pre need the specialised 16-bit MAP_LINEAR epilogue (N %% 128 == 0, a bias, 16-byte rows)");

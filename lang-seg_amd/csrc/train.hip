@@ -430,32 +430,24 @@ int Engine::pick_split(int M, int N, int nk, GemmArgs& g) {
 }
 
 // ---- weight gradient straight from the row-major operands (gemm.hip "K-MAJOR operands") ------------------------------------------------
-// tile + split-K plan of a K-major wgrad [rows x cols] over nk K-steps: 128 x 128 tiles cut into ~2 work items per CU of >= 8 K-steps.
-// 256 x 256 tiles (LSEG_WGRAD_TILE=6; fewer LDS fragment reads per MFMA, one workgroup per CU) are built and parity-tested but measured
-// 2 % slower on the whole training step (45.4 vs 44.6 ms, profiles/r03_train_experiments.txt), so they stay a tool switch
+// split-K plan of a K-major wgrad [rows x cols] over nk K-steps: 128 x 128 tiles cut into ~2 work items per CU of >= 8 K-steps.
+// (256 x 256 K-major tiles were built, parity-tested and measured 2 % slower on the whole training step in round 3 --
+// profiles/r03_train_experiments.txt -- and removed in round 4.)
 static void plan_kmajor(GemmArgs& g, int rows, int cols, int nk, size_t ws_floats) {
-    static const int force = getenv("LSEG_WGRAD_TILE") ? atoi(getenv("LSEG_WGRAD_TILE")) : 0;      // tools: 6 = 256 x 256 tiles
-    auto plan = [&](long tiles, long target) {
-        long ns = (target + tiles - 1) / tiles;
-        if (ns > nk / 8) ns = nk / 8;
-        while (ns > 1 && (size_t)ns * rows * cols > ws_floats) --ns;
-        if (ns < 1) ns = 1;
-        const int steps = (int)((nk + ns - 1) / ns);
-        return std::pair<int, int>((int)((nk + steps - 1) / steps), steps);
-    };
-    const long t_mid = (long)((rows + 127) / 128) * (cols / 128), t_huge = (long)((rows + 255) / 256) * ((cols + 255) / 256);
-    auto pm = plan(t_mid, 512), ph = plan(t_huge, 512);
-    const bool can_huge = (cols % 256) == 0 && (g.kconv_cin == 0 || (g.kconv_cin % 256) == 0);      // a tile's columns stay inside one conv tap
-    const bool huge = force == 6 && can_huge && rows >= 192;
-    g.tile_hint = huge ? 6 : 2;
-    g.nsplit = huge ? ph.first : pm.first;
-    g.split_steps = huge ? ph.second : pm.second;
+    const long tiles = (long)((rows + 127) / 128) * (cols / 128);
+    long ns = (512 + tiles - 1) / tiles;
+    if (ns > nk / 8) ns = nk / 8;
+    while (ns > 1 && (size_t)ns * rows * cols > ws_floats) --ns;
+    if (ns < 1) ns = 1;
+    const int steps = (int)((nk + ns - 1) / ns);
+    g.tile_hint = 2;
+    g.nsplit = (int)((nk + steps - 1) / steps);
+    g.split_steps = steps;
     g.c_split_stride = (size_t)rows * cols;
 }
 
 bool wgrad_kmajor_ok(int rows_out, int cols_out, size_t ws_floats) {
-    static const bool off = getenv("LSEG_WGRAD_TRANSPOSE") != nullptr;           // tools: A/B switch back to the transposing path
-    return !off && rows_out >= 1 && (cols_out % 128) == 0 && (size_t)rows_out * cols_out <= ws_floats;
+    return rows_out >= 1 && (cols_out % 128) == 0 && (size_t)rows_out * cols_out <= ws_floats;
 }
 int launch_wgrad_kmajor(const void* dy, int ldy, const void* x, int ldx, int M, int rows_out, int cols_out, float* dw, int accumulate,
                         float* ws, size_t ws_floats, int ab_dtype, hipStream_t st) {

@@ -85,6 +85,7 @@ SIGNATURES = {
     "lseg_op_conv3x3": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "lseg_op_upsample2x_nhwc": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "lseg_op_upsample2x_planes": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "lseg_op_upsample4x_planes_scaled": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "lseg_op_correlation": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "lseg_op_head_features": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "lseg_op_seg_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

@@ -360,13 +360,15 @@ class LSeg(BaseModel):
         self._last_engine = eng
         out = eng.forward(x.float(), want_logits=_want_logits)
         mode = getattr(self, "overflow_fallback", True)
-        if eng.image_dtype == "fp16" and mode and (mode == "always" or getattr(eng, "_range_stamp", None) != eng._stamp):
+        if mode and (mode == "always" or getattr(eng, "_range_stamp", None) != eng._stamp):
             # fp16 MFMA operands saturate at 65504 where the reference's fp32 tower cannot (lseg_vit.py:196-197).  Checked on the first
             # forward after every (re)pack of the weights ("always": on every forward, one synchronising ~1 ms scan): any inf / NaN in
-            # a 16-bit activation buffer -> this network switches to bf16 operands (same speed, fp32 range), LOUDLY, and re-runs.
+            # a 16-bit activation buffer of an fp16 engine -> this network switches to bf16 operands (same speed, fp32 range), LOUDLY,
+            # and re-runs.  A bf16 engine that still shows non-finite values (the head map g is fp16 in every mode: DESIGN par. 3.4)
+            # raises -- never inf / NaN masks without an error.
             eng._range_stamp = eng._stamp
             r = eng.check_range()
-            if r["nonfinite"] > 0:
+            if r["nonfinite"] > 0 and eng.image_dtype == "fp16":
                 warnings.warn(f"LSeg: {r['nonfinite']} non-finite values in the fp16 image tower's activations (largest finite |x| "
                               f"{r['max_abs']:.3g}; fp16 saturates at 65504): this network's activations leave the fp16 range -- "
                               "falling back to bf16 MFMA operands for all further forwards (image_dtype='bf16')", RuntimeWarning, stacklevel=2)
@@ -375,6 +377,10 @@ class LSeg(BaseModel):
                     self._engines.pop(key).close()
                 self._last_engine = None
                 return self.forward(x, labelset, _want_logits)
+            if r["nonfinite"] > 0:
+                raise RuntimeError(f"LSeg: {r['nonfinite']} non-finite values in the image tower's 16-bit activations with {eng.image_dtype} operands "
+                                   f"(largest finite |x| {r['max_abs']:.3g}): the head feature map leaves the fp16 range, or the input / weights "
+                                   "are not finite; image_dtype='strict' keeps fp32-class range and precision")
             self.last_range_check = r
         return out
 

@@ -160,7 +160,10 @@ def test_training_step_loss_and_gradients_match_the_oracle(bb, H, W, B, K, seed)
     assert not torch.equal(sd_dev[k0].cpu(), sd[k0])
 
 
-COS_MEDIAN, COS_WORST = 0.90, 0.30      # provisional until the first measured run
+# cosine between the engine's and the reference-autograd gradient over the stored elements, measured (profiles/r04_train_parity_table.txt):
+# medians 0.985-0.998 (B = 8 at 480 x 480, 1040 elements per tensor: 0.9977), worst tensor 0.86-0.90 (80-element samples of early-block
+# tensors: bf16 ReLU-mask flips + the fp16-subnormal head gradient land on other elements than in the fp32 reference)
+COS_MEDIAN, COS_WORST = 0.98, 0.80
 
 
 def _sample_index(numel, n=64):                       # == oracle/make_ref_train_golden.sample_index
