@@ -72,24 +72,23 @@ __device__ __forceinline__ float gelu_grad_as(float z) {
     const float e = 1.0f - poly * ex;
     return 0.5f * (1.0f + (z < 0.f ? -e : e)) + z * 0.3989422804014327f * ex;
 }
-// The same GELU on two values at once: the polynomial runs on v_pk_fma_f32 / v_pk_mul_f32 (packed
-// fp32), only rcp and exp2 stay per-element: 21 VALU per pair instead of ~40.
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2_t gelu_erf2(f32x2_t x) {
-    const f32x2_t z = x * 0.70710678118654752f;
-    f32x2_t az; az[0] = fabsf(z[0]); az[1] = fabsf(z[1]);
-    const f32x2_t d = az * 0.3275911f + 1.0f;
-    f32x2_t t; t[0] = __builtin_amdgcn_rcpf(d[0]); t[1] = __builtin_amdgcn_rcpf(d[1]);
-    f32x2_t p = t * 1.061405429f + (-1.453152027f);
-    p = p * t + 1.421413741f;
-    p = p * t + (-0.284496736f);
-    p = p * t + 0.254829592f;
-    p = p * t;
-    const f32x2_t nz2 = -(az * az) * 1.4426950408889634f;
-    f32x2_t e; e[0] = __builtin_amdgcn_exp2f(nz2[0]); e[1] = __builtin_amdgcn_exp2f(nz2[1]);
-    const f32x2_t erfabs = 1.0f - p * e;                       // erf(|z|)
-    f32x2_t axh; axh[0] = 0.5f * fabsf(x[0]); axh[1] = 0.5f * fabsf(x[1]);
-    return x * 0.5f + axh * erfabs;                            // 0.5x(1+erf z), erf odd
+// GELU(erf) through erfc(|z|) ~= exp2(|z| R(|z|)), z = x / sqrt 2: R = degree-5 fit of log2(erfc(z)) / z on [0, 4.4] (erfc(0) = 1 exactly; max
+// |erfc error| 4.7e-7, GELU error <= 4.6e-7 absolute in fp32 evaluation -- tools/fit_gelu.py).  With h = erfc(|z|) / 2 = exp2(|z| R - 1):
+//   y = x Phi(x) = max(x, 0) - |x| h        (x >= 0: x (1 - h);  x < 0: x h -- no cancellation in the negative tail)
+// 11 VALU instructions, ONE transcendental, |x| for free as a source modifier -- against 13 + rcp + exp2 + two v_and for the
+// Abramowitz-Stegun form above on packed fp32 (half rate on gfx950): the GELU arithmetic was 58 of the 319 us of an mlp.fc1 launch at
+// B = 36 (profiles/r04_epilogue_table.txt: no-store build vs K-loop-only build).  Past |z| = 4.4 (|x| > 6.2) h is held at 3e-10.
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float az = fminf(fabsf(x) * 0.70710678118654752f, 4.4f);
+    float r = 0.0001754754048306495f;
+    r = fmaf(r, az, -0.003827860578894615f);
+    r = fmaf(r, az, 0.03118317201733589f);
+    r = fmaf(r, az, -0.14992395043373108f);
+    r = fmaf(r, az, -0.9180861115455627f);
+    r = fmaf(r, az, -1.6279354095458984f);
+    const float h = __builtin_amdgcn_exp2f(fmaf(r, az, -1.0f));
+    return fmaf(-fabsf(x), h, fmaxf(x, 0.f));
 }
 
 // ReLU on 8 packed 16-bit floats (bf16 or fp16): negative <=> sign bit <=> negative int16.
@@ -189,8 +188,8 @@ __device__ __forceinline__ void apply_act(const GemmArgs& g, float (&v)[4]) {
         for (int r = 0; r < 4; ++r) v[r] = to_f32<T>(from_f32<T>(v[r]));
     }
     if (g.act == ACT_GELU) {
-        const f32x2_t lo = gelu_erf2(f32x2_t{v[0], v[1]}), hi = gelu_erf2(f32x2_t{v[2], v[3]});
-        v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_fast(v[r]);
     } else if (g.act == ACT_QUICKGELU) {
         // x * sigmoid(1.702 x); with round_mid every step is rounded like the fp16 eager ops
 #pragma unroll
@@ -429,7 +428,7 @@ __device__ __forceinline__ uint4 widen16(const float (&x)[4], const float (&y)[4
 // mrow0 / ncol0: first row / column of this WAVE's sub-tile (wave-uniform).  acc[i][j]: rows
 // mrow0 + j*16 + (lane&15), columns ncol0 + i*16 + (lane>>4)*4 .. +3.
 template <typename T, int EPI, int MI, int NI>
-__device__ __forceinline__ void fast_epilogue(const GemmArgs& g, f32x4_t (&acc)[NI][MI], int mrow0, int ncol0, int lane,
+__device__ __forceinline__ void fast_epilogue(const GemmArgs& g, const GemmArgs& gk, f32x4_t (&acc)[NI][MI], int mrow0, int ncol0, int lane,
                                               const float4 (&bias)[NI], size_t c_extra) {
     const int r16 = lane >> 4, ml = lane & 15;
     const int cw = (r16 & 1) * 16 + (r16 >> 1) * 8;       // lane's 8 columns inside a 32-column pair after the swap
@@ -469,18 +468,14 @@ __device__ __forceinline__ void fast_epilogue(const GemmArgs& g, f32x4_t (&acc)[
                     const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
                     if (m < g.M) *reinterpret_cast<uint4*>((uint16_t*)g.C_pre + (size_t)m * g.ldc + ncol0 + cw + i * 16) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-                    const f32x2_t a = gelu_erf2(f32x2_t{to_f32<T>((uint16_t)a0), to_f32<T>((uint16_t)(a0 >> 16))});
-                    const f32x2_t b = gelu_erf2(f32x2_t{to_f32<T>((uint16_t)a1), to_f32<T>((uint16_t)(a1 >> 16))});
-                    const f32x2_t c = gelu_erf2(f32x2_t{to_f32<T>((uint16_t)b0), to_f32<T>((uint16_t)(b0 >> 16))});
-                    const f32x2_t d = gelu_erf2(f32x2_t{to_f32<T>((uint16_t)b1), to_f32<T>((uint16_t)(b1 >> 16))});
-                    x[0] = a[0]; x[1] = a[1]; x[2] = b[0]; x[3] = b[1];
-                    y[0] = c[0]; y[1] = c[1]; y[2] = d[0]; y[3] = d[1];
+                    x[0] = gelu_fast(to_f32<T>((uint16_t)a0)); x[1] = gelu_fast(to_f32<T>((uint16_t)(a0 >> 16)));
+                    x[2] = gelu_fast(to_f32<T>((uint16_t)a1)); x[3] = gelu_fast(to_f32<T>((uint16_t)(a1 >> 16)));
+                    y[0] = gelu_fast(to_f32<T>((uint16_t)b0)); y[1] = gelu_fast(to_f32<T>((uint16_t)(b0 >> 16)));
+                    y[2] = gelu_fast(to_f32<T>((uint16_t)b1)); y[3] = gelu_fast(to_f32<T>((uint16_t)(b1 >> 16)));
                 }
                 if constexpr (EPI == EPI_LIN16_GELU) {
-                    const f32x2_t a = gelu_erf2(f32x2_t{x[0], x[1]}), b = gelu_erf2(f32x2_t{x[2], x[3]});
-                    const f32x2_t c = gelu_erf2(f32x2_t{y[0], y[1]}), d = gelu_erf2(f32x2_t{y[2], y[3]});
-                    x[0] = a[0]; x[1] = a[1]; x[2] = b[0]; x[3] = b[1];
-                    y[0] = c[0]; y[1] = c[1]; y[2] = d[0]; y[3] = d[1];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { x[r] = gelu_fast(x[r]); y[r] = gelu_fast(y[r]); }
                 }
                 const uint4 o = widen16<OT>(x, y);
                 if (m < g.M) st_u4(p + i * 16, o);
@@ -620,41 +615,67 @@ __device__ __forceinline__ void fast_epilogue(const GemmArgs& g, f32x4_t (&acc)[
             });
         });
     } else if constexpr (EPI == EPI_QKV16) {
-        // every 32-column pair of a wave lies inside one head of one of q / k / v (wave-uniform per pair); a wave's
-        // 64 or 128 columns may span two heads (128-wide wave tiles) or a q|k|v boundary (dim not a multiple of WN)
-        static_for<0, MI>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            const int m = mrow0 + j * 16 + ml;
-            const int mm = m < g.M ? m : g.M - 1;
-            const int b = mm / g.qkv_ntok, t = mm - b * g.qkv_ntok;
-            static_for<0, NI / 2>([&](auto pc) {
-                constexpr int i = 2 * decltype(pc)::value;
-                const int c0 = ncol0 + i * 16;                            // first column of the pair
-                const int which = c0 / g.qkv_dim, rem = c0 - which * g.qkv_dim;
-                const int head = rem >> 6, d0 = rem & 63;                 // d0 in {0, 32}
-                const size_t bh = (size_t)b * g.qkv_heads + head;
-                float x[4], y[4];
-                biased(std::integral_constant<int, i>{}, jc, x);
-                biased(std::integral_constant<int, i + 1>{}, jc, y);
-                if (which == 0 && g.qkv_qscale != 0.f) {          // q carries the softmax scale (wave-uniform branch)
+        // Column side on the scalar unit (ncol0 is wave-uniform): every 32-column pair of a wave lies inside one head of one of q / k / v,
+        // and -- select_epi checks qkv_dim % 128 == 0 -- ALL columns of a wave inside one of the three: ONE division per tile decides the
+        // destination, the per-pair offsets are shifts of rem0 + 32 * pair.  32-bit ELEMENT offsets: q, k [b, head, t, d]: head * npad * 64 + d0;
+        // v^T [b, head, d, t]: (head * 64 + d0) * npad.  Row side: (b, t) of the wave's first row by one division, the lane's rows by adds.
+        // (Round 3 decoded which / head per pair and b / t per row with run-time integer divisions inside the unrolled code: ~370 v_readlane
+        // SGPR reloads and 221 64-bit address adds per wave tile, 24 us of a 252 us launch before a single store --
+        // profiles/r04_epilogue_table.txt.)
+        const int c0 = __builtin_amdgcn_readfirstlane(ncol0);
+        const int which = c0 / gk.qkv_dim, rem0 = c0 - which * gk.qkv_dim;
+        const int ntok = gk.qkv_ntok, npad = gk.qkv_npad, Mr = gk.M;
+        const int mr0 = __builtin_amdgcn_readfirstlane(mrow0 < Mr ? mrow0 : Mr - 1);
+        const int b0 = mr0 / ntok, t0 = mr0 - b0 * ntok;
+        const uint32_t hn = (uint32_t)gk.qkv_heads * (uint32_t)npad;
+        if (which < 2 || GEMM_EPI_ABL == 4) {
+            uint16_t* base = (uint16_t*)(which == 2 ? gk.Cv : which ? gk.Ck : gk.C);         // wave-uniform: SGPR base + 32-bit lane offset
+            const float qs = which == 0 && gk.qkv_qscale != 0.f ? gk.qkv_qscale : 1.0f;      // q carries the softmax scale
+            static_for<0, MI>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                int b = b0, t = t0 + j * 16 + ml;
+                while (t >= ntok) { t -= ntok; ++b; }                  // at most once for ntok >= 80
+                const uint32_t rq = ((uint32_t)b * hn + (uint32_t)t) * 64u + (uint32_t)cw;
+                const bool ok = mrow0 + j * 16 + ml < Mr;
+                static_for<0, NI / 2>([&](auto pc) {
+                    constexpr int pi = decltype(pc)::value, i = 2 * pi;
+                    const uint32_t rem = (uint32_t)rem0 + 32u * pi;
+                    const uint32_t cb = (rem >> 6) * (uint32_t)npad * 64u + (rem & 63u);
+                    float x[4], y[4];
+                    biased(std::integral_constant<int, i>{}, jc, x);
+                    biased(std::integral_constant<int, i + 1>{}, jc, y);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { x[r] *= g.qkv_qscale; y[r] *= g.qkv_qscale; }
-                }
-                if (which < 2 || GEMM_EPI_ABL == 4) {
-                    uint16_t* p = (uint16_t*)(which == 2 ? g.Cv : which ? g.Ck : g.C) + (bh * g.qkv_npad + t) * 64 + d0 + cw;
+                    for (int r = 0; r < 4; ++r) { x[r] *= qs; y[r] *= qs; }
                     const uint4 o = widen16<T>(x, y);
-                    if (m < g.M) st_u4(p, o);
-                } else if (m < g.M) {
-                    // V^T [b, head, d, t]: t is the contiguous axis; 16 lanes write 16 consecutive tokens
-                    uint16_t* p = (uint16_t*)g.Cv + (bh * 64 + d0 + r16 * 4) * g.qkv_npad + t;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        st_h(p + (size_t)r * g.qkv_npad, from_f32<T>(x[r]));
-                        st_h(p + (size_t)(16 + r) * g.qkv_npad, from_f32<T>(y[r]));
-                    }
-                }
+                    if (ok) st_u4(reinterpret_cast<char*>(base) + ((rq + cb) << 1), o);       // 32-bit BYTE offset on a uniform base (elements < 2^31)
+                });
             });
-        });
+        } else {
+            // V^T [b, head, d, t]: t is the contiguous axis; 16 lanes write 16 consecutive tokens, 2 bytes each
+            uint16_t* base = (uint16_t*)gk.Cv;
+            static_for<0, MI>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                int b = b0, t = t0 + j * 16 + ml;
+                while (t >= ntok) { t -= ntok; ++b; }
+                const uint32_t rv = (uint32_t)b * hn * 64u + (uint32_t)t + (uint32_t)(r16 * 4) * (uint32_t)npad;
+                const bool ok = mrow0 + j * 16 + ml < Mr;
+                static_for<0, NI / 2>([&](auto pc) {
+                    constexpr int pi = decltype(pc)::value, i = 2 * pi;
+                    const uint32_t rem = (uint32_t)rem0 + 32u * pi;
+                    const uint32_t cb = rem * (uint32_t)npad;                  // (head * 64 + d0) * npad with head * 64 + d0 == rem
+                    float x[4], y[4];
+                    biased(std::integral_constant<int, i>{}, jc, x);
+                    biased(std::integral_constant<int, i + 1>{}, jc, y);
+                    if (ok) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            st_h(reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(base) + ((rv + cb + (uint32_t)r * (uint32_t)npad) << 1)), from_f32<T>(x[r]));
+                            st_h(reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(base) + ((rv + cb + (uint32_t)(16 + r) * (uint32_t)npad) << 1)), from_f32<T>(y[r]));
+                        }
+                    }
+                });
+            });
+        }
     }
 }
 
@@ -1164,7 +1185,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
 #pragma unroll
                     for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(acc[i][j][0]), "v"(acc[i][j][1]), "v"(acc[i][j][2]), "v"(acc[i][j][3]));
             } else {
-                fast_epilogue<T, EPI, MI, NI>(g, acc, m0c + wm * WM, n0c + wn * WN, lane, biasv,
+                fast_epilogue<T, EPI, MI, NI>(g, gk, acc, m0c + wm * WM, n0c + wn * WN, lane, biasv,
                                               nsplit > 1 ? (size_t)(tile / per_split) * g.c_split_stride : 0);
             }
         } else {
@@ -1294,7 +1315,8 @@ int select_epi(const GemmArgs& g) {
         g.act == ACT_NONE && (g.ldc % 4) == 0 && !(reinterpret_cast<uintptr_t>(g.res) & 15))
         return EPI_RES32;
     if (g.map_mode == MAP_QKV && g.res_mode == RES_NONE && g.act == ACT_NONE && g.out_dtype == dt &&
-        (g.qkv_dim % 64) == 0 && g.qkv_dim == g.qkv_heads * 64 &&
+        (g.qkv_dim % 128) == 0 && g.qkv_dim == g.qkv_heads * 64 && g.qkv_ntok > 0 &&       // a wave's (<= 128) columns inside one of q | k | v
+        (long long)((g.M + g.qkv_ntok - 1) / g.qkv_ntok) * g.qkv_heads * g.qkv_npad * 64 < (1ll << 31) &&      // 32-bit element offsets in the epilogue
         !((reinterpret_cast<uintptr_t>(g.Ck) | reinterpret_cast<uintptr_t>(g.Cv)) & 15))
         return EPI_QKV16;
     return EPI_GENERIC;

@@ -55,12 +55,59 @@ class EngineSGD(torch.optim.SGD):
                 return eng
         return None
 
-    def _fusable(self):
+    def _fusable(self, eng=None):
+        """The fused lseg_sgd_step assigns the two learning rates by KEY PREFIX (pretrained.* / scratch.*): it may only replace torch's
+        step when the optimizer's groups are exactly those two sets, every parameter of them trainable, equal hyper-parameters otherwise.
+        A caller who regrouped, froze or added parameters gets torch.optim.SGD."""
         g = self.param_groups
         if len(g) != 2:
             return False
         same = all(g[0][k] == g[1][k] for k in ("momentum", "weight_decay", "dampening", "nesterov"))
-        return same and g[0]["dampening"] == 0 and not g[0]["nesterov"] and not g[0].get("maximize", False)
+        if not (same and g[0]["dampening"] == 0 and not g[0]["nesterov"] and not g[0].get("maximize", False)):
+            return False
+        if eng is None:
+            return True
+        key = (id(eng), tuple(len(x["params"]) for x in g))
+        if getattr(self, "_fusable_cache", (None, None))[0] != key:
+            names = {id(p): k for k, p in self._net.named_parameters()}
+            groups = [{names.get(id(p)) for p in x["params"]} for x in g]
+            want0 = {k for k in eng.grads if k.startswith("pretrained.")}
+            want1 = {k for k in eng.grads if k.startswith("scratch.")}
+            trainable = all(p.requires_grad for x in g for p in x["params"])
+            # parameters the backward never reaches (pretrained.model.norm / head, refinenet4.resConfUnit1: DDP's find_unused_parameters
+            # in the reference) sit in the groups without a gradient: torch skips them, and so does the engine
+            ok = trainable and want0 <= groups[0] and want1 <= groups[1] and not (groups[0] & want1) and not (groups[1] & want0)
+            ok = ok and all(k is None or k in eng.grads or not k.startswith(("pretrained.", "scratch.")) or self._never_has_grad(k)
+                            for k in (groups[0] | groups[1]))
+            self._fusable_cache = (key, ok)
+        return self._fusable_cache[1]
+
+    @staticmethod
+    def _never_has_grad(key):
+        return key.startswith(("pretrained.model.norm.", "pretrained.model.head.")) or ".refinenet4.resConfUnit1." in key
+
+    def _momentum_owner(self):
+        """The ONE training engine that holds the momentum buffers (the first that took a fused step)."""
+        for e in (self._net._engines.values() if self._net is not None else []):
+            ts = getattr(e, "_ts", None)
+            if ts is not None and ts.sgd_steps > 0:
+                return e
+        return None
+
+    def _sync_momentum_to_torch(self):
+        """Before torch's own step takes over after fused steps: the engine's momentum becomes torch's `momentum_buffer` state (and the
+        engine forgets it), so the two paths never run on different optimizer states."""
+        owner = self._momentum_owner()
+        if owner is None:
+            return
+        params = {k: p for k, p in self._net.named_parameters()}
+        for k in owner.grads:
+            p = params.get(k)
+            if p is not None:
+                self.state[p]["momentum_buffer"] = owner.get_momentum(k).to(p.device)
+        torch.cuda.current_stream(owner.device).synchronize()
+        owner._ts.sgd_steps = 0
+        owner.mark_sgd_initialized(False)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -69,13 +116,29 @@ class EngineSGD(torch.optim.SGD):
             with torch.enable_grad():
                 loss = closure()
         eng = self._engine()
-        if eng is None or not self._fusable() or self._net.autograd_grads:
+        if eng is None or self._net.autograd_grads or not self._fusable(eng):
+            self._sync_momentum_to_torch()
             super().step()
             return loss
         ts = eng._ts
+        owner = self._momentum_owner()
+        if owner is not None and owner is not eng:
+            # a second training engine (another crop size / batch path) takes a fused step: the momentum moves with the optimizer, it
+            # is not re-started per engine
+            self._push_momentum(eng, {k: owner.get_momentum(k) for k in owner.grads})
+            torch.cuda.current_stream(owner.device).synchronize()
+            ts.sgd_steps = owner._ts.sgd_steps
+            owner._ts.sgd_steps = 0
+            owner.mark_sgd_initialized(False)
         if self._pending_momentum is not None:                # restored from a checkpoint: push it into the engine once
             self._push_momentum(eng, self._pending_momentum)
             self._pending_momentum = None
+        elif ts.sgd_steps == 0 and any("momentum_buffer" in st for st in self.state.values()):
+            # torch steps came first (fallback path): their momentum seeds the engine's
+            params = {id(p): k for k, p in self._net.named_parameters()}
+            self._push_momentum(eng, {params[id(p)]: st["momentum_buffer"] for p, st in self.state.items()
+                                      if "momentum_buffer" in st and id(p) in params})
+            self.state.clear()
         g = self.param_groups
         eng.sgd_step(g[0]["lr"], g[1]["lr"], g[0]["momentum"], g[0]["weight_decay"])
         ts.sgd_steps += 1
@@ -93,6 +156,12 @@ class EngineSGD(torch.optim.SGD):
                     eng_any = True
         if not eng_any:
             super().zero_grad(set_to_none=set_to_none)
+            return
+        # the engine's buckets are overwritten by the next backward (no memset of 1.4 GB); what a hook or a clip could still see through
+        # .grad would be last step's values, so the references are dropped like torch's set_to_none (the backward re-attaches the views)
+        for grp in self.param_groups:
+            for p in grp["params"]:
+                p.grad = None
 
     # ---- checkpoint compatibility with torch.optim.SGD ------------------------------------------------------------------------
     def _index_keys(self):

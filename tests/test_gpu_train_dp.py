@@ -369,3 +369,56 @@ def test_lightning_shaped_loop_runs_on_the_native_path():
     step_a = (ma.net.state_dict()[k0] - wa[k0]).norm().item()
     diff = (ma.net.state_dict()[k0] - md.net.state_dict()[k0]).norm().item()
     assert diff <= 0.15 * step_a, (diff, step_a)       # without the restored momentum the 4th step would differ by ~70 %
+
+
+def test_momentum_follows_the_optimizer_across_training_engines_and_into_torch_sgd():
+    """momentum lives in the training engine that steps.  A second training engine (another input size) must CONTINUE the
+    optimizer state, not restart it; a fallback to torch's own step (here: the groups no longer match the engine's key prefixes) must
+    start from the engine's momentum; zero_grad() drops the .grad references."""
+    warnings.simplefilter("ignore")
+    from lseg_hip.config import get_config
+    from lseg_hip.synth import synthetic_images, synthetic_state_dict, read_labels
+    from oracle import make_golden as MG
+    cfg = get_config("tiny16")
+    sd = synthetic_state_dict(cfg, seed=12)
+    labels = read_labels(MG.LABELS)[:5]
+    m = _TinyModule.make(sd, labels)
+    (opt,), _ = m.configure_optimizers()
+    mom, wd = opt.param_groups[0]["momentum"], opt.param_groups[0]["weight_decay"]
+    key = "scratch.head1.weight"
+    p = dict(m.net.named_parameters())[key]
+    idx = next(i for i, k in opt._index_keys().items() if k == key)
+
+    def one_step(H, W, seed):
+        x, t = synthetic_images(2, H, W, seed=seed).cuda(), _targets(2, H, W, 5, seed).cuda()
+        loss = m.training_step((x, t), 0)
+        loss.backward()
+        g, w = p.grad.detach().clone(), p.detach().clone()
+        opt.step()
+        opt.zero_grad()
+        assert p.grad is None                                  # no stale gradient values visible after zero_grad
+        torch.cuda.synchronize()
+        return g, w
+
+    g1, w1 = one_step(64, 64, 1)
+    m1 = opt.state_dict()["state"][idx]["momentum_buffer"].clone()
+    assert (m1 - (g1 + wd * w1)).abs().max().item() <= 1e-5 * m1.abs().max().item() + 1e-9        # first step: buffer = d_p
+    g2, w2 = one_step(96, 64, 2)                               # ANOTHER training engine takes the fused step
+    assert len([k for k in m.net._engines if k[3]]) == 2
+    m2 = opt.state_dict()["state"][idx]["momentum_buffer"].clone()
+    want = mom * m1 + (g2 + wd * w2)
+    assert (m2 - want).abs().max().item() <= 1e-4 * want.abs().max().item() + 1e-9, (m2 - want).abs().max().item()
+    # regrouped parameters: the fused step would hand out the wrong learning rates -> torch's step, seeded with the engine's momentum
+    extra = opt.param_groups[1]["params"].pop()
+    opt.param_groups[0]["params"].append(extra)
+    x, t = synthetic_images(2, 64, 64, seed=3).cuda(), _targets(2, 64, 64, 5, 3).cuda()
+    loss = m.training_step((x, t), 0)
+    loss.backward()
+    g3, w3 = p.grad.detach().clone(), p.detach().clone()
+    opt.step()
+    torch.cuda.synchronize()
+    m3 = opt.state[p]["momentum_buffer"]
+    want3 = mom * m2 + (g3 + wd * w3)
+    assert (m3 - want3).abs().max().item() <= 1e-4 * want3.abs().max().item() + 1e-9
+    lr = opt.param_groups[1]["lr"]
+    assert (p.detach() - (w3 - lr * want3)).abs().max().item() <= 1e-5 * w3.abs().max().item()
