@@ -49,18 +49,19 @@ namespace {
 // NW waves per workgroup = 32 * NW query rows: 4 for the bulk shapes; 2 when the grid would not fill the chip (B = 1: 8 x 16 workgroups of
 // 4 waves on 256 CUs -> 15 x 16 of 2)
 // NS K / V^T stages in LDS: tile t + NS - 1 is requested while tile t is computed (NS = 3: a direct-to-LDS load has two tile times to land)
-// VER  instruction schedule / arithmetic of the tile body (DESIGN.md par. 3.2):
-//   0  round-3 body: every MFMA behind its own ds_read + lgkmcnt(0) (the compiler's order of the source loop)
-//   1  same arithmetic, bit for bit; all 8 K fragments of a tile are requested before the first QK^T MFMA and the 8 V^T fragments right
-//      after the last one (they land under the softmax VALU); the two accumulators of each product alternate, so no MFMA waits for an
-//      LDS round trip or for its predecessor's result
-//   2  + q pre-scaled by scale * log2(e) and the REFERENCE MAX BAKED INTO THE ACCUMULATOR: S^T starts from -m_ref (a per-query constant
-//      = a per-lane constant in this orientation), so the MFMA delivers the exp2 argument itself -- no fma per score.  m_ref is the
-//      running max, refreshed only when a tile's relative max exceeds 2^THR (exact: the rescale of O and l is the usual one; every
-//      p <= 2^THR fits the 16-bit operand type and fp32 sums).  The first tile always takes the refresh path.
-//   3  + the row sums from the matrix pipe: l += 1^T P^T as four more MFMAs per tile on a ones operand (sums exactly the ROUNDED
-//      probabilities the PV product uses) instead of 32 v_add_f32
-template <typename T, int NW, int NS, int VER>
+// Tile body (DESIGN.md par. 3.2): all 8 K fragments of a tile are requested before the first QK^T MFMA and the 8 V^T fragments right
+// after the last one (they land under the softmax VALU); the two accumulators of each product alternate, so no MFMA waits for an LDS
+// round trip or for its predecessor's result.  (Round 3's body had every MFMA behind its own ds_read + lgkmcnt(0); same arithmetic.)
+// PRE = false: q as the Linear wrote it, softmax scale applied to the scores (training forward -- the backward consumes q --, the causal
+//   text tower, the C-ABI brick lseg_op_attention).  Bit-identical to round 3's kernel.
+// PRE = true (the inference image tower): q PRE-SCALED by scale * log2(e) in the QKV epilogue's single rounding, and the REFERENCE MAX
+//   BAKED INTO THE ACCUMULATOR: S^T starts from -m_ref (a per-query constant = a per-lane constant in this orientation), so the matrix
+//   pipe delivers the exp2 argument itself -- no fma per score.  m_ref is the running max, refreshed only when a tile's relative max
+//   exceeds 2^THR (exact: the rescale of O and l is the usual one; every p <= 2^THR fits the 16-bit operand type and fp32 sums); the
+//   first tile always takes the refresh path.  The row sums come from the matrix pipe too: l += 1^T P^T as four more MFMAs per tile on
+//   a ones operand (they sum exactly the ROUNDED probabilities the PV product uses) instead of 32 v_add_f32.
+//   Measured at B = 36 (tools/attention_bench.py, profiles/r04_attention_experiments.txt): bf16 221.6 -> 196.5 us, fp16 225.0 -> 212.9.
+template <typename T, int NW, int NS, bool PRE>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void lseg_attention_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // NS x (K 8 KB + Vt 8 KB)
     constexpr int TILE = 8192, STAGE = 2 * TILE;
@@ -133,8 +134,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void lseg_attention_kerne
     for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    float m_run = VER >= 2 ? 0.f : -1e30f, l_run = 0.f;
-    f32x16_t lacc;                            // VER 3: every register = this query's running sum (1^T P^T on the matrix pipe)
+    float m_run = PRE ? 0.f : -1e30f, l_run = 0.f;
+    f32x16_t lacc;                            // PRE: every register = this query's running sum (1^T P^T on the matrix pipe)
 #pragma unroll
     for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
     const int one2 = std::is_same<T, F16>::value ? 0x3C003C00 : 0x3F803F80;       // two 16-bit ones
@@ -161,103 +162,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void lseg_attention_kerne
         const char* sk = smem + st_use * STAGE;
         const char* sv = sk + TILE;
 
-        if constexpr (VER == 0) {
-            // ---- S^T[key][q] for 64 keys: 2 sub-tiles x 4 k-steps ---------------------------------
-            f32x16_t s[2];
-    #pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
-    #pragma unroll
-                for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
-    #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const i32x4_t kf = *reinterpret_cast<const i32x4_t*>(sk + tile_off(sub * 32 + ql, ks * 2 + hi));
-                    s[sub] = mfma32<T>(kf, qf[ks], s[sub]);
-                }
-            }
-            ATTN_PROBE(2)
-            // ---- mask, online softmax (scale folded into the exp2 argument) -------------------------
-            const bool need_mask = a.causal || (t * 64 + 64 > a.ntok);        // wave-uniform
-            if (need_mask) {
-    #pragma unroll
-                for (int sub = 0; sub < 2; ++sub)
-    #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = t * 64 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        const bool ok = key < a.ntok && (!a.causal || key <= qrow);
-                        s[sub][r] = ok ? s[sub][r] : -INFINITY;
-                    }
-            }
-            float mx = -INFINITY;
-    #pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-    #pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[sub][r]);
-            {   // max over the two half-waves holding a query's keys: one v_permlane32_swap (VALU) instead of a ds_bpermute round trip
-                // on the critical path of every tile -- afterwards sw[0] = the lower half's value in both halves, sw[1] = the upper half's
-                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * a.scale_log2e;               // scale > 0
-            }
-            ATTN_PROBE(3)
-            const float m_new = fmaxf(m_run, mx);
-            // exact "defer": when no row of this wave raised its running max the rescale factor is
-            // exactly 1 for every lane, so the exp and the 32 accumulator multiplies are skipped
-            const bool grew = !__all(m_new == m_run);
-            float alpha = 1.0f;
-            if (grew) alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            m_run = m_new;
-            // (plain v_fma_f32 / v_add_f32 on purpose: on gfx950 the packed fp32 forms run at half rate AND do not overlap with another
-            // wave's MFMAs the way scalar-lane VALU does -- tools/probes/valu_mfma_probe.py)
-            float lsum = 0.f;
-    #pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-    #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(s[sub][r], a.scale_log2e, -m_new));
-                    s[sub][r] = p;
-                    lsum += p;
-                }
-            l_run = l_run * alpha + lsum;
-            if (grew) {
-    #pragma unroll
-                for (int d = 0; d < 2; ++d)
-    #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-            }
-
-            // ---- P^T fragments (B operand) ----------------------------------------------------------
-            // The accumulator gives a lane keys {0-3, 8-11} (+4 for the upper half-wave) of each 16-key
-            // step.  One v_permlane32_swap per packed word trades the second quad of the lower half with
-            // the first quad of the upper half, so a lane ends up with 8 CONTIGUOUS keys (lower half
-            // 0-7, upper half 8-15): the standard operand order, and V^T is then read with one
-            // conflict-free ds_read_b128 per fragment instead of two 2-way-conflicting ds_read_b64.
-            i32x4_t pf[2][2];
-    #pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-    #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const uint32_t a0 = pack2<T>(s[sub][8 * s2 + 0], s[sub][8 * s2 + 1]);   // quad A, words 0/1
-                    const uint32_t a1 = pack2<T>(s[sub][8 * s2 + 2], s[sub][8 * s2 + 3]);
-                    const uint32_t b0 = pack2<T>(s[sub][8 * s2 + 4], s[sub][8 * s2 + 5]);   // quad B
-                    const uint32_t b1 = pack2<T>(s[sub][8 * s2 + 6], s[sub][8 * s2 + 7]);
-                    const auto w0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-                    const auto w1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-                    pf[sub][s2][0] = (int)w0[0]; pf[sub][s2][1] = (int)w1[0];
-                    pf[sub][s2][2] = (int)w0[1]; pf[sub][s2][3] = (int)w1[1];
-                }
-            ATTN_PROBE(4)
-            // ---- O^T[d][q] += V^T[d][keys] P^T[keys][q] -----------------------------------------------
-    #pragma unroll
-            for (int d = 0; d < 2; ++d) {
-                const int row = d * 32 + ql;
-    #pragma unroll
-                for (int sub = 0; sub < 2; ++sub)
-    #pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        const i32x4_t vf = *reinterpret_cast<const i32x4_t*>(sv + tile_off(row, sub * 4 + s2 * 2 + hi));
-                        o[d] = mfma32<T>(vf, pf[sub][s2], o[d]);
-                    }
-            }
-        } else {
+        {
             // ---- S^T[key][q] for 64 keys: all 8 K fragments in flight, then 8 MFMAs alternating the two 32-key accumulators ----
             i32x4_t kf[8];
 #pragma unroll
@@ -267,7 +172,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void lseg_attention_kerne
                     kf[ks * 2 + sub] = *reinterpret_cast<const i32x4_t*>(sk + tile_off(sub * 32 + ql, ks * 2 + hi));
             __builtin_amdgcn_sched_barrier(0);
             f32x16_t s[2];
-            const float s_init = VER >= 2 ? -m_run : 0.f;        // VER >= 2: m_run = the reference max the scores are taken against (0 before tile 0)
+            const float s_init = PRE ? -m_run : 0.f;             // PRE: m_run = the reference max the scores are taken against (0 before tile 0)
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
@@ -309,7 +214,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void lseg_attention_kerne
             }
             ATTN_PROBE(3)
             float lsum = 0.f;
-            if constexpr (VER == 1) {
+            if constexpr (!PRE) {
                 mx *= a.scale_log2e;
                 const float m_new = fmaxf(m_run, mx);
                 const bool grew = !__all(m_new == m_run);
@@ -348,23 +253,16 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void lseg_attention_kerne
                         for (int d = 0; d < 2; ++d)
 #pragma unroll
                             for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-                        if constexpr (VER == 3) {
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
-                        } else {
-                            l_run *= alpha;
-                        }
+                        for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
                     }
                 }
 #pragma unroll
                 for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const float p = __builtin_amdgcn_exp2f(s[sub][r]);
-                        s[sub][r] = p;
-                        if constexpr (VER == 2) lsum += p;
+                        s[sub][r] = __builtin_amdgcn_exp2f(s[sub][r]);
                     }
-                if constexpr (VER == 2) l_run += lsum;
             }
             i32x4_t pf[2][2];
 #pragma unroll
@@ -388,7 +286,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void lseg_attention_kerne
                 for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
                     for (int d = 0; d < 2; ++d) o[d] = mfma32<T>(vf[(sub * 2 + s2) * 2 + d], pf[sub][s2], o[d]);
-                    if constexpr (VER == 3) lacc = mfma32<T>(ones, pf[sub][s2], lacc);
+                    if constexpr (PRE) lacc = mfma32<T>(ones, pf[sub][s2], lacc);
                 }
         }
         ATTN_PROBE(5)
@@ -396,7 +294,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void lseg_attention_kerne
     ATTN_PROBE_DUMP
 
     // ---- normalise and store: lane holds O[q][d = dblk*32 + 8g + 4hi + 0..3] -------------------------
-    const float l_tot = VER == 3 ? lacc[0] : l_run + __shfl_xor(l_run, 32);      // the MFMA already summed both key halves
+    const float l_tot = PRE ? lacc[0] : l_run + __shfl_xor(l_run, 32);      // the MFMA already summed both key halves
     const float inv = 1.0f / l_tot;
     if (a.lse2 && hi == 0 && qrow < a.ntok) a.lse2[(size_t)bh * a.npad + qrow] = m_run + __builtin_amdgcn_logf(l_tot);   // v_log_f32 = log2
     if (qrow < a.ntok) {
@@ -427,7 +325,7 @@ int launch_attention_lse(const void* q, const void* k, const void* vt, void* out
 }
 
 // prescaled != 0: q was written as T(q * scale * log2(e)) (one rounding, in the QKV GEMM's epilogue: GemmArgs::qkv_qscale) -- the
-// inference engine's path; the matrix pipe then delivers the exp2 argument directly (kernel VER 2 / 3).  Not for causal masks.
+// inference engine's path; the matrix pipe then delivers the exp2 argument directly (kernel PRE = true).  Not for causal masks.
 int launch_attention_ex(const void* q, const void* k, const void* vt, void* out, float* lse2, int B, int H, int ntok,
                         int npad, int dtype, int causal, float scale, int prescaled, hipStream_t stream) {
     if (npad % 128 != 0 || npad < ntok) return set_error(LSEG_ERR_INVALID, "attention: npad=%d must be a multiple of 128 and >= ntok=%d", npad, ntok);
@@ -441,19 +339,14 @@ int launch_attention_ex(const void* q, const void* k, const void* vt, void* out,
     if (dtype != DT_BF16 && dtype != DT_F16) return set_error(LSEG_ERR_INVALID, "attention: dtype %d", dtype);
     int dev = 0;
     LSEG_HIP_TRY(hipGetDevice(&dev));
-    static const int force_nw = getenv("LSEG_ATTN_WAVES") ? atoi(getenv("LSEG_ATTN_WAVES")) : 0;      // tools: 2 | 4
-    static const int force_ver = getenv("LSEG_ATTN_VER") ? atoi(getenv("LSEG_ATTN_VER")) : -1;        // tools: kernel body A/B (see VER)
-    const bool narrow = force_nw ? force_nw == 2 : ((long)((ntok + 127) / 128) * B * H < 2L * device_cu_count(dev) && !causal);
+    const bool narrow = (long)((ntok + 127) / 128) * B * H < 2L * device_cu_count(dev) && !causal;      // 2-wave workgroups when the grid would not fill the chip
     const int nw = narrow ? 2 : 4;
-    int ver = prescaled ? 3 : 1;
-    if (force_ver >= 0) ver = prescaled ? (force_ver >= 2 ? force_ver : 3) : (force_ver <= 1 ? force_ver : 1);   // the arithmetic follows the operand
     const size_t lds = (size_t)2 * 2 * 8192;
     dim3 grid(((ntok + 32 * nw - 1) / (32 * nw)) * B * H);
-#define ATT(TT, NWV, VV) hipLaunchKernelGGL((lseg_attention_kernel<TT, NWV, 2, VV>), grid, dim3(64 * NWV), lds, stream, a)
-#define ATT_T(NWV, VV) do { if (dtype == DT_BF16) ATT(BF16, NWV, VV); else ATT(F16, NWV, VV); } while (0)
-#define ATT_V(NWV) do { if (ver == 0) ATT_T(NWV, 0); else if (ver == 1) ATT_T(NWV, 1); else if (ver == 2) ATT_T(NWV, 2); else ATT_T(NWV, 3); } while (0)
-    if (nw == 2) ATT_V(2); else ATT_V(4);
-#undef ATT_V
+#define ATT(TT, NWV, PV) hipLaunchKernelGGL((lseg_attention_kernel<TT, NWV, 2, PV>), grid, dim3(64 * NWV), lds, stream, a)
+#define ATT_T(NWV, PV) do { if (dtype == DT_BF16) ATT(BF16, NWV, PV); else ATT(F16, NWV, PV); } while (0)
+    if (nw == 2) { if (prescaled) ATT_T(2, true); else ATT_T(2, false); }
+    else { if (prescaled) ATT_T(4, true); else ATT_T(4, false); }
 #undef ATT_T
 #undef ATT
     LSEG_HIP_TRY(hipGetLastError());

@@ -667,14 +667,12 @@ __global__ __launch_bounds__(256) void upsample2x_planes_scaled_kernel(const flo
 // The same followed by scratch.output_conv's x2 bilinear (lseg_net.py:203) in one pass: R [P, H+2, W+2] -> logits [P, 4H, 4W], the
 // (2H, 2W) logits only ever exist as a band in LDS.  Bit-identical to upsample2x_planes_scaled + upsample2x_planes (bilerp).
 // A block = one plane x the output rows whose upper source row lies in a band of LB low rows.
-// LDS image of the low-resolution band: each row DE-INTERLEAVED -- even columns in the first half, odd columns in the second.  The
-// output pass reads, for output column group x4, the low columns {2 x4 - 1 .. 2 x4 + 2}: with plain rows consecutive lanes read floats
-// two apart (every ds_read_b32 a 2-way bank conflict: SQ_LDS_BANK_CONFLICT = 2.1e8 per launch in round 3); in this image consecutive
-// lanes read consecutive floats.  lofs(i) = offset of low column i inside a row.
-template <int DEINT>
-__device__ __forceinline__ int lofs(int i, int half) { return DEINT ? ((i & 1) ? half : 0) + (i >> 1) : i; }
-
-template <int LB, int DEINT>
+// Band height of the one-pass x4 upsample: 16 low rows (32 output rows) per block.  Measured in round 4 (tools/upsample_bench.py,
+// profiles/r04_head_kernels.txt): 8 -> 16 rows 1501 -> 1389 us at B = 36 (fewer re-staged boundary rows, half the blocks); a
+// de-interleaved LDS image that makes every ds_read_b32 of the output pass conflict-free (SQ_LDS_BANK_CONFLICT 2.1e8 -> 0) changed
+// NOTHING (1501 vs 1505 us): the 2-way conflicts were never on the critical path, and the variant was removed.
+constexpr int UPS4_LB = 16;
+template <int LB>
 __global__ __launch_bounds__(256) void upsample4x_planes_scaled_kernel(const float* __restrict__ in, const float* __restrict__ scale,
                                                                        float* __restrict__ out, int P, int K, int H, int W) {
     extern __shared__ float sm[];             // Rr [<= LB/2 + 4][W] | Lr [LB + 1][2W]
@@ -696,12 +694,7 @@ __global__ __launch_bounds__(256) void upsample4x_planes_scaled_kernel(const flo
             for (int Y = ya + sub; Y <= yb; Y += nsub) {
                 float o[4];
                 ups_low4(Rr, sc, H, W, ry1, r_lo, Y, x4, t, o);
-                if (DEINT) {
-                    *reinterpret_cast<float2*>(Lr + (Y - ya) * Wl + x4 * 2) = make_float2(o[0], o[2]);
-                    *reinterpret_cast<float2*>(Lr + (Y - ya) * Wl + W + x4 * 2) = make_float2(o[1], o[3]);
-                } else {
-                    *reinterpret_cast<float4*>(Lr + (Y - ya) * Wl + x4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
-                }
+                *reinterpret_cast<float4*>(Lr + (Y - ya) * Wl + x4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
             }
         }
     }
@@ -718,9 +711,6 @@ __global__ __launch_bounds__(256) void upsample4x_planes_scaled_kernel(const flo
         const int sub = w4 < 256 ? threadIdx.x / w4 : 0;
         if (sub >= nsub) break;
         const ColTerms t = col_terms4(rx, x4, Wl);
-        int a0[4], a1[4];                           // LDS offsets of the two source columns of each output column (loop invariant)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { a0[e] = lofs<DEINT>(t.x0[e], W); a1[e] = lofs<DEINT>(t.x1[e], W); }
         for (int yo = yo_first + sub; yo < yo_end; yo += nsub) {
             int y0, y1;
             float ly;
@@ -729,7 +719,7 @@ __global__ __launch_bounds__(256) void upsample4x_planes_scaled_kernel(const flo
             const float* q1 = Lr + (y1 - ya) * Wl;
             float o[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = bilerp(q0[a0[e]], q0[a1[e]], q1[a0[e]], q1[a1[e]], t.lx[e], ly);
+            for (int e = 0; e < 4; ++e) o[e] = bilerp(q0[t.x0[e]], q0[t.x1[e]], q1[t.x0[e]], q1[t.x1[e]], t.lx[e], ly);
             const f32x4_t ov = {o[0], o[1], o[2], o[3]};     // written once, never re-read by the engine
             __builtin_nontemporal_store(ov, reinterpret_cast<f32x4_t*>(out + ((size_t)pl * Ho + yo) * Wo) + x4);
         }
@@ -2551,15 +2541,9 @@ int launch_upsample2x_planes_scaled(const float* in_padded, const float* scale, 
 // R planes -> the full-resolution logits in one pass (x2 with the per-pixel scale and fp16 rounding, then output_conv's x2)
 int launch_upsample4x_planes_scaled(const float* in_padded, const float* scale, float* out, int P, int K, int H, int W, hipStream_t st) {
     if (W % 2 != 0) return set_error(LSEG_ERR_UNSUPPORTED, "scaled upsample: W=%d must be even", W);
-    static const int variant = getenv("LSEG_UPS4_VARIANT") ? atoi(getenv("LSEG_UPS4_VARIANT")) : 1;    // tools: 0 = round 3's plain LDS rows, band 8
-#define UPS4(LBV, DV)                                                                                                                      \
-    do {                                                                                                                                   \
-        const int bands = (2 * H + LBV - 1) / LBV;                                                                                         \
-        const size_t lds = ((size_t)(LBV / 2 + 4) * W + (size_t)(LBV + 1) * 2 * W) * sizeof(float);                                        \
-        hipLaunchKernelGGL((upsample4x_planes_scaled_kernel<LBV, DV>), dim3((unsigned)P * bands), dim3(256), lds, st, in_padded, scale, out, P, K, H, W); \
-    } while (0)
-    if (variant == 0) UPS4(8, 0); else if (variant == 2) UPS4(16, 1); else if (variant == 3) UPS4(16, 0); else UPS4(8, 1);
-#undef UPS4
+    const int bands = (2 * H + UPS4_LB - 1) / UPS4_LB;
+    const size_t lds = ((size_t)(UPS4_LB / 2 + 4) * W + (size_t)(UPS4_LB + 1) * 2 * W) * sizeof(float);
+    hipLaunchKernelGGL((upsample4x_planes_scaled_kernel<UPS4_LB>), dim3((unsigned)P * bands), dim3(256), lds, st, in_padded, scale, out, P, K, H, W);
     CHECK_LAUNCH();
     return 0;
 }

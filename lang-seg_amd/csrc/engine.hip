@@ -771,10 +771,9 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
         g.bias = b.qkv.b; g.out_dtype = img_dt_; g.map_mode = MAP_QKV;
         g.C = q_; g.Ck = k_; g.Cv = vt_; g.qkv_dim = D; g.qkv_ntok = ntok_; g.qkv_npad = npad_; g.qkv_heads = H;
         // the softmax scale (head_dim^-0.5 = 0.125 for 64) * log2(e) rides on q through the QKV epilogue's single rounding: the attention
-        // kernel's matrix pipe then delivers exp2 arguments (attention.hip VER 2 / 3)
-        static const bool no_prescale = getenv("LSEG_ATTN_NO_PRESCALE") != nullptr;      // tools: A/B against the scale-in-the-softmax form
+        // kernel's matrix pipe then delivers exp2 arguments (attention.hip PRE)
         g.qkv_qscale = 0.125f * 1.4426950408889634f;
-        const bool prescaled = !strict_ && !no_prescale && gemm_qkv_scales_q(g, img_dt_);
+        const bool prescaled = !strict_ && gemm_qkv_scales_q(g, img_dt_);
         if (!prescaled) g.qkv_qscale = 0.f;
         pe = prof_begin(PF_QKV, st);
         TRY(igemm(g, st));

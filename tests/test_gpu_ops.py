@@ -180,7 +180,7 @@ def test_attention_rescale_branch(lib):
                                         (1, 2, 901, "low"), (40, 16, 197, "plain")])
 def test_attention_prescaled(lib, dtype, B, H, N, mode):
     """The inference engine's attention: q arrives as T(q * scale * log2 e) and the kernel bakes the reference max into the QK^T
-    accumulator (attention.hip VER 2 / 3; the reference max moves only when a tile exceeds it by 2^8).  Against fp32 torch on the same
+    accumulator (attention.hip PRE = true; the reference max moves only when a tile exceeds it by 2^8).  Against fp32 torch on the same
     rounded operands.  spike: one key dominates one query late in the sequence (the refresh branch fires mid-sequence); ramp: scores
     grow steadily along the keys (refresh after refresh); low: every score far BELOW zero (the first-tile reference must be the tile's
     own max, not 0, or every probability underflows); B = 40 runs the 4-wave kernel on a shape whose last query block is mostly padding."""

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Time lseg_op_attention at the ViT-L shape (901 tokens, 16 heads, head_dim 64) and check it against fp32 torch on two heads (tools).
-Knobs are read once per process: LSEG_ATTN_VER=0|1 picks the tile body of the plain kernel (0 = round 3's order, 1 = batched fragment reads),
-2|3 that of the pre-scaled kernel (PRESCALED=1: q arrives as q * scale * log2 e; 3 = row sums on the matrix pipe); LSEG_ATTN_WAVES=2|4."""
+PRESCALED=1 times the inference engine's form (lseg_op_attention_prescaled: q arrives as q * scale * log2 e).  The round-4 A/B of the four
+kernel bodies is recorded in profiles/r04_attention_experiments.txt."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "lang-seg_amd"))
@@ -36,4 +36,4 @@ for B in (int(v) for v in (sys.argv[1:] or ["36"])):
             ref = s.softmax(-1) @ vt[bh, :, :N].float().t()
             b, h = bh // H, bh % H
             err = max(err, (out[b, :, h * 64:(h + 1) * 64].float() - ref).abs().max().item())
-        print(f"ver={os.environ.get('LSEG_ATTN_VER', 'default')} prescaled={int(pre)} B={B} {str(dt)[6:]}: {us:.1f} us -> {4.0 * B * H * N * N * 64 / us / 1e6:.0f} TF/s; max|err| vs fp32 torch {err:.4f}", flush=True)
+        print(f"prescaled={int(pre)} B={B} {str(dt)[6:]}: {us:.1f} us -> {4.0 * B * H * N * N * 64 / us / 1e6:.0f} TF/s; max|err| vs fp32 torch {err:.4f}", flush=True)
