@@ -422,8 +422,10 @@ def test_engine_matches_the_reference_at_the_baseline_configs(name, dtype, golde
 # absolute bars of the 480 x 480 mask test (the "ties" statement above scales with the measured error; these do not): fraction of the
 # output pixels whose label may differ from the reference's, and the largest reference top-2 margin at such a pixel.  Measured at
 # 240 x 240 in round 3: K = 150 bf16 1.62 % / 0.099, fp16 0.27 % / 0.0092, strict 0.16 % / 0.0024; K = 1000 10.8 % / 0.101, 1.85 % / 0.013,
-# 0.91 % / 0.0039 (1000 synthetic prompts on a random text tower: median top-2 margin 0.055)
-MASK480_CAPS = {150: {"bf16": (0.025, 0.15), "fp16": (0.005, 0.02), "strict": (0.003, 0.006)},
+# 0.91 % / 0.0039 (1000 synthetic prompts on a random text tower: median top-2 margin 0.055).  Measured at 480 x 480 in round 4: K = 150 bf16
+# 2.1-2.4 % (the flip fraction of the bf16 tower moves by +-0.4 % with any change of rounding points: random weights amplify), fp16 0.22 %,
+# strict 0.12 %; K = 1000 10.9 % / 1.6-1.8 % / 0.95 %
+MASK480_CAPS = {150: {"bf16": (0.035, 0.15), "fp16": (0.005, 0.02), "strict": (0.003, 0.006)},
                 1000: {"bf16": (0.14, 0.15), "fp16": (0.026, 0.025), "strict": (0.013, 0.008)}}
 
 

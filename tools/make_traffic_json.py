@@ -8,7 +8,7 @@ import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "profiles", "summary.json")
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 36
-dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r03_traffic.json")
+dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r04_traffic.json")
 dtype = sys.argv[4] if len(sys.argv) > 4 else "fp16"
 commit = sys.argv[5] if len(sys.argv) > 5 else None
 S = json.load(open(src))
@@ -67,7 +67,7 @@ entry("mlp_fc1_gemm", g(2, 1), 2 * (M * D + 4 * D * D + M * 4 * D), 2.0 * M * 4 
 # attn.proj and mlp.fc2 share the symbol (fp32 residual epilogue): per-launch averages over both shapes
 entry("res32_gemm", g(3, 0), (2 * (M * D + D * D) + 8 * M * D + 2 * (M * 4 * D + 4 * D * D) + 8 * M * D) // 2, (2.0 * M * D * D + 2.0 * M * 4 * D * D) / 2)
 entry("qkv_gemm", g(4, 0), 2 * (M * D + 3 * D * D + M * 3 * D), 2.0 * M * 3 * D * D)
-entry("attention", lambda k: "lseg_attention_kernel<" + T + ", 4>" in k, 2 * 4 * B * 16 * 1024 * 64, 4.0 * B * ntok * ntok * D)
+entry("attention", lambda k: "lseg_attention_kernel<" + T + ", 4, 2, true>" in k, 2 * 4 * B * 16 * 1024 * 64, 4.0 * B * ntok * ntok * D)
 # ---- HBM-bound kernels of the head: algorithmic bytes = what the schedule must move once
 P122, P120 = B * 122 * 122, B * 120 * 120
 entry("correlation_label_planes", lambda k: "lseg_gemm_kernel<lseg::F16" in k and "TileCfg<160, 128" in k,
