@@ -716,6 +716,14 @@ using CfgHuge = TileCfg<256, 256, 4, 2, 2, 1>;     // half the operand bytes per
 // Row config: one workgroup owns complete 512-wide output rows (fused head1 + L2-norm + fp16 casts);
 // 128 accumulator registers per lane, one wave per SIMD, 152 KB of rings + 1 KB reduction scratch
 using CfgRow = TileCfg<64, 512, 1, 4, 2, 1>;
+// Round-4 tile probes for the ViT block's GEMMs (LSEG_GEMM_TILE = 7 / 8 / 9, tools/epilogue_table.py): what a tile that leaves registers
+// for a residual prefetch / deferred stores costs in the K-loop.
+//   Wide   256x128, 4x2 waves (64x64 per wave, 64 accumulators),  128 KB LDS, two waves per SIMD
+//   Wide4  256x128, 2x2 waves (128x64 per wave, 128 accumulators), 128 KB LDS, ONE wave per SIMD (512 registers)
+//   Huge4  256x256, 2x2 waves (128x128 per wave, 256 accumulators), 160 KB LDS, one wave per SIMD
+using CfgWide = TileCfg<256, 128, 4, 2, 2, 1>;
+using CfgWide4 = TileCfg<256, 128, 2, 2, 2, 1>;
+using CfgHuge4 = TileCfg<256, 256, 2, 2, 2, 1>;
 
 // Counted waits go through the BUILTIN, not inline asm: SIInsertWaitcnts understands a pre-existing
 // s_waitcnt and keeps its own scoreboard consistent.  An opaque asm wait left it believing that
@@ -1253,7 +1261,8 @@ int launch_one(const GemmArgs& g, hipStream_t stream) {
 template <typename T, bool CONV, bool RELU_IN, int EPI, int TAG>
 int pick_tile(const GemmArgs& g, hipStream_t stream) {
     const long t_mid = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.nsplit > 1 ? g.nsplit : 1);
-    static const int force = getenv("LSEG_GEMM_TILE") ? atoi(getenv("LSEG_GEMM_TILE")) : 0;   // tools/tests: 1 = 64x64, 2 = 128x128, 6 = 256x256
+    const char* force_env = getenv("LSEG_GEMM_TILE");                                         // tools/tests: 1 = 64x64, 2 = 128x128, 6 = 256x256
+    const int force = force_env ? atoi(force_env) : 0;                                        // (read per launch: a tool sweeps tiles in one process)
     int pick = t_mid >= 192 ? 2 : 1;
     if (EPI == EPI_GENERIC && !CONV && g.map_mode == MAP_LABELPLANES && g.M > 128 && g.M <= 160 && !force)
         return launch_one<T, CfgLab, false, false, EPI_GENERIC, TAG>(g, stream);
@@ -1269,6 +1278,11 @@ int pick_tile(const GemmArgs& g, hipStream_t stream) {
     if (g.tile_hint == 2 || g.tile_hint == 6) pick = g.tile_hint;
     if (force) pick = force;
     if (pick == 6 && (g.N % 256) != 0) pick = 2;      // the specialised epilogues write whole tile rows: N must be a multiple of BN
+    if constexpr (!CONV && !RELU_IN && TAG == 0 && (EPI == EPI_RES32 || EPI == EPI_QKV16 || EPI == EPI_LIN16_GELU)) {
+        if (force == 7 && (g.N % 128) == 0) return launch_one<T, CfgWide, false, false, EPI, 0>(g, stream);
+        if (force == 9 && (g.N % 128) == 0) return launch_one<T, CfgWide4, false, false, EPI, 0>(g, stream);
+        if (force == 8 && (g.N % 256) == 0) return launch_one<T, CfgHuge4, false, false, EPI, 0>(g, stream);
+    }
     if constexpr (EPI != EPI_GENERIC) {
         if (pick == 6) return launch_one<T, CfgHuge, CONV, RELU_IN, EPI, TAG>(g, stream);
     }
