@@ -300,14 +300,19 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 3) void lseg_attention_kerne
     if (qrow < a.ntok) {
         const int b = bh / a.H, h = bh - b * a.H;
         uint16_t* orow = a.out + ((size_t)b * a.ntok + qrow) * (a.H * 64) + h * 64;
+        // A row's 8-dim group g is split over the two half-waves (hi = 0: dims 8g .. 8g+3, hi = 1: 8g+4 .. 8g+7).  One v_permlane32_swap per
+        // packed word on a PAIR of groups (g, g + 1) gives the lower lane all 16 bytes of group g and the upper lane all 16 bytes of group
+        // g + 1: 4 stores of 16 bytes per lane instead of 8 of 8 (the store tail of a row-per-lane epilogue is bound by the number of store
+        // instructions, cdna_hip_programming.md T21) -- same bytes at the same addresses.
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 pk;
-                pk.x = pack2<T>(o[d][g * 4 + 0] * inv, o[d][g * 4 + 1] * inv);
-                pk.y = pack2<T>(o[d][g * 4 + 2] * inv, o[d][g * 4 + 3] * inv);
-                *reinterpret_cast<uint2*>(orow + d * 32 + g * 8 + hi * 4) = pk;
+            for (int g = 0; g < 4; g += 2) {
+                const uint32_t ax = pack2<T>(o[d][g * 4 + 0] * inv, o[d][g * 4 + 1] * inv), ay = pack2<T>(o[d][g * 4 + 2] * inv, o[d][g * 4 + 3] * inv);
+                const uint32_t bx = pack2<T>(o[d][g * 4 + 4] * inv, o[d][g * 4 + 5] * inv), by = pack2<T>(o[d][g * 4 + 6] * inv, o[d][g * 4 + 7] * inv);
+                const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);      // [0]: own g | lower's g+1, [1]: upper's g | own g+1
+                const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                *reinterpret_cast<uint4*>(orow + d * 32 + (g + hi) * 8) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
             }
     }
 }

@@ -485,7 +485,11 @@ __device__ __forceinline__ void fast_epilogue(const GemmArgs& g, const GemmArgs&
         // every residual load of the sub-tile is in flight before the first store (in place: x += f(x))
         float* cbase = (float*)g.C + ncol0 + r16 * 4;
         const float* rbase = (const float*)g.res + ncol0 + r16 * 4;
-        constexpr int JC = (16 / NI) < 1 ? 1 : ((16 / NI) > MI ? MI : (16 / NI));      // rows per chunk: <= 64 registers of prefetched residual
+#ifndef GEMM_RES32_REGS
+#define GEMM_RES32_REGS 64
+#endif
+        constexpr int JC0 = GEMM_RES32_REGS / 4 / NI;
+        constexpr int JC = JC0 < 1 ? 1 : (JC0 > MI ? MI : JC0);      // rows per chunk: <= GEMM_RES32_REGS registers of prefetched residual
         static_for<0, MI / JC>([&](auto cc) {
             constexpr int jb = decltype(cc)::value * JC;
             float4 rv[JC][NI];
@@ -618,7 +622,10 @@ __device__ __forceinline__ void fast_epilogue(const GemmArgs& g, const GemmArgs&
         // Column side on the scalar unit (ncol0 is wave-uniform): every 32-column pair of a wave lies inside one head of one of q / k / v,
         // and -- select_epi checks qkv_dim % 128 == 0 -- ALL columns of a wave inside one of the three: ONE division per tile decides the
         // destination, the per-pair offsets are shifts of rem0 + 32 * pair.  32-bit ELEMENT offsets: q, k [b, head, t, d]: head * npad * 64 + d0;
-        // v^T [b, head, d, t]: (head * 64 + d0) * npad.  Row side: (b, t) of the wave's first row by one division, the lane's rows by adds.
+        // v^T [b, head, d, t]: (head * 64 + d0) * npad.  Row side: (b, t) of the wave's first row by one division, the lane's rows by adds and
+        // ONE select when an image has at least as many tokens as a wave has rows (ViT: 901), a per-row division otherwise (the text tower's
+        // <= 77 positions).  No loop: a `while (t >= ntok)` here made hipcc build exec-masked loops whose preheaders carry s_waitcnt vmcnt(0)
+        // -- four full drains of the epilogue's stores and of the next tile's DMA per tile (qkv 197 -> 223 us in the engine at B = 36).
         // (Round 3 decoded which / head per pair and b / t per row with run-time integer divisions inside the unrolled code: ~370 v_readlane
         // SGPR reloads and 221 64-bit address adds per wave tile, 24 us of a 252 us launch before a single store --
         // profiles/r04_epilogue_table.txt.)
@@ -628,13 +635,26 @@ __device__ __forceinline__ void fast_epilogue(const GemmArgs& g, const GemmArgs&
         const int mr0 = __builtin_amdgcn_readfirstlane(mrow0 < Mr ? mrow0 : Mr - 1);
         const int b0 = mr0 / ntok, t0 = mr0 - b0 * ntok;
         const uint32_t hn = (uint32_t)gk.qkv_heads * (uint32_t)npad;
+        auto row_bt = [&](int j, int& b, int& t) {            // (image, token) of this lane's row j * 16 + ml of the wave tile
+            if (ntok >= MI * 16) {
+                t = t0 + j * 16 + ml;
+                const bool wrap = t >= ntok;
+                t -= wrap ? ntok : 0;
+                b = b0 + (wrap ? 1 : 0);
+            } else {
+                int mm = mrow0 + j * 16 + ml;
+                mm = mm < Mr ? mm : Mr - 1;
+                b = mm / ntok;
+                t = mm - b * ntok;
+            }
+        };
         if (which < 2 || GEMM_EPI_ABL == 4) {
             uint16_t* base = (uint16_t*)(which == 2 ? gk.Cv : which ? gk.Ck : gk.C);         // wave-uniform: SGPR base + 32-bit lane offset
             const float qs = which == 0 && gk.qkv_qscale != 0.f ? gk.qkv_qscale : 1.0f;      // q carries the softmax scale
             static_for<0, MI>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                int b = b0, t = t0 + j * 16 + ml;
-                while (t >= ntok) { t -= ntok; ++b; }                  // at most once for ntok >= 80
+                int b, t;
+                row_bt(j, b, t);
                 const uint32_t rq = ((uint32_t)b * hn + (uint32_t)t) * 64u + (uint32_t)cw;
                 const bool ok = mrow0 + j * 16 + ml < Mr;
                 static_for<0, NI / 2>([&](auto pc) {
@@ -655,8 +675,8 @@ __device__ __forceinline__ void fast_epilogue(const GemmArgs& g, const GemmArgs&
             uint16_t* base = (uint16_t*)gk.Cv;
             static_for<0, MI>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
-                int b = b0, t = t0 + j * 16 + ml;
-                while (t >= ntok) { t -= ntok; ++b; }
+                int b, t;
+                row_bt(j, b, t);
                 const uint32_t rv = (uint32_t)b * hn * 64u + (uint32_t)t + (uint32_t)(r16 * 4) * (uint32_t)npad;
                 const bool ok = mrow0 + j * 16 + ml < Mr;
                 static_for<0, NI / 2>([&](auto pc) {
@@ -716,14 +736,9 @@ using CfgHuge = TileCfg<256, 256, 4, 2, 2, 1>;     // half the operand bytes per
 // Row config: one workgroup owns complete 512-wide output rows (fused head1 + L2-norm + fp16 casts);
 // 128 accumulator registers per lane, one wave per SIMD, 152 KB of rings + 1 KB reduction scratch
 using CfgRow = TileCfg<64, 512, 1, 4, 2, 1>;
-// Round-4 tile probes for the ViT block's GEMMs (LSEG_GEMM_TILE = 7 / 8 / 9, tools/epilogue_table.py): what a tile that leaves registers
-// for a residual prefetch / deferred stores costs in the K-loop.
-//   Wide   256x128, 4x2 waves (64x64 per wave, 64 accumulators),  128 KB LDS, two waves per SIMD
-//   Wide4  256x128, 2x2 waves (128x64 per wave, 128 accumulators), 128 KB LDS, ONE wave per SIMD (512 registers)
-//   Huge4  256x256, 2x2 waves (128x128 per wave, 256 accumulators), 160 KB LDS, one wave per SIMD
-using CfgWide = TileCfg<256, 128, 4, 2, 2, 1>;
-using CfgWide4 = TileCfg<256, 128, 2, 2, 2, 1>;
-using CfgHuge4 = TileCfg<256, 256, 2, 2, 2, 1>;
+// (Round 4 measured three more shapes for the ViT block's GEMMs -- 256x128 on 8 waves, 256x128 and 256x256 on 4 waves (one per SIMD, 512
+// registers) -- as carriers of a residual prefetch / deferred stores: K-loop alone +11 ... +33 % / +15 ... +22 % / +40 % against this
+// 256x256 8-wave tile; removed again, profiles/r04_gemm_experiments.txt.)
 
 // Counted waits go through the BUILTIN, not inline asm: SIInsertWaitcnts understands a pre-existing
 // s_waitcnt and keeps its own scoreboard consistent.  An opaque asm wait left it believing that
@@ -1106,6 +1121,9 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
     static_for<0, A_SPW>([&](auto qc) { issue_q(std::integral_constant<int, W_SPW + decltype(qc)::value>{}); });   // A(1)
     static_for<0, CFG::Q_B2>([&](auto qc) { issue_q(qc); });                               // head of {W(1), A(2)}
 
+#ifdef GEMM_PRIO_YOUNG      // probe build (make probes): static priority for the second-dispatched half of an 8-wave workgroup (MI355X_MICROARCH "two waves per SIMD", item 4)
+    if (NW == 8 && w >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     constexpr bool BIAS_PREFETCH = MI * NI <= 16;
     float4 biasv[EPI != EPI_GENERIC ? NI : 1];
     for (; tile < tile_end; tile += wpx) {
@@ -1186,6 +1204,11 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
                     biasv[i] = *reinterpret_cast<const float4*>(g.bias + (EPI == EPI_PIX16 ? (n0c + wn * WN + i * 16) % g.ps_C : n0c + wn * WN + i * 16) + (lane >> 4) * 4);
+                // ONE explicit wait (a builtin: the compiler's scoreboard sees it).  Left to the compiler, an epilogue whose stores sit in
+                // per-row conditional blocks (EPI_QKV16) got an s_waitcnt vmcnt(0) at the top of EVERY block -- "the bias may still be
+                // pending on the path that skipped the previous block" -- and each of those also waits for the previous block's stores:
+                // four store round trips per tile, attn.qkv 197 -> 223 us in the engine at B = 36 (profiles/r04_gemm_experiments.txt).
+                wait_vmcnt<0>();
             }
             if constexpr (GEMM_EPI_ABL == 2) {          // attribution build: the K-loop alone (accumulators kept live)
 #pragma unroll
@@ -1278,11 +1301,6 @@ int pick_tile(const GemmArgs& g, hipStream_t stream) {
     if (g.tile_hint == 2 || g.tile_hint == 6) pick = g.tile_hint;
     if (force) pick = force;
     if (pick == 6 && (g.N % 256) != 0) pick = 2;      // the specialised epilogues write whole tile rows: N must be a multiple of BN
-    if constexpr (!CONV && !RELU_IN && TAG == 0 && (EPI == EPI_RES32 || EPI == EPI_QKV16 || EPI == EPI_LIN16_GELU)) {
-        if (force == 7 && (g.N % 128) == 0) return launch_one<T, CfgWide, false, false, EPI, 0>(g, stream);
-        if (force == 9 && (g.N % 128) == 0) return launch_one<T, CfgWide4, false, false, EPI, 0>(g, stream);
-        if (force == 8 && (g.N % 256) == 0) return launch_one<T, CfgHuge4, false, false, EPI, 0>(g, stream);
-    }
     if constexpr (EPI != EPI_GENERIC) {
         if (pick == 6) return launch_one<T, CfgHuge, CONV, RELU_IN, EPI, TAG>(g, stream);
     }
