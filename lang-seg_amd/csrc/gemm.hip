@@ -485,11 +485,11 @@ __device__ __forceinline__ void fast_epilogue(const GemmArgs& g, const GemmArgs&
         // every residual load of the sub-tile is in flight before the first store (in place: x += f(x))
         float* cbase = (float*)g.C + ncol0 + r16 * 4;
         const float* rbase = (const float*)g.res + ncol0 + r16 * 4;
-#ifndef GEMM_RES32_REGS
-#define GEMM_RES32_REGS 64
-#endif
-        constexpr int JC0 = GEMM_RES32_REGS / 4 / NI;
-        constexpr int JC = JC0 < 1 ? 1 : (JC0 > MI ? MI : JC0);      // rows per chunk: <= GEMM_RES32_REGS registers of prefetched residual
+        // rows per chunk: <= 32 registers of prefetched residual.  With 64 the 256x256 instance spilled 156 bytes, and the reloads sat in
+        // the K-loop's tile-advance paths behind s_waitcnt vmcnt(0) -- two drains of the DMA ring per tile.  A/B in the engine (B = 36, fp16,
+        // lease F): attn.proj 124.4 -> 108.3 us, mlp.fc2 279.4 -> 261.3 us per launch.
+        constexpr int JC0 = 32 / 4 / NI;
+        constexpr int JC = JC0 < 1 ? 1 : (JC0 > MI ? MI : JC0);
         static_for<0, MI / JC>([&](auto cc) {
             constexpr int jb = decltype(cc)::value * JC;
             float4 rv[JC][NI];
@@ -1121,9 +1121,6 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
     static_for<0, A_SPW>([&](auto qc) { issue_q(std::integral_constant<int, W_SPW + decltype(qc)::value>{}); });   // A(1)
     static_for<0, CFG::Q_B2>([&](auto qc) { issue_q(qc); });                               // head of {W(1), A(2)}
 
-#ifdef GEMM_PRIO_YOUNG      // probe build (make probes): static priority for the second-dispatched half of an 8-wave workgroup (MI355X_MICROARCH "two waves per SIMD", item 4)
-    if (NW == 8 && w >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
     constexpr bool BIAS_PREFETCH = MI * NI <= 16;
     float4 biasv[EPI != EPI_GENERIC ? NI : 1];
     for (; tile < tile_end; tile += wpx) {
