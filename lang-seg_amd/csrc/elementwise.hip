@@ -2,7 +2,6 @@
 // readout concat, bilinear x2 (NHWC bf16 and NCHW fp32 planes), the L2-norm/scale/fp16 cast
 // in front of the correlation GEMM, text embedding / pooling / normalisation, one-off weight
 // repacking.  All are coalesced 16-byte-per-lane streams (cdna_hip_programming.md G2/G13).
-#include <cstdlib>
 #include "ops.h"
 #include "../../include/lseg_hip.h"
 
@@ -669,33 +668,27 @@ __global__ __launch_bounds__(256) void upsample2x_planes_scaled_kernel(const flo
 // (2H, 2W) logits only ever exist as a band in LDS.  Bit-identical to upsample2x_planes_scaled + upsample2x_planes (bilerp).
 // A block = one plane x the output rows whose upper source row lies in a band of LB low rows: phase 1 stages the R rows under the band
 // [Rr], phase 2 the band of (2H, 2W) logits, LB + 1 rows [Lr]: low = fp16(scale * bilerp(R)), phase 3 writes the output rows.
-// Phase 3 forms (MODE; round 4, tools/upsample_bench.py, profiles/r04_head_kernels.txt -- a fill of the same 4.98 GB runs at 6.9 TB/s,
-// this kernel at 3.8: it is not write-bound):
-//   0  direct: bilerp() of four Lr taps per output pixel (16 ds_read_b32 + ~65 VALU instructions per 16 bytes stored)
-//   1  rolling rows: a thread owns one group of 4 output columns and walks CONSECUTIVE output rows, keeping the horizontal interpolation
-//      h = fma(lx, b, (1 - lx) a) of its two current source rows in registers: a new h row only when the source row advances (every
-//      second output row) -- 1/4 of the horizontal work and LDS reads, no further LDS image, same occupancy
-//   2  separable through LDS: all h rows of the band staged as a third image [Hh], vertical pass with aligned ds_read_b128 (49 KB of LDS
-//      per block: 3 blocks per CU instead of 7 -- measured SLOWER than 0: 1466 vs 1379 us at B = 36, lease F)
-// Same operations in the same association as bilerp() in every form: same bits (test_one_pass_x4_upsample_equals_its_two_stages).
-// Band height: 16 low rows per block measured best for form 0 (8 -> 16: 1501 -> 1389 us at B = 36, fewer re-staged boundary rows).
+// Phase 3, ROLLING ROWS (round 4): a thread owns one group of 4 output columns and walks CONSECUTIVE output rows, keeping the horizontal
+// interpolation h = fma(lx, b, (1 - lx) a) -- the first half of bilerp() -- of its two current source rows in registers; a new h row is
+// formed only when the source row advances (every second output row): a quarter of the horizontal work and of the LDS reads of the
+// direct form (bilerp() of four Lr taps per output pixel: 16 ds_read_b32 + ~65 VALU instructions per 16 bytes stored), no further LDS
+// image, same occupancy, same operations in the same association = same bits (test_one_pass_x4_upsample_equals_its_two_stages).
+// tools/upsample_bench.py, B = 36, one box (profiles/r04_head_kernels.txt): direct 1372 / 1258 us, rolling 1184 / 1168 us (4.5 TB/s;
+// B = 4: 115-118 -> 96-102 us); plain instead of non-temporal stores 1192 (B = 4: 136); rolling on a band of 8 rows 1268; a third LDS
+// image of all h rows + aligned ds_read_b128 (49 KB of LDS: 3 blocks per CU instead of 7) 1354-1466.  A fill of the same 4.98 GB runs at
+// 6.9 TB/s (tools/fill_bench.py): the kernel is still bound by its phase structure (three barriers, global -> LDS -> LDS -> HBM), not by
+// the write.
 constexpr int UPS4_LB = 16;
 __device__ __forceinline__ float hlerp(float a, float b, float l) { return __builtin_fmaf(l, b, (1.f - l) * a); }   // bilerp()'s h0 / h1
-template <bool NT>
-__device__ __forceinline__ void ups_store4(float* p, const f32x4_t v) {
-    if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(p));     // written once, never re-read by the engine
-    else *reinterpret_cast<f32x4_t*>(p) = v;
-}
-template <int LB, int MODE, bool NT>
+template <int LB>
 __global__ __launch_bounds__(256) void upsample4x_planes_scaled_kernel(const float* __restrict__ in, const float* __restrict__ scale,
                                                                        float* __restrict__ out, int P, int K, int H, int W) {
-    extern __shared__ float sm[];             // MODE 0 / 1: Rr [<= LB/2 + 4][W] | Lr [LB + 1][2W];  MODE 2: Hh [LB + 1][4W] (head = Rr) | Lr
+    extern __shared__ float sm[];             // Rr [<= LB/2 + 4][W] | Lr [LB + 1][2W]
     const int Hl = 2 * H, Wl = 2 * W, Ho = 2 * Hl, Wo = 2 * Wl, w4 = Wo / 4, wl4 = Wl / 4, bands = (Hl + LB - 1) / LB;
     const int pl = blockIdx.x / bands, ya = (blockIdx.x - pl * bands) * LB;
     const int yb = ya + LB < Hl - 1 ? ya + LB : Hl - 1;        // last low row read (the band's rows + the next one)
     float* Rr = sm;
-    float* Hh = sm;
-    float* Lr = sm + (MODE == 2 ? (LB + 1) * Wo : (LB / 2 + 4) * W);
+    float* Lr = sm + (LB / 2 + 4) * W;
     const float ry1 = (float)(H - 1) / (float)(Hl - 1), rx1 = (float)(W - 1) / (float)(Wl - 1);
     const int r_lo = ups_stage_r(in, Rr, pl, H, W, ry1, ya, yb);
     __syncthreads();
@@ -713,97 +706,54 @@ __global__ __launch_bounds__(256) void upsample4x_planes_scaled_kernel(const flo
             }
         }
     }
-    __syncthreads();              // Lr complete, Rr dead
+    __syncthreads();
     const float ry = (float)(Hl - 1) / (float)(Ho - 1), rx = (float)(Wl - 1) / (float)(Wo - 1);
-    const int nsub = w4 < 256 ? 256 / w4 : 1;
     // output rows of this band: y0(yo) = floor(ry * yo) in [ya, ya + LB)
     int yo_first = (int)ceilf((float)ya / ry);
     while (yo_first > 0 && (int)(ry * (float)(yo_first - 1)) >= ya) --yo_first;
     while ((int)(ry * (float)yo_first) < ya) ++yo_first;
     int yo_end = yo_first;
     while (yo_end < Ho && (int)(ry * (float)yo_end) < ya + LB) ++yo_end;
-    if constexpr (MODE == 2) {
-        const int nrow = yb - ya + 1;
-        for (int x4 = threadIdx.x % (w4 < 256 ? w4 : 256); x4 < w4; x4 += 256) {      // horizontal pass: a thread keeps ONE column group
-            const int sub = w4 < 256 ? threadIdx.x / w4 : 0;
-            if (sub >= nsub) break;
-            const ColTerms t = col_terms4(rx, x4, Wl);
-            for (int r = sub; r < nrow; r += nsub) {
-                const float* q = Lr + r * Wl;
-                *reinterpret_cast<float4*>(Hh + r * Wo + x4 * 4) =
-                    make_float4(hlerp(q[t.x0[0]], q[t.x1[0]], t.lx[0]), hlerp(q[t.x0[1]], q[t.x1[1]], t.lx[1]),
-                                hlerp(q[t.x0[2]], q[t.x1[2]], t.lx[2]), hlerp(q[t.x0[3]], q[t.x1[3]], t.lx[3]));
-            }
-        }
-        __syncthreads();
-    }
+    const int nsub = w4 < 256 ? 256 / w4 : 1;
+    const int per = (yo_end - yo_first + nsub - 1) / nsub;       // sub-group `sub` takes a contiguous share of the band's output rows
     for (int x4 = threadIdx.x % (w4 < 256 ? w4 : 256); x4 < w4; x4 += 256) {
         const int sub = w4 < 256 ? threadIdx.x / w4 : 0;
         if (sub >= nsub) break;
-        if constexpr (MODE == 0) {
-            const ColTerms t = col_terms4(rx, x4, Wl);
-            for (int yo = yo_first + sub; yo < yo_end; yo += nsub) {
-                int y0, y1;
-                float ly;
-                src_tap(ry, yo, Hl, y0, y1, ly);
-                const float* q0 = Lr + (y0 - ya) * Wl;
-                const float* q1 = Lr + (y1 - ya) * Wl;
-                float o[4];
+        const ColTerms t = col_terms4(rx, x4, Wl);
+        const int ys = yo_first + sub * per, ye = ys + per < yo_end ? ys + per : yo_end;
+        float h0[4] = {0.f, 0.f, 0.f, 0.f}, h1[4] = {0.f, 0.f, 0.f, 0.f};
+        int c0 = -1, c1 = -1;                                // the source rows h0 / h1 hold
+        auto hrow = [&](int y, float (&h)[4]) {
+            const float* q = Lr + (y - ya) * Wl;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = bilerp(q0[t.x0[e]], q0[t.x1[e]], q1[t.x0[e]], q1[t.x1[e]], t.lx[e], ly);
-                ups_store4<NT>(out + ((size_t)pl * Ho + yo) * Wo + x4 * 4, f32x4_t{o[0], o[1], o[2], o[3]});
-            }
-        } else if constexpr (MODE == 1) {
-            // sub-group `sub` takes a contiguous share of the band's output rows
-            const ColTerms t = col_terms4(rx, x4, Wl);
-            const int per = (yo_end - yo_first + nsub - 1) / nsub;
-            const int ys = yo_first + sub * per, ye = ys + per < yo_end ? ys + per : yo_end;
-            float h0[4] = {0.f, 0.f, 0.f, 0.f}, h1[4] = {0.f, 0.f, 0.f, 0.f};
-            int c0 = -1, c1 = -1;                            // source rows h0 / h1 hold
-            auto hrow = [&](int y, float (&h)[4]) {
-                const float* q = Lr + (y - ya) * Wl;
+            for (int e = 0; e < 4; ++e) h[e] = hlerp(q[t.x0[e]], q[t.x1[e]], t.lx[e]);
+        };
+        for (int yo = ys; yo < ye; ++yo) {
+            int y0, y1;
+            float ly;
+            src_tap(ry, yo, Hl, y0, y1, ly);
+            if (y0 != c0) {
+                if (y0 == c1) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h[e] = hlerp(q[t.x0[e]], q[t.x1[e]], t.lx[e]);
-            };
-            for (int yo = ys; yo < ye; ++yo) {
-                int y0, y1;
-                float ly;
-                src_tap(ry, yo, Hl, y0, y1, ly);
-                if (y0 != c0) {
-                    if (y0 == c1) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) h0[e] = h1[e];
-                    } else {
-                        hrow(y0, h0);
-                    }
-                    c0 = y0;
+                    for (int e = 0; e < 4; ++e) h0[e] = h1[e];
+                } else {
+                    hrow(y0, h0);
                 }
-                if (y1 != c1) {
-                    if (y1 == c0) {                        // the clamped last row: both taps on one source row
+                c0 = y0;
+            }
+            if (y1 != c1) {
+                if (y1 == c0) {                                // the clamped last row: both taps on one source row
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) h1[e] = h0[e];
-                    } else {
-                        hrow(y1, h1);
-                    }
-                    c1 = y1;
+                    for (int e = 0; e < 4; ++e) h1[e] = h0[e];
+                } else {
+                    hrow(y1, h1);
                 }
-                const float wy = 1.f - ly;
-                ups_store4<NT>(out + ((size_t)pl * Ho + yo) * Wo + x4 * 4,
-                               f32x4_t{__builtin_fmaf(ly, h1[0], wy * h0[0]), __builtin_fmaf(ly, h1[1], wy * h0[1]),
-                                       __builtin_fmaf(ly, h1[2], wy * h0[2]), __builtin_fmaf(ly, h1[3], wy * h0[3])});
+                c1 = y1;
             }
-        } else {
-            for (int yo = yo_first + sub; yo < yo_end; yo += nsub) {
-                int y0, y1;
-                float ly;
-                src_tap(ry, yo, Hl, y0, y1, ly);
-                const float4 h0 = *reinterpret_cast<const float4*>(Hh + (y0 - ya) * Wo + x4 * 4);
-                const float4 h1 = *reinterpret_cast<const float4*>(Hh + (y1 - ya) * Wo + x4 * 4);
-                const float wy = 1.f - ly;
-                ups_store4<NT>(out + ((size_t)pl * Ho + yo) * Wo + x4 * 4,
-                               f32x4_t{__builtin_fmaf(ly, h1.x, wy * h0.x), __builtin_fmaf(ly, h1.y, wy * h0.y),
-                                       __builtin_fmaf(ly, h1.z, wy * h0.z), __builtin_fmaf(ly, h1.w, wy * h0.w)});
-            }
+            const float wy = 1.f - ly;
+            const f32x4_t ov = {__builtin_fmaf(ly, h1[0], wy * h0[0]), __builtin_fmaf(ly, h1[1], wy * h0[1]),
+                                __builtin_fmaf(ly, h1[2], wy * h0[2]), __builtin_fmaf(ly, h1[3], wy * h0[3])};
+            __builtin_nontemporal_store(ov, reinterpret_cast<f32x4_t*>(out + ((size_t)pl * Ho + yo) * Wo) + x4);     // written once, never re-read by the engine
         }
     }
 }
@@ -2623,21 +2573,9 @@ int launch_upsample2x_planes_scaled(const float* in_padded, const float* scale, 
 // R planes -> the full-resolution logits in one pass (x2 with the per-pixel scale and fp16 rounding, then output_conv's x2)
 int launch_upsample4x_planes_scaled(const float* in_padded, const float* scale, float* out, int P, int K, int H, int W, hipStream_t st) {
     if (W % 2 != 0) return set_error(LSEG_ERR_UNSUPPORTED, "scaled upsample: W=%d must be even", W);
-    // tools/upsample_bench.py: LSEG_UPS4_VARIANT = 10 * form + (1: plain instead of non-temporal stores) + (100: band of 8 low rows)
-    const char* ev = getenv("LSEG_UPS4_VARIANT");
-    const int var = ev ? atoi(ev) : 0;
-    const int mode = (var / 10) % 10, lb = var >= 100 ? 8 : UPS4_LB;
-    const bool nt = (var % 10) == 0;
-    const int bands = (2 * H + lb - 1) / lb;
-    const size_t lds = (mode == 2 ? (size_t)(lb + 1) * 4 * W + (size_t)(lb + 1) * 2 * W : (size_t)(lb / 2 + 4) * W + (size_t)(lb + 1) * 2 * W) * sizeof(float);
-    const dim3 grid((unsigned)P * bands), blk(256);
-#define UPS4(LBV, MODEV, NTV) hipLaunchKernelGGL((upsample4x_planes_scaled_kernel<LBV, MODEV, NTV>), grid, blk, lds, st, in_padded, scale, out, P, K, H, W)
-#define UPS4_M(LBV, MODEV) do { if (nt) UPS4(LBV, MODEV, true); else UPS4(LBV, MODEV, false); } while (0)
-#define UPS4_L(MODEV) do { if (lb == 8) UPS4_M(8, MODEV); else UPS4_M(UPS4_LB, MODEV); } while (0)
-    if (mode == 1) UPS4_L(1); else if (mode == 2) UPS4_L(2); else UPS4_L(0);
-#undef UPS4_L
-#undef UPS4_M
-#undef UPS4
+    const int bands = (2 * H + UPS4_LB - 1) / UPS4_LB;
+    const size_t lds = ((size_t)(UPS4_LB / 2 + 4) * W + (size_t)(UPS4_LB + 1) * 2 * W) * sizeof(float);
+    hipLaunchKernelGGL((upsample4x_planes_scaled_kernel<UPS4_LB>), dim3((unsigned)P * bands), dim3(256), lds, st, in_padded, scale, out, P, K, H, W);
     CHECK_LAUNCH();
     return 0;
 }

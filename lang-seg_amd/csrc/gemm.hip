@@ -488,7 +488,8 @@ __device__ __forceinline__ void fast_epilogue(const GemmArgs& g, const GemmArgs&
         // rows per chunk: <= 32 registers of prefetched residual.  With 64 the 256x256 instance spilled 156 bytes, and the reloads sat in
         // the K-loop's tile-advance paths behind s_waitcnt vmcnt(0) -- two drains of the DMA ring per tile.  A/B in the engine (B = 36, fp16,
         // lease F): attn.proj 124.4 -> 108.3 us, mlp.fc2 279.4 -> 261.3 us per launch.
-        constexpr int JC0 = 32 / 4 / NI;
+        // (the 64-accumulator tiles keep 64: they have the registers, and a bigger batch of loads per wait)
+        constexpr int JC0 = (MI * NI > 16 ? 32 : 64) / 4 / NI;
         constexpr int JC = JC0 < 1 ? 1 : (JC0 > MI ? MI : JC0);
         static_for<0, MI / JC>([&](auto cc) {
             constexpr int jb = decltype(cc)::value * JC;

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """The one-pass x4 logits upsample (the 4.98 GB write of a B = 36 forward) standalone: time, GB/s on the algorithmic bytes, and bit
-equality with the two-stage form.  LSEG_UPS4_VARIANT (read per launch) = 10 * form + (1: plain instead of non-temporal stores) + (100: band
-of 8 low rows); forms: 0 direct bilerp per pixel, 1 rolling rows in registers, 2 separable through a third LDS image.
-  python tools/upsample_bench.py 36 4 [-- variant ...]"""
+equality with the two-stage form (round 4's phase-3 forms -- direct / rolling rows / separable through LDS, plain / non-temporal stores,
+band 8 / 16 -- were compared with this tool behind a launch-time switch; figures in profiles/r04_head_kernels.txt, the rolling form is kept).
+  python tools/upsample_bench.py 36 4"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "lang-seg_amd"))
@@ -11,12 +11,8 @@ from lseg_hip import _lib
 lib = _lib.load()
 P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-argv = sys.argv[1:]
-variants = [v for v in argv[argv.index("--") + 1:]] if "--" in argv else [os.environ.get("LSEG_UPS4_VARIANT", "0")]
-batches = [int(v) for v in (argv[:argv.index("--")] if "--" in argv else argv)] or [36]
-for variant in variants:
-  os.environ["LSEG_UPS4_VARIANT"] = variant
-  for B in batches:
+for _ in (0,):
+  for B in [int(v) for v in sys.argv[1:]] or [36]:
       K, H, W = 150, 120, 120
       g = torch.Generator(device="cuda").manual_seed(0)
       R = torch.zeros((B * K, H + 2, W + 2), device="cuda")
@@ -37,5 +33,5 @@ for variant in variants:
           _lib.check(lib.lseg_op_upsample4x_planes_scaled(P(R), P(sc), P(ref), B, K, H, W, 1, P(low), st))
           torch.cuda.synchronize()
           same = bool(torch.equal(ref, out))
-      print(f"variant={os.environ.get('LSEG_UPS4_VARIANT', 'default')} B={B}: {us:.1f} us -> {nbytes / us / 1e3:.0f} GB/s ({nbytes / us / 1e3 / 8000:.3f} of 8 TB/s)"
+      print(f"B={B}: {us:.1f} us -> {nbytes / us / 1e3:.0f} GB/s ({nbytes / us / 1e3 / 8000:.3f} of 8 TB/s)"
             + (f"; equals the two-stage form bit for bit: {same}" if same is not None else ""), flush=True)
