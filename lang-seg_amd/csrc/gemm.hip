@@ -780,6 +780,21 @@ __device__ __forceinline__ i32x4_t ds_read_tr16_pair(const char* p0, const char*
     return u.v;
 }
 
+// The same two transpose reads as INLINE ASM (lds = the wave-relative LDS byte address, IMM0 / IMM1 immediate offsets).  Through the builtin
+// hipcc's s_waitcnt insertion treats every ds_read_b64_tr_b16 as a possible reader of ANY pending direct-to-LDS load and puts
+// s_waitcnt vmcnt(0) in front of the first one of each MFMA block: the K-major kernel drained its whole DMA ring twice per K-step (the
+// row-major kernels' plain ds_read_b128 do not draw that wait).  The asm form is invisible to that pass -- the K-loop's own counted vmcnt +
+// barrier already order the reads behind the loads they need -- and to the lgkmcnt bookkeeping as well: the kernel waits lgkmcnt(0) itself
+// before the MFMA block that consumes the fragments (the reads are issued a block earlier, interleaved with that block's first MFMAs).
+template <int IMM0, int IMM1>
+__device__ __forceinline__ i32x4_t ds_read_tr16_pair_asm(uint32_t lds) {
+    typedef int v2i_t __attribute__((ext_vector_type(2)));
+    v2i_t lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(lds), "n"(IMM0));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(lds), "n"(IMM1));
+    return i32x4_t{lo[0], lo[1], hi[0], hi[1]};
+}
+
 template <typename T, typename CFG, bool CONV, bool RELU_IN, int EPI, int TAG>
 __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(const GemmArgs g) {
     constexpr int BM = CFG::BM, BN = CFG::BN, NS = CFG::NS, NW = CFG::NW;
@@ -1010,24 +1025,34 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
 #pragma unroll
         for (int i = 0; i < NI; ++i) w_tr[i] = (kg * 8 + (ti >> 2)) * (BN * 2) + ((((wn * WN) >> 4) + i) ^ gl) * 32 + (ti & 3) * 8;
     }
-    auto ldfrag_t = [&](const char* st, int off, int khalf, int pitch) {
-        return ds_read_tr16_pair(st + off + (khalf * 32) * pitch, st + off + (khalf * 32 + 4) * pitch);
+    // K-major fragments through the asm transpose reads (see ds_read_tr16_pair_asm) unless a ReLU runs on the fragments right after the read
+    // (that form needs the compiler's own lgkmcnt tracking; the training step hands in materialised ReLU maps and never takes it)
+    constexpr bool TR_ASM = KMAJ && !RELU_IN;
+    const uint32_t lds0 = TR_ASM ? (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem) : 0u;
+    auto ldfrag_t = [&](const char* st, int off, auto khc, auto pitchc) {
+        constexpr int khalf = decltype(khc)::value, pitch = decltype(pitchc)::value;
+        if constexpr (TR_ASM) return ds_read_tr16_pair_asm<(khalf * 32) * pitch, (khalf * 32 + 4) * pitch>(lds0 + (uint32_t)(st - smem) + (uint32_t)off);
+        else return ds_read_tr16_pair(st + off + (khalf * 32) * pitch, st + off + (khalf * 32 + 4) * pitch);
     };
-    // kh = K-half of the 64-deep stage (a literal 0 / 1 at every call site)
-    auto lda = [&](const char* st, int j, int kh) {
-        if constexpr (KMAJ) return ldfrag_t(st, a_tr[j], kh, BM * 2);
+    // khc = K-half of the 64-deep stage (std::integral_constant 0 / 1)
+    auto lda = [&](const char* st, int j, auto khc) {
+        constexpr int kh = decltype(khc)::value;
+        if constexpr (KMAJ) return ldfrag_t(st, a_tr[j], khc, std::integral_constant<int, BM * 2>{});
         i32x4_t v = ldfrag(st + abase_off + j * 2048 + (kh ? foff1 : foff0));
         if (RELU_IN) v = relu_frag(v);
         return v;
     };
-    auto ldw = [&](const char* st, int i, int kh) {
+    auto ldw = [&](const char* st, int i, auto khc) {
+        constexpr int kh = decltype(khc)::value;
         if constexpr (KMAJ) {
-            i32x4_t v = ldfrag_t(st, w_tr[i], kh, BN * 2);
+            i32x4_t v = ldfrag_t(st, w_tr[i], khc, std::integral_constant<int, BN * 2>{});
             if (RELU_IN) v = relu_frag(v);                    // K-major conv wgrad: the W operand is the conv input, read through a ReLU
             return v;
         }
         return ldfrag(st + wbase_off + i * 2048 + (kh ? foff1 : foff0));
     };
+    using kh0_t = std::integral_constant<int, 0>;
+    using kh1_t = std::integral_constant<int, 1>;
 
     unsigned long long tmark[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // dbg&4: cycles in {vm wait, barrier, epilogue, MFMA blocks}
     unsigned long long kc0 = 0, kr0 = 0;                       // dbg&4: whole-kernel s_memtime / s_memrealtime (100 MHz)
@@ -1047,6 +1072,10 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
         // partner waiting at the barrier -- then keeps the matrix pipe fed; in groups of 4 MFMAs followed by
         // 3-5 loads the pipe drained after every group (a lone wave reached ~65% of the MFMA rate).
         // ---- block A: NI*MI MFMAs; ops = k-half-1 fragment reads (A fragments first), then Q_A DMA issues
+        if constexpr (TR_ASM) {                        // the k-half-0 fragments (asm reads of the previous block B2 / the prologue) have arrived
+            wait_lgkmcnt0();
+            __builtin_amdgcn_sched_barrier(0);         // (no MFMA of this block may be scheduled above the wait: the compiler sees no dependence)
+        }
         {
             constexpr int NMF = NI * MI, OPS = NI + MI + CFG::Q_A;
             static_for<0, NMF>([&](auto tc) {
@@ -1054,8 +1083,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
                 acc[i][j] = mm(wf0[i], af0[j], acc[i][j]);
                 static_for<(t * OPS) / NMF, ((t + 1) * OPS) / NMF>([&](auto oc) {
                     constexpr int o = decltype(oc)::value;
-                    if constexpr (o < MI) af1[o] = lda(sa, o, 1);
-                    else if constexpr (o < MI + NI) wf1[o - MI] = ldw(sw, o - MI, 1);
+                    if constexpr (o < MI) af1[o] = lda(sa, o, kh1_t{});
+                    else if constexpr (o < MI + NI) wf1[o - MI] = ldw(sw, o - MI, kh1_t{});
 #ifndef GEMM_ABL_NODMA
                     else issue_q(std::integral_constant<int, CFG::Q_B2 + o - MI - NI>{});
 #endif
@@ -1077,6 +1106,10 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
             if ((g.dbg & 4)) t3 = __builtin_readcyclecounter();
         };
         if (NW == 8 && early) sync();
+        if constexpr (TR_ASM) {                        // the k-half-1 fragments (asm reads of block A) have arrived
+            wait_lgkmcnt0();
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // ---- block B1
         static_for<0, NI / 2>([&](auto ic) {
             constexpr int i = decltype(ic)::value;
@@ -1093,8 +1126,8 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
                 acc[i][j] = mm(wf1[i], af1[j], acc[i][j]);
                 static_for<(t * OPS) / NMF, ((t + 1) * OPS) / NMF>([&](auto oc) {
                     constexpr int o = decltype(oc)::value;
-                    if constexpr (o < MI) af0[o] = lda(nxa, o, 0);
-                    else if constexpr (o < MI + NI) wf0[o - MI] = ldw(nxw, o - MI, 0);
+                    if constexpr (o < MI) af0[o] = lda(nxa, o, kh0_t{});
+                    else if constexpr (o < MI + NI) wf0[o - MI] = ldw(nxw, o - MI, kh0_t{});
 #ifndef GEMM_ABL_NODMA
                     else issue_q(std::integral_constant<int, o - MI - NI>{});
 #endif
@@ -1116,9 +1149,9 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int i = 0; i < NI; ++i) wf0[i] = ldw(smem + W_RING_OFF, i, 0);
+    for (int i = 0; i < NI; ++i) wf0[i] = ldw(smem + W_RING_OFF, i, kh0_t{});
 #pragma unroll
-    for (int j = 0; j < MI; ++j) af0[j] = lda(smem, j, 0);
+    for (int j = 0; j < MI; ++j) af0[j] = lda(smem, j, kh0_t{});
     static_for<0, A_SPW>([&](auto qc) { issue_q(std::integral_constant<int, W_SPW + decltype(qc)::value>{}); });   // A(1)
     static_for<0, CFG::Q_B2>([&](auto qc) { issue_q(qc); });                               // head of {W(1), A(2)}
 
