@@ -1060,17 +1060,6 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
 
     int ca = 0, cw = 0;                                  // ring slots of the K-step being computed
     const bool early = NW == 8 && w >= 4 && !(g.dbg & 8);   // see sync() below (dbg bit 3: A/B switch, tools)
-    // FIRST barrier of a tile behind a specialised epilogue (128-accumulator tiles).  vmcnt counts loads and stores in issue order, so the
-    // plain count -- "everything but the last A_SPW operations has completed" -- makes that barrier wait for ALL of the previous tile's
-    // epilogue stores, although what it needs (W(1), A(1) of the new tile) was issued BEFORE the epilogue.  The epilogue of a FULL tile
-    // (no row beyond M: every store instruction issues) is at least EPI_OPS vector-memory instructions -- NI bias loads, the residual loads,
-    // the stores -- so that barrier may leave A_SPW + EPI_OPS operations in flight: the stores get one more K-step to drain (the next
-    // barrier needs W(2), issued behind them).  A lower bound only: more operations in flight than counted would be a race.
-    constexpr int EPI_OPS0 = (MI * NI <= 16 || KMAJ || CONV || GEMM_EPI_ABL != 0) ? 0
-                           : (EPI == EPI_LIN16 || EPI == EPI_LIN16_GELU || EPI == EPI_LIN16_F16 || EPI == EPI_QKV16) ? NI + MI * NI / 2
-                           : EPI == EPI_RES32 ? NI + 2 * MI * NI : 0;
-    constexpr int EPI_OPS = EPI_OPS0 > 59 - A_SPW ? 59 - A_SPW : EPI_OPS0;          // vmcnt is a 6-bit counter
-    bool relax_first = false;                            // the next barrier is the first one behind a full tile's epilogue
     auto step = [&]() {
         const char* sa = smem + ca * A_BYTES;                                   // this step's panels
         const char* sw = smem + W_RING_OFF + cw * CFG::W_BYTES;
@@ -1111,12 +1100,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
         auto sync = [&]() {
             if ((g.dbg & 4)) t1 = __builtin_readcyclecounter();
             wait_lgkmcnt0();
-            if constexpr (EPI_OPS > 0) {
-                if (relax_first) wait_vmcnt<A_SPW + EPI_OPS>(); else wait_vmcnt<A_SPW>();
-                relax_first = false;
-            } else {
-                wait_vmcnt<A_SPW>();
-            }
+            wait_vmcnt<A_SPW>();
             if ((g.dbg & 4)) t2 = __builtin_readcyclecounter();
             __builtin_amdgcn_s_barrier();
             if ((g.dbg & 4)) t3 = __builtin_readcyclecounter();
@@ -1289,7 +1273,6 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
         }
         }
         }
-        if constexpr (EPI_OPS > 0) relax_first = pm0 + BM <= g.M && !(g.dbg & 3) && !g.split;     // (the epilogue just run was a full tile's)
         if ((g.dbg & 4)) tmark[2] += __builtin_readcyclecounter() - te0;
     }
     if ((g.dbg & 4) && lane == 0 && g.res2) {
