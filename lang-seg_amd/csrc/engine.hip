@@ -773,7 +773,8 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
         // the softmax scale (head_dim^-0.5 = 0.125 for 64) * log2(e) rides on q through the QKV epilogue's single rounding: the attention
         // kernel's matrix pipe then delivers exp2 arguments (attention.hip PRE)
         g.qkv_qscale = 0.125f * 1.4426950408889634f;
-        const bool prescaled = !strict_ && gemm_qkv_scales_q(g, img_dt_);
+        static const int pre_env = getenv("LSEG_ATTN_PRE") ? atoi(getenv("LSEG_ATTN_PRE")) : -1;      // tools: 0 = the scale-in-softmax body, 1 = pre-scaled q
+        const bool prescaled = !strict_ && gemm_qkv_scales_q(g, img_dt_) && pre_env != 0;
         if (!prescaled) g.qkv_qscale = 0.f;
         pe = prof_begin(PF_QKV, st);
         TRY(igemm(g, st));
