@@ -773,8 +773,10 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
         // the softmax scale (head_dim^-0.5 = 0.125 for 64) * log2(e) rides on q through the QKV epilogue's single rounding: the attention
         // kernel's matrix pipe then delivers exp2 arguments (attention.hip PRE)
         g.qkv_qscale = 0.125f * 1.4426950408889634f;
-        static const int pre_env = getenv("LSEG_ATTN_PRE") ? atoi(getenv("LSEG_ATTN_PRE")) : -1;      // tools: 0 = the scale-in-softmax body, 1 = pre-scaled q
-        const bool prescaled = !strict_ && gemm_qkv_scales_q(g, img_dt_) && pre_env != 0;
+        // fp16 operands only: with bf16 the pre-scaled body moved the mask flips at configs[1] from 1.57 % to 2.64 % (max |dlogit| 0.204 ->
+        // 0.241; fp16 0.264 % vs 0.274 %: unchanged) -- lease J, profiles/r04_attention_experiments.txt.  LSEG_ATTN_PRE=0 / 1 (tools) forces a body.
+        static const int pre_env = getenv("LSEG_ATTN_PRE") ? atoi(getenv("LSEG_ATTN_PRE")) : -1;
+        const bool prescaled = !strict_ && gemm_qkv_scales_q(g, img_dt_) && (pre_env < 0 ? img_dt_ == DT_F16 : pre_env != 0);
         if (!prescaled) g.qkv_qscale = 0.f;
         pe = prof_begin(PF_QKV, st);
         TRY(igemm(g, st));
