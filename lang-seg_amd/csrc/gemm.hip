@@ -76,18 +76,20 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 // GELU(erf) through erfc(|z|) ~= exp2(|z| R(|z|)), z = x / sqrt 2: R = degree-5 fit of log2(erfc(z)) / z on [0, 4.4] (erfc(0) = 1 exactly; max
 // |erfc error| 4.7e-7, GELU error <= 4.6e-7 absolute in fp32 evaluation -- tools/fit_gelu.py).  With h = erfc(|z|) / 2 = exp2(|z| R - 1):
 //   y = x Phi(x) = max(x, 0) - |x| h        (x >= 0: x (1 - h);  x < 0: x h -- no cancellation in the negative tail)
-// 11 VALU instructions, ONE transcendental, |x| for free as a source modifier -- against 13 + rcp + exp2 + two v_and for the
-// Abramowitz-Stegun form above on packed fp32 (half rate on gfx950): the GELU arithmetic was 58 of the 319 us of an mlp.fc1 launch at
-// B = 36 (profiles/r04_epilogue_table.txt: no-store build vs K-loop-only build).  Past |z| = 4.4 (|x| > 6.2) h is held at 3e-10.
+// The 1 / sqrt 2 is folded into the coefficients (the polynomial runs in u = |x| directly: d_k = c_k 2^(-(k+1)/2)), |x| is a source
+// modifier (the last fma is paired into a v_pk_fma_f32 by the SLP vectoriser, which costs a v_and per element): 11 VALU instructions, ONE
+// transcendental -- against 13 + rcp + exp2 + two v_and for the Abramowitz-Stegun form above on
+// packed fp32 (half rate on gfx950): the GELU arithmetic was 58 of the 319 us of an mlp.fc1 launch at B = 36
+// (profiles/r04_epilogue_table.txt: no-store build vs K-loop-only build).  Past |x| = 6.22 (|z| = 4.4) h is held at 3e-10.
 __device__ __forceinline__ float gelu_fast(float x) {
-    const float az = fminf(fabsf(x) * 0.70710678118654752f, 4.4f);
-    float r = 0.0001754754048306495f;
-    r = fmaf(r, az, -0.003827860578894615f);
-    r = fmaf(r, az, 0.03118317201733589f);
-    r = fmaf(r, az, -0.14992395043373108f);
-    r = fmaf(r, az, -0.9180861115455627f);
-    r = fmaf(r, az, -1.6279354095458984f);
-    const float h = __builtin_amdgcn_exp2f(fmaf(r, az, -1.0f));
+    const float u = fminf(fabsf(x), 6.222539901733398f);
+    float r = 2.1934425603831187e-05f;
+    r = fmaf(r, u, -0.000676676572766155f);
+    r = fmaf(r, u, 0.007795793004333973f);
+    r = fmaf(r, u, -0.0530061200261116f);
+    r = fmaf(r, u, -0.45904305577278137f);
+    r = fmaf(r, u, -1.151124119758606f);
+    const float h = __builtin_amdgcn_exp2f(fmaf(r, u, -1.0f));
     return fmaf(-fabsf(x), h, fmaxf(x, 0.f));
 }
 

@@ -15,12 +15,15 @@ for it in range(200):
     w = (t * np.log(2)) * (1 + 4 * np.abs(err) / (np.abs(err).max() + 1e-30))
 c32 = c.astype(np.float32)
 print("R coefficients (z^0 .. z^5):", [repr(float(v)) for v in c32])
+# gemm.hip evaluates in u = |x| = sqrt(2) z: t(u) = sum_k d_k u^(k+1) - 1 with d_k = c_k 2^(-(k+1)/2) (round 4: one multiply less per element)
+d32 = np.array([c[k] * 0.70710678118654752 ** (k + 1) for k in range(6)]).astype(np.float32)
+print("folded coefficients (u^1 .. u^6):", [repr(float(v)) for v in d32], "; clamp |x| at", repr(float(np.float32(4.4 / 0.70710678118654752))))
 print("max |erfc error| (f64 evaluation): %.3g" % np.abs(err).max())
 x = np.linspace(-10, 10, 2000001).astype(np.float32)
-az = np.minimum(np.abs(x) * np.float32(0.70710678118654752), np.float32(4.4)).astype(np.float32)
-r = np.float32(c32[5]) * np.ones_like(az)
+az = np.minimum(np.abs(x), np.float32(4.4 / 0.70710678118654752)).astype(np.float32)
+r = np.float32(d32[5]) * np.ones_like(az)
 for k in range(4, -1, -1):
-    r = (r * az + c32[k]).astype(np.float32)
+    r = (r * az + d32[k]).astype(np.float32)
 h = np.exp2((r * az - np.float32(1.0)).astype(np.float32)).astype(np.float32)
 y = (np.maximum(x, 0) - np.abs(x) * h).astype(np.float32)
 ref = 0.5 * x.astype(np.float64) * special.erfc(-x.astype(np.float64) / np.sqrt(2))
