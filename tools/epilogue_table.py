@@ -73,22 +73,6 @@ def table(batch=36):
         del pr
 
 
-def tiles(batch=36):
-    """The same kernels under forced tile configurations (LSEG_GEMM_TILE, read per launch): 6 = 256x256 with 8 waves (the engine's), 7 = 256x128
-    with 8 waves, 9 = 256x128 with 4 waves (one per SIMD), 8 = 256x256 with 4 waves -- what a tile that leaves registers for a residual
-    prefetch costs in the K-loop (run with the abl2 build) and in the whole kernel."""
-    st = torch.cuda.current_stream()
-    for kind in KINDS:
-        pr = Problem(kind, batch * NTOK)
-        for tile in (6, 7, 9, 8):
-            os.environ["LSEG_GEMM_TILE"] = str(tile)
-            us = timed(lambda: pr.launch(st), iters=12)
-            print(json.dumps({"mode": "tiles", "variant": VARIANT, "dtype": DT, "kind": kind, "tile": tile, "us": round(us, 2),
-                              "TF": round(pr.flops / us / 1e6, 1)}), flush=True)
-        os.environ.pop("LSEG_GEMM_TILE", None)
-        del pr
-
-
 def partial():
     st = torch.cuda.current_stream()
     for kind in KINDS:
@@ -149,4 +133,4 @@ def stagger(rounds=3):
 
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else "table"
-    {"table": table, "partial": partial, "stagger": stagger, "tiles": tiles}[mode]()
+    {"table": table, "partial": partial, "stagger": stagger}[mode]()
