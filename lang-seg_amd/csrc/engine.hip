@@ -167,14 +167,7 @@ int Engine::init() {
     ALLOC(tpool_, uint16_t, Kl * W);
     ALLOC(tfeat_, uint16_t, Kl * c.out_c);
     ALLOC(tnorm_, uint16_t, Kl * c.out_c);
-    {   // tools: LSEG_TEXT_STREAM_PRIORITY = low | high gives the text tower's side stream the device's least / greatest priority
-        const char* pr = getenv("LSEG_TEXT_STREAM_PRIORITY");
-        int least = 0, greatest = 0;
-        if (pr && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && (pr[0] == 'l' || pr[0] == 'h'))
-            LSEG_HIP_TRY(hipStreamCreateWithPriority(&text_stream_, hipStreamNonBlocking, pr[0] == 'l' ? least : greatest));
-        else
-            LSEG_HIP_TRY(hipStreamCreateWithFlags(&text_stream_, hipStreamNonBlocking));
-    }
+    LSEG_HIP_TRY(hipStreamCreateWithFlags(&text_stream_, hipStreamNonBlocking));
     LSEG_HIP_TRY(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
     LSEG_HIP_TRY(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
     LSEG_HIP_TRY(hipEventCreateWithFlags(&ev_text_done_, hipEventDisableTiming));
