@@ -147,3 +147,60 @@ def test_attention_block_map_keeps_a_head_on_one_xcd(nb, BH):
     if BH % 8 == 0:      # workgroups are dealt to the 8 XCDs round-robin by linear id: all blocks of a head must share L & 7
         for bh in range(BH):
             assert len({seen[(blk, bh)] & 7 for blk in range(nb)}) == 1
+
+
+# ---- upsample4x_planes_scaled_kernel (elementwise.hip): bands, output-row shares and the rolling source rows --------------------------
+def _src_tap(r, i, n):
+    """common.h src_tap in float32: i0 = floor(r i), i1 = min(i0 + 1, n - 1)"""
+    s = np.float32(r) * np.float32(i)
+    i0 = int(s)
+    return i0, i0 + (1 if i0 < n - 1 else 0)
+
+
+@pytest.mark.parametrize("H,W,LB", [(120, 120, 16), (120, 120, 8), (32, 24, 16), (15, 20, 16), (6, 8, 16)])
+def test_x4_upsample_bands_cover_every_output_row_once_and_rolling_rows_hold_the_taps(H, W, LB):
+    """Integer model of the kernel's row logic (the arithmetic itself is held bit for bit to the two-stage form on the GPU): every output
+    row of the (4H) map is written by exactly one (band, sub-group) share; the two source rows the rolling registers hold when a row is
+    written are that row's taps, both inside the band's LDS image; a share forms at most rows / 2 + 2 new horizontal rows (the direct form:
+    2 per output row)."""
+    Hl, Ho = 2 * H, 4 * H
+    Wo = 4 * W
+    w4 = Wo // 4
+    nsub = 256 // w4 if w4 < 256 else 1
+    ry = np.float32(Hl - 1) / np.float32(Ho - 1)
+    bands = (Hl + LB - 1) // LB
+    written = np.zeros(Ho, dtype=int)
+    for band in range(bands):
+        ya = band * LB
+        yb = min(ya + LB, Hl - 1)
+        # yo_first / yo_end exactly as the kernel finds them
+        yo_first = int(np.ceil(np.float32(ya) / ry))
+        while yo_first > 0 and int(ry * np.float32(yo_first - 1)) >= ya:
+            yo_first -= 1
+        while int(ry * np.float32(yo_first)) < ya:
+            yo_first += 1
+        yo_end = yo_first
+        while yo_end < Ho and int(ry * np.float32(yo_end)) < ya + LB:
+            yo_end += 1
+        per = (yo_end - yo_first + nsub - 1) // nsub
+        for sub in range(nsub):
+            ys = yo_first + sub * per
+            ye = min(ys + per, yo_end)
+            c0 = c1 = -1
+            formed = 0
+            for yo in range(ys, ye):
+                y0, y1 = _src_tap(ry, yo, Hl)
+                if y0 != c0:
+                    if y0 != c1:
+                        formed += 1
+                    c0 = y0
+                if y1 != c1:
+                    if y1 != c0:
+                        formed += 1
+                    c1 = y1
+                assert (c0, c1) == (y0, y1)
+                assert ya <= y0 <= yb and ya <= y1 <= yb          # rows of the band's Lr image
+                written[yo] += 1
+            if ye > ys:
+                assert formed <= (ye - ys) // 2 + 2
+    assert (written == 1).all()
