@@ -91,7 +91,11 @@ typedef struct {
                                * probabilities below ~N * 3e-8 flush to zero.  Default (bit clear) = the reference's arithmetic.
                                * bit 2: batch-invariant schedule -- no split-K at small batches, so every GEMM accumulates K in one order
                                * whatever the batch size and image b of a batch equals the same image run alone to fp32 round-off
-                               * (default: attn.proj / mlp.fc2 / the deep 3x3 convs split their contraction when B <= ~6) */
+                               * (default: attn.proj / mlp.fc2 / the deep 3x3 convs split their contraction when B <= ~6)
+                               * bit 3 (training): deterministic reductions -- the bias-gradient and BatchNorm column sums write partial
+                               * rows summed in a fixed order instead of fp32 atomics: two runs of the same step on the same inputs
+                               * give BIT-identical gradients (what torch.use_deterministic_algorithms buys the reference's
+                               * training loop, modules/lsegmentation_module.py:66-81); one small extra launch per sum */
 } lseg_config;
 
 typedef struct lseg_engine* lseg_handle;

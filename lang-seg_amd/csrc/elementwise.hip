@@ -1251,14 +1251,17 @@ __global__ void softmax_ce_backward_kernel(const float* __restrict__ scores, con
 // ---- train-mode BatchNorm2d on the padded-NHWC maps (DPT ResidualConvUnit bn1/bn2, lseg_blocks.py:276-283, train()) ----
 // The maps carry a zero border, so per-channel sums over ALL padded positions equal the sums over the image; n = B*H*W.
 // Column statistics of 16-bit row-major matrices, 16 bytes per lane: a block = 32 column groups of 8 columns x 8 row lanes over
-// `rows_per_block` rows; the row lanes are summed through LDS, then one fp32 atomic per column and block (out zeroed by the launcher).
+// `rows_per_block` rows; the row lanes are summed through LDS, then one fp32 atomic per column and block (out zeroed by the launcher) --
+// or, with `partial` (deterministic reductions, lseg_config.flags bit 3), one partial row [gridDim.y][ncol] per row block, summed in a
+// fixed order by colreduce_kernel.
 //   MODE 0: out[c] += sum_r a[r,c]                                   (bias gradients)
 //   MODE 1: out[c] += sum a ; out[C+c] += sum a^2                    (BatchNorm batch statistics)
 //   MODE 2: out[c] += sum a ; out[C+c] += sum a * (b - mean_c) * rstd_c   (BatchNorm backward: a = dy, b = x, mean/rstd from `stats`)
 template <int MODE>
 __global__ __launch_bounds__(256) void colstats16_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
                                                          const float* __restrict__ stats, float inv_n, float eps, int dtype,
-                                                         float* __restrict__ out, int R, int C, int ld, int rows_per_block) {
+                                                         float* __restrict__ out, int R, int C, int ld, int rows_per_block,
+                                                         float* __restrict__ partial) {
     __shared__ float red[MODE == 0 ? 1 : 2][8][32][8];
     const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
     const int c0 = (blockIdx.x * 32 + cg) * 8;
@@ -1320,17 +1323,25 @@ __global__ __launch_bounds__(256) void colstats16_kernel(const uint16_t* __restr
             t += red[0][j][g][k];
             if (MODE != 0) t2 += red[MODE == 0 ? 0 : 1][j][g][k];
         }
-        atomicAdd(&out[c], t);
-        if (MODE != 0) atomicAdd(&out[C + c], t2);
+        if (partial) {
+            float* prow = partial + (size_t)blockIdx.y * (MODE == 0 ? C : 2 * C);
+            prow[c] = t;
+            if (MODE != 0) prow[C + c] = t2;
+        } else {
+            atomicAdd(&out[c], t);
+            if (MODE != 0) atomicAdd(&out[C + c], t2);
+        }
     }
 }
-__global__ void colsum16_scalar_kernel(const uint16_t* __restrict__ in, int dtype, float* __restrict__ out, int R, int C, int ld, int rows_per_block) {
+__global__ void colsum16_scalar_kernel(const uint16_t* __restrict__ in, int dtype, float* __restrict__ out, int R, int C, int ld, int rows_per_block,
+                                       float* __restrict__ partial) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
     float s = 0.f;
     for (int r = r0; r < r1; ++r) s += load_as_f32(in, (size_t)r * ld + c, dtype);
-    atomicAdd(&out[c], s);
+    if (partial) partial[(size_t)blockIdx.y * C + c] = s;
+    else atomicAdd(&out[c], s);
 }
 // 0xffff per 16-bit half of a packed pair that is > 0 (bf16 / fp16 alike: sign bit clear, not zero)
 __device__ __forceinline__ uint32_t relu_mask2(uint32_t x2) {
@@ -1943,27 +1954,35 @@ __global__ void embed_bwd_kernel(const float* __restrict__ gx, uint16_t* __restr
         dpos[idx] = acc;
     }
 }
-// transpose of pos_resize_kernel: dpos [1 + gh*gw, D] -> d pos_embed [1 + g_old^2, D] (+= with atomics; the caller zeroes
-// unless accumulating), plus d cls_token = dpos[0] (cls_token is added to row 0 of every image)
+// transpose of pos_resize_kernel: dpos [1 + gh*gw, D] -> d pos_embed [1 + g_old^2, D] (+=; the caller zeroes unless accumulating), plus
+// d cls_token = dpos[0] (cls_token is added to row 0 of every image).  GATHER form: a thread owns one (old cell, channel) and sums the
+// resized positions whose bilinear footprint touches it in a fixed order (y ascending, x ascending) -- no atomics, bit-reproducible.
 __global__ void pos_resize_bwd_kernel(const float* __restrict__ dpos, float* __restrict__ dposemb, float* __restrict__ dcls, int g_old,
                                       int gh, int gw, int D) {
-    const size_t total = (size_t)(1 + gh * gw) * D;
+    const size_t total = (size_t)(1 + g_old * g_old) * D;
+    const float ry = (float)g_old / (float)gh, rx = (float)g_old / (float)gw;
     for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int d = (int)(idx % D);
         const int t = (int)(idx / D);
-        const float g = dpos[idx];
-        if (t == 0) { atomicAdd(&dposemb[d], g); if (dcls) atomicAdd(&dcls[d], g); continue; }
-        const int y = (t - 1) / gw, x = (t - 1) - y * gw;
-        const float sy = fmaxf(0.f, ((float)y + 0.5f) * ((float)g_old / (float)gh) - 0.5f);
-        const float sx = fmaxf(0.f, ((float)x + 0.5f) * ((float)g_old / (float)gw) - 0.5f);
-        const int y0 = (int)sy, x0 = (int)sx;
-        const int y1 = y0 + (y0 < g_old - 1), x1 = x0 + (x0 < g_old - 1);
-        const float ly = sy - (float)y0, lx = sx - (float)x0;
-        float* o = dposemb + D;
-        atomicAdd(&o[((size_t)y0 * g_old + x0) * D + d], (1.f - ly) * (1.f - lx) * g);
-        atomicAdd(&o[((size_t)y0 * g_old + x1) * D + d], (1.f - ly) * lx * g);
-        atomicAdd(&o[((size_t)y1 * g_old + x0) * D + d], ly * (1.f - lx) * g);
-        atomicAdd(&o[((size_t)y1 * g_old + x1) * D + d], ly * lx * g);
+        if (t == 0) { const float g = dpos[d]; dposemb[d] += g; if (dcls) dcls[d] += g; continue; }
+        const int oy = (t - 1) / g_old, ox = (t - 1) - oy * g_old;
+        float acc = 0.f;
+        for (int y = 0; y < gh; ++y) {
+            const float sy = fmaxf(0.f, ((float)y + 0.5f) * ry - 0.5f);
+            const int y0 = (int)sy, y1 = y0 + (y0 < g_old - 1);
+            if (y0 != oy && y1 != oy) continue;
+            const float ly = sy - (float)y0;
+            const float wy = (y0 == oy ? 1.f - ly : 0.f) + (y1 == oy ? ly : 0.f);
+            for (int x = 0; x < gw; ++x) {
+                const float sx = fmaxf(0.f, ((float)x + 0.5f) * rx - 0.5f);
+                const int x0 = (int)sx, x1 = x0 + (x0 < g_old - 1);
+                if (x0 != ox && x1 != ox) continue;
+                const float lx = sx - (float)x0;
+                const float wx = (x0 == ox ? 1.f - lx : 0.f) + (x1 == ox ? lx : 0.f);
+                acc += wy * wx * dpos[((size_t)1 + (size_t)y * gw + x) * D + d];
+            }
+        }
+        dposemb[idx] += acc;
     }
 }
 // gradient re-layouts into the reference's parameter shapes (dst = or += src):
@@ -2324,13 +2343,33 @@ static int colstats_rows(int R, int C) {
     rpb = (rpb + 7) / 8 * 8;
     return rpb < 32 ? 32 : rpb;
 }
-int launch_bn_stats(const void* x, float* stats, int B, int H, int W, int C, int dtype, hipStream_t st, int pre_zeroed) {
-    const int Mp = B * (H + 2) * (W + 2), rpb = colstats_rows(Mp, C);
-    if (!pre_zeroed) LSEG_HIP_TRY(hipMemsetAsync(stats, 0, (size_t)2 * C * sizeof(float), st));
-    hipLaunchKernelGGL(colstats16_kernel<1>, dim3((C + 255) / 256, (Mp + rpb - 1) / rpb), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)nullptr,
-                       (const float*)nullptr, 0.f, 0.f, dtype, stats, Mp, C, C, rpb);
+// deterministic finish of a column-statistics launch: out[0..ncol) (+)= the nb partial rows, fixed order
+static int colstats_reduce(const float* partial, float* out, int nb, int ncol, int accumulate, hipStream_t st) {
+    if (!(ncol & 3) && !(((uintptr_t)out | (uintptr_t)partial) & 15))
+        hipLaunchKernelGGL(colreduce_kernel<16>, dim3((ncol + 15) / 16), dim3(1024), 0, st, partial, out, (float*)nullptr, nb, ncol, 0, ncol, accumulate);
+    else
+        hipLaunchKernelGGL(colreduce_scalar_kernel, dim3((ncol + 63) / 64), dim3(1024), 0, st, partial, out, (float*)nullptr, nb, ncol, 0, ncol, accumulate);
     CHECK_LAUNCH();
     return 0;
+}
+// rows per block such that the partial rows of a deterministic launch fit `cap` floats
+static int colstats_rows_det(int R, int C, int ncol, size_t cap) {
+    int rpb = colstats_rows(R, C);
+    const size_t max_rows = cap / (size_t)ncol;
+    if (max_rows == 0) return -1;
+    if ((size_t)((R + rpb - 1) / rpb) > max_rows) rpb = (int)(((size_t)R + max_rows - 1) / max_rows + 7) / 8 * 8;
+    return rpb;
+}
+int launch_bn_stats(const void* x, float* stats, int B, int H, int W, int C, int dtype, hipStream_t st, int pre_zeroed, float* det_ws, size_t det_cap) {
+    const int Mp = B * (H + 2) * (W + 2);
+    const int rpb = det_ws ? colstats_rows_det(Mp, C, 2 * C, det_cap) : colstats_rows(Mp, C);
+    if (rpb < 0) return set_error(LSEG_ERR_INVALID, "bn_stats: deterministic workspace too small for C=%d", C);
+    if (!pre_zeroed && !det_ws) LSEG_HIP_TRY(hipMemsetAsync(stats, 0, (size_t)2 * C * sizeof(float), st));
+    const int nb = (Mp + rpb - 1) / rpb;
+    hipLaunchKernelGGL(colstats16_kernel<1>, dim3((C + 255) / 256, nb), dim3(256), 0, st, (const uint16_t*)x, (const uint16_t*)nullptr,
+                       (const float*)nullptr, 0.f, 0.f, dtype, stats, Mp, C, C, rpb, det_ws);
+    CHECK_LAUNCH();
+    return det_ws ? colstats_reduce(det_ws, stats, nb, 2 * C, 0, st) : 0;      // (a pre-zeroed buffer is simply overwritten)
 }
 int launch_bn_apply(const void* x, void* y, const float* stats, const float* gamma, const float* beta, const void* res1, const void* res2,
                     int B, int H, int W, int C, float eps, double count, int dtype, hipStream_t st, void* y_relu) {
@@ -2343,13 +2382,16 @@ int launch_bn_apply(const void* x, void* y, const float* stats, const float* gam
     return 0;
 }
 int launch_bn_bwd_stats(const void* dy, const void* x, const float* stats, float* bstats, int B, int H, int W, int C, float eps,
-                        double count, int dtype, hipStream_t st) {
-    const int Mp = B * (H + 2) * (W + 2), rpb = colstats_rows(Mp, C);
-    LSEG_HIP_TRY(hipMemsetAsync(bstats, 0, (size_t)2 * C * sizeof(float), st));
-    hipLaunchKernelGGL(colstats16_kernel<2>, dim3((C + 255) / 256, (Mp + rpb - 1) / rpb), dim3(256), 0, st, (const uint16_t*)dy, (const uint16_t*)x,
-                       stats, (float)(1.0 / count), eps, dtype, bstats, Mp, C, C, rpb);
+                        double count, int dtype, hipStream_t st, float* det_ws, size_t det_cap) {
+    const int Mp = B * (H + 2) * (W + 2);
+    const int rpb = det_ws ? colstats_rows_det(Mp, C, 2 * C, det_cap) : colstats_rows(Mp, C);
+    if (rpb < 0) return set_error(LSEG_ERR_INVALID, "bn_bwd_stats: deterministic workspace too small for C=%d", C);
+    if (!det_ws) LSEG_HIP_TRY(hipMemsetAsync(bstats, 0, (size_t)2 * C * sizeof(float), st));
+    const int nb = (Mp + rpb - 1) / rpb;
+    hipLaunchKernelGGL(colstats16_kernel<2>, dim3((C + 255) / 256, nb), dim3(256), 0, st, (const uint16_t*)dy, (const uint16_t*)x,
+                       stats, (float)(1.0 / count), eps, dtype, bstats, Mp, C, C, rpb, det_ws);
     CHECK_LAUNCH();
-    return 0;
+    return det_ws ? colstats_reduce(det_ws, bstats, nb, 2 * C, 0, st) : 0;
 }
 int launch_bn_bwd_apply(const void* dy, const void* x, const float* stats, const float* bstats, const float* gamma, void* dx,
                         int B, int H, int W, int C, float eps, double count, int dtype, hipStream_t st) {
@@ -2422,20 +2464,20 @@ int launch_l2norm_scale_backward(const void* da, int da_dtype, const float* x, v
     CHECK_LAUNCH();
     return 0;
 }
-int launch_colsum16(const void* in, int dtype, float* out, int R, int C, int ld, hipStream_t st, int accumulate) {
-    if (!accumulate) LSEG_HIP_TRY(hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st));
+int launch_colsum16(const void* in, int dtype, float* out, int R, int C, int ld, hipStream_t st, int accumulate, float* det_ws, size_t det_cap) {
+    if (!accumulate && !det_ws) LSEG_HIP_TRY(hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st));
     const bool vec = !(ld & 7) && !((uintptr_t)in & 15);
-    const int rpb = colstats_rows(R, C);
+    const int rpb = det_ws ? colstats_rows_det(R, C, C, det_cap) : colstats_rows(R, C);
+    if (rpb < 0) return set_error(LSEG_ERR_INVALID, "colsum: deterministic workspace too small for C=%d", C);
     dim3 grid((C + 255) / 256, (R + rpb - 1) / rpb);
     if (!vec) {          // odd leading dimensions (op-level tests): one thread per column and row chunk
-        hipLaunchKernelGGL(colsum16_scalar_kernel, grid, dim3(256), 0, st, (const uint16_t*)in, dtype, out, R, C, ld, rpb);
-        CHECK_LAUNCH();
-        return 0;
+        hipLaunchKernelGGL(colsum16_scalar_kernel, grid, dim3(256), 0, st, (const uint16_t*)in, dtype, out, R, C, ld, rpb, det_ws);
+    } else {
+        hipLaunchKernelGGL(colstats16_kernel<0>, grid, dim3(256), 0, st, (const uint16_t*)in, (const uint16_t*)nullptr, (const float*)nullptr, 0.f, 0.f,
+                           dtype, out, R, C, ld, rpb, det_ws);
     }
-    hipLaunchKernelGGL(colstats16_kernel<0>, grid, dim3(256), 0, st, (const uint16_t*)in, (const uint16_t*)nullptr, (const float*)nullptr, 0.f, 0.f,
-                       dtype, out, R, C, ld, rpb);
     CHECK_LAUNCH();
-    return 0;
+    return det_ws ? colstats_reduce(det_ws, out, (int)grid.y, C, accumulate, st) : 0;
 }
 
 int launch_seg_stats(const float* scores, const int64_t* target, int B, int K, int HW, int ignore_index,
@@ -2495,7 +2537,7 @@ int launch_embed_bwd(const float* gx, void* dtok, float* dpos, int B, int ntok, 
     return 0;
 }
 int launch_pos_resize_bwd(const float* dpos, float* dposemb, float* dcls, int g_old, int gh, int gw, int D, hipStream_t st) {
-    hipLaunchKernelGGL(pos_resize_bwd_kernel, dim3(grid_for((size_t)(1 + gh * gw) * D)), dim3(256), 0, st, dpos, dposemb, dcls, g_old, gh, gw, D);
+    hipLaunchKernelGGL(pos_resize_bwd_kernel, dim3(grid_for((size_t)(1 + g_old * g_old) * D)), dim3(256), 0, st, dpos, dposemb, dcls, g_old, gh, gw, D);
     CHECK_LAUNCH();
     return 0;
 }

@@ -200,6 +200,7 @@ private:
     float* ws_part_ = nullptr; size_t ws_part_n_ = 0;   // split-K partial results of the weight-gradient GEMMs
     float* ws_dw_ = nullptr; size_t ws_dw_n_ = 0;   // wgrad output in the engine's packed layout before the re-layout into the parameter's
     float *ws_stats_ = nullptr, *zeros_ = nullptr, *ws_ln_ = nullptr;
+    float* ws_det_ = nullptr; size_t ws_det_n_ = 0;     // cfg.flags bit 3: partial rows of the deterministic column reductions
     float *gx_ = nullptr, *dpos_ = nullptr, *lse_px_ = nullptr;     // lse_px_: per-pixel log-sum-exp of the up-sampled logits [B, 2h, 2w]
     char* attn_ws_ = nullptr;              // per-layer scratch of the attention backward (transposed / head-major operand copies)
     uint16_t *g16_ = nullptr, *dmlp_ = nullptr, *dln_ = nullptr, *datt_ = nullptr, *dqkv_ = nullptr, *dtok_ = nullptr;

@@ -64,7 +64,9 @@ int launch_upsample2x_nhwc_backward(const void* dout, void* din, int B, int H, i
 int launch_softmax_ce_backward(const float* scores, const int64_t* target, float* dz, int B, int K, int HW, int ignore_index,
                                const double* nll, hipStream_t st);
 int launch_conv_dgrad_pack(const void* wp, void* wd, int Co, int Ci, hipStream_t st);
-int launch_colsum16(const void* in, int dtype, float* out, int R, int C, int ld, hipStream_t st, int accumulate = 0);
+// det_ws (optional, det_cap floats): deterministic reductions -- partial rows + a fixed-order sum instead of fp32 atomics
+int launch_colsum16(const void* in, int dtype, float* out, int R, int C, int ld, hipStream_t st, int accumulate = 0,
+                    float* det_ws = nullptr, size_t det_cap = 0);
 int launch_relu_backward_add(const void* dy, const void* x, const void* add, void* dx, size_t n, int dtype, hipStream_t st);
 int launch_seg_stats_ex(const float* scores, const int64_t* target, int B, int K, int HW, int ignore_index, unsigned long long* counts,
                         double* nll, uint8_t* argmax_out, int up, int h, int w, hipStream_t st, float* lse_out = nullptr);
@@ -104,12 +106,13 @@ int launch_attention_lse(const void* q, const void* k, const void* vt, void* out
                          int causal, float scale, hipStream_t stream);
 int launch_attention_ex(const void* q, const void* k, const void* vt, void* out, float* lse2, int B, int H, int ntok, int npad, int dtype,
                         int causal, float scale, int prescaled, hipStream_t stream);
-int launch_bn_stats(const void* x, float* stats, int B, int H, int W, int C, int dtype, hipStream_t st, int pre_zeroed = 0);
+int launch_bn_stats(const void* x, float* stats, int B, int H, int W, int C, int dtype, hipStream_t st, int pre_zeroed = 0,
+                    float* det_ws = nullptr, size_t det_cap = 0);
 int launch_bn_apply(const void* x, void* y, const float* stats, const float* gamma, const float* beta, const void* res1, const void* res2,
                     int B, int H, int W, int C, float eps, double count, int dtype, hipStream_t st,
                     void* y_relu = nullptr);      // y_relu: ReLU(y), same geometry (y may then be NULL)
 int launch_bn_bwd_stats(const void* dy, const void* x, const float* stats, float* bstats, int B, int H, int W, int C, float eps,
-                        double count, int dtype, hipStream_t st);
+                        double count, int dtype, hipStream_t st, float* det_ws = nullptr, size_t det_cap = 0);
 int launch_bn_bwd_apply(const void* dy, const void* x, const float* stats, const float* bstats, const float* gamma, void* dx,
                         int B, int H, int W, int C, float eps, double count, int dtype, hipStream_t st);
 int launch_bn_running_update(const float* stats, float* rmean, float* rvar, int C, double count, float momentum, hipStream_t st);

@@ -115,7 +115,8 @@ int Engine::zero_end(ZeroSet& z) {
 }
 // db[c] (+)= column sums of dy: the bias gradient of a Linear / 1x1 conv
 int Engine::bias_sum(const uint16_t* dy, float* db, int R, int C, int ld, int acc, hipStream_t st) {
-    if (acc) return launch_colsum16(dy, img_dt_, db, R, C, ld, st, 1);
+    if (acc) return launch_colsum16(dy, img_dt_, db, R, C, ld, st, 1, ws_det_, ws_det_n_);
+    if (ws_det_) return launch_colsum16(dy, img_dt_, db, R, C, ld, st, 0, ws_det_, ws_det_n_);       // overwrites: nothing to pre-zero
     return launch_colsum16(dy, img_dt_, db, R, C, ld, st, zero_note(zero_bwd_, db, (size_t)C) ? 1 : 0);
 }
 
@@ -184,6 +185,10 @@ int Engine::train_alloc() {
     TALLOC(ws_stats_, float, 2 * std::max<size_t>(F, 16 * 1024));
     TALLOC(zeros_, float, 16 * 1024);
     TALLOC(ws_ln_, float, (size_t)LN_BWD_PARTIAL_BLOCKS * 2 * D);
+    if (c.flags & 8) {                               // deterministic reductions: partial rows of the column-statistics kernels (bias
+        ws_det_n_ = (size_t)1 << 20;                 // gradients, BatchNorm batch sums forward / backward) instead of fp32 atomics
+        TALLOC(ws_det_, float, ws_det_n_);
+    }
     TALLOC(gx_, float, M * D); TALLOC(dpos_, float, (size_t)ntok_ * D);
     TALLOC(attn_ws_, char, attention_backward_ws_bytes((int)B, (int)H, npad_));
     TALLOC(g16_, uint16_t, M * D); TALLOC(dmlp_, uint16_t, M * 4 * D); TALLOC(dln_, uint16_t, M * D); TALLOC(datt_, uint16_t, M * D);
@@ -271,11 +276,11 @@ int Engine::rcu_train(const uint16_t* in, const uint16_t* in_relu, Rcu& U, const
     U.in_relu = in_relu;
     if (in_relu) TRY(conv3x3(in_relu, c1, nullptr, nullptr, U.cv1, B, H, W, 1, 0, 0, st));
     else TRY(conv3x3(in, c1, nullptr, nullptr, U.cv1, B, H, W, 1, 1, 0, st));
-    TRY(launch_bn_stats(U.cv1, U.st1, B, H, W, F, img_dt_, st, zero_note(zero_fwd_, U.st1, (size_t)2 * F) ? 1 : 0));
+    TRY(launch_bn_stats(U.cv1, U.st1, B, H, W, F, img_dt_, st, ws_det_ ? 1 : zero_note(zero_fwd_, U.st1, (size_t)2 * F) ? 1 : 0, ws_det_, ws_det_n_));
     TRY(bn_sync(U.st1, 2 * F, st));
     TRY(launch_bn_apply(U.cv1, nullptr, U.st1, U.g1, U.be1, nullptr, nullptr, B, H, W, F, 1e-5f, cnt, img_dt_, st, U.n1));
     TRY(conv3x3(U.n1, c2, nullptr, nullptr, U.cv2, B, H, W, 1, 0, 0, st));
-    TRY(launch_bn_stats(U.cv2, U.st2, B, H, W, F, img_dt_, st, zero_note(zero_fwd_, U.st2, (size_t)2 * F) ? 1 : 0));
+    TRY(launch_bn_stats(U.cv2, U.st2, B, H, W, F, img_dt_, st, ws_det_ ? 1 : zero_note(zero_fwd_, U.st2, (size_t)2 * F) ? 1 : 0, ws_det_, ws_det_n_));
     TRY(bn_sync(U.st2, 2 * F, st));
     TRY(launch_bn_apply(U.cv2, out, U.st2, U.g2, U.be2, in, res2, B, H, W, F, 1e-5f, cnt, img_dt_, st, out_relu));
     // running statistics live in the caller's tensors (momentum 0.1, unbiased variance: nn.BatchNorm2d / SyncBatchNorm)
@@ -573,7 +578,7 @@ int Engine::rcu_backward(const uint16_t* dout, const uint16_t* in, Rcu& U, uint1
     uint16_t* dD = dmapD_[lev];
     float* bst = ws_stats_;
     // bn2
-    TRY(launch_bn_bwd_stats(dout, U.cv2, U.st2, bst, B, H, W, F, 1e-5f, cnt, img_dt_, st));
+    TRY(launch_bn_bwd_stats(dout, U.cv2, U.st2, bst, B, H, W, F, 1e-5f, cnt, img_dt_, st, ws_det_, ws_det_n_));
     TRY(launch_fold_rows(bst, grad(U.key + "bn2.bias", F), 1, F, F, acc, st));
     TRY(launch_fold_rows(bst + F, grad(U.key + "bn2.weight", F), 1, F, F, acc, st));
     TRY(bn_sync(bst, 2 * F, st));
@@ -582,7 +587,7 @@ int Engine::rcu_backward(const uint16_t* dout, const uint16_t* in, Rcu& U, uint1
     TRY(conv_bwd(dC, U.n1, 0, U.r2, dD, grad(U.key + "conv2.weight", (size_t)F * F * 9), B, H, W, F, F, F, F, acc, st));
     TRY(launch_relu_backward(dD, U.n1, dD, nmap, st));
     // bn1
-    TRY(launch_bn_bwd_stats(dD, U.cv1, U.st1, bst, B, H, W, F, 1e-5f, cnt, img_dt_, st));
+    TRY(launch_bn_bwd_stats(dD, U.cv1, U.st1, bst, B, H, W, F, 1e-5f, cnt, img_dt_, st, ws_det_, ws_det_n_));
     TRY(launch_fold_rows(bst, grad(U.key + "bn1.bias", F), 1, F, F, acc, st));
     TRY(launch_fold_rows(bst + F, grad(U.key + "bn1.weight", F), 1, F, F, acc, st));
     TRY(bn_sync(bst, 2 * F, st));
@@ -633,7 +638,7 @@ int Engine::reassemble_backward(int l, int B, int acc, hipStream_t st) {
         TRY(launch_unpixshuf(dL_[l], rowsA_, B, gh_, gw_, s, Cp, st));                     // dG [Mr, s*s*Cp]
         TRY(lin_bwd(rowsA_, Mr, N, Cp, v.r1, rsmp_[l].wt, rowsB_, ws_dw_, nullptr, 0, st));
         TRY(launch_convT_wgrad_unpack(ws_dw_, grad(a + "4.weight", (size_t)C * C * s * s), C, Cp, s, acc, st));
-        TRY(launch_colsum16(rowsA_, img_dt_, ws_stats_, Mr, N, N, st));
+        TRY(launch_colsum16(rowsA_, img_dt_, ws_stats_, Mr, N, N, st, 0, ws_det_, ws_det_n_));
         TRY(launch_fold_rows(ws_stats_, grad(a + "4.bias", C), s * s, C, Cp, acc, st));
         d_r1 = rowsB_;
     } else if (c.resample_kind[l] == LSEG_RS_CONV_S2) {

@@ -46,7 +46,7 @@ class _HipMemcpy:
 
 def to_c_config(cfg: LSegConfig, img_h: int, img_w: int, max_batch: int, max_labels: int,
                 image_dtype: str = "bf16", full_text_context: bool = False, exact_head_grad: bool = False,
-                batch_invariant: bool = False) -> _lib.LSegConfigC:
+                batch_invariant: bool = False, deterministic: bool = False) -> _lib.LSegConfigC:
     c = _lib.LSegConfigC()
     c.abi_version = _lib.ABI_VERSION
     c.patch, c.dim, c.depth, c.heads = cfg.patch, cfg.dim, cfg.depth, cfg.heads
@@ -65,7 +65,8 @@ def to_c_config(cfg: LSegConfig, img_h: int, img_w: int, max_batch: int, max_lab
     c.max_batch, c.max_labels = max_batch, max_labels
     # "strict": split-precision validation mode ((hi, lo) fp16 operand pairs, ~21 mantissa bits; include/lseg_hip.h)
     c.image_dtype = {"bf16": _lib.LSEG_BF16, "fp16": _lib.LSEG_F16, "strict": _lib.LSEG_F16_SPLIT}[image_dtype]
-    c.flags = (1 if full_text_context else 0) | (2 if exact_head_grad else 0) | (4 if batch_invariant else 0)
+    c.flags = ((1 if full_text_context else 0) | (2 if exact_head_grad else 0) | (4 if batch_invariant else 0)
+               | (8 if deterministic else 0))
     return c
 
 
@@ -74,7 +75,15 @@ class HipEngine:
 
     def __init__(self, cfg: LSegConfig, img_h: int, img_w: int, max_batch: int, max_labels: int,
                  device: Optional[torch.device] = None, image_dtype: str = "bf16",
-                 full_text_context: bool = False, exact_head_grad: bool = False, batch_invariant: bool = False):
+                 full_text_context: bool = False, exact_head_grad: bool = False, batch_invariant: bool = False,
+                 deterministic: Optional[bool] = None):
+        """deterministic: the training step's column sums (bias gradients, BatchNorm batch statistics) in a fixed order instead of
+        fp32 atomics -- the same step twice gives bit-identical gradients (include/lseg_hip.h, flags bit 3).  None = the environment's
+        LSEG_DETERMINISTIC (the parity suite sets it: tests/conftest.py), default off."""
+        import os
+        if deterministic is None:
+            deterministic = os.environ.get("LSEG_DETERMINISTIC", "0") not in ("", "0")
+        self.deterministic = bool(deterministic)
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise _lib.LSegError(-2, "no GPU visible: the LSeg HIP engine has no CPU fallback")
@@ -82,7 +91,8 @@ class HipEngine:
         self.cfg = cfg
         self.img_h, self.img_w = img_h, img_w
         self.max_batch, self.max_labels = max_batch, max_labels
-        self._c = to_c_config(cfg, img_h, img_w, max_batch, max_labels, image_dtype, full_text_context, exact_head_grad, batch_invariant)
+        self._c = to_c_config(cfg, img_h, img_w, max_batch, max_labels, image_dtype, full_text_context, exact_head_grad, batch_invariant,
+                               self.deterministic)
         h = C.c_void_p()
         _lib.check(self.lib.lseg_create(C.byref(self._c), self.device.index or 0, C.byref(h)))
         self._h = h
