@@ -80,7 +80,10 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 // modifier (the last fma is paired into a v_pk_fma_f32 by the SLP vectoriser, which costs a v_and per element): 11 VALU instructions, ONE
 // transcendental -- against 13 + rcp + exp2 + two v_and for the Abramowitz-Stegun form above on
 // packed fp32 (half rate on gfx950): the GELU arithmetic was 58 of the 319 us of an mlp.fc1 launch at B = 36
-// (profiles/r04_epilogue_table.txt: no-store build vs K-loop-only build).  Past |x| = 6.22 (|z| = 4.4) h is held at 3e-10.
+// (profiles/r04_epilogue_table.txt: no-store build vs K-loop-only build).  Past |x| = 6.22 (|z| = 4.4) h is held at 3e-10: for very negative x
+// the result is -3e-10 |x| instead of -> 0 (2e-5 at the fp16 limit, below one fp16 ulp of anything the next GEMM adds it to), and +-inf gives
+// NaN like every other arithmetic on a non-finite accumulator -- lseg_check_range reports those; a compare + select per element to return
+// max(x, 0) there would cost the issue-bound epilogue 2 more VALU instructions per element.
 __device__ __forceinline__ float gelu_fast(float x) {
     const float u = fminf(fabsf(x), 6.222539901733398f);
     float r = 2.1934425603831187e-05f;
@@ -1317,8 +1320,10 @@ int launch_one(const GemmArgs& g, hipStream_t stream) {
 template <typename T, bool CONV, bool RELU_IN, int EPI, int TAG>
 int pick_tile(const GemmArgs& g, hipStream_t stream) {
     const long t_mid = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * (g.nsplit > 1 ? g.nsplit : 1);
-    const char* force_env = getenv("LSEG_GEMM_TILE");                                         // tools/tests: 1 = 64x64, 2 = 128x128, 6 = 256x256
-    const int force = force_env ? atoi(force_env) : 0;                                        // (read per launch: a tool sweeps tiles in one process)
+    // tools/tests: 1 = 64x64, 2 = 128x128, 6 = 256x256.  Read ONCE per process (function-local static: thread-safe initialisation, no getenv
+    // on the launch path -- several hundred launches per forward, possibly from several host threads); the sweeping tool and the forced-tile
+    // tests start one interpreter per tile (tools/tile_sweep.py, tests/test_gpu_tile_configs.py)
+    static const int force = [] { const char* e = getenv("LSEG_GEMM_TILE"); return e ? atoi(e) : 0; }();
     int pick = t_mid >= 192 ? 2 : 1;
     if (EPI == EPI_GENERIC && !CONV && g.map_mode == MAP_LABELPLANES && g.M > 128 && g.M <= 160 && !force)
         return launch_one<T, CfgLab, false, false, EPI_GENERIC, TAG>(g, stream);

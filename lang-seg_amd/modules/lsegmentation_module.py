@@ -67,7 +67,10 @@ class EngineSGD(torch.optim.SGD):
             return False
         if eng is None:
             return True
-        key = (id(eng), tuple(len(x["params"]) for x in g))
+        # the key holds everything the answer depends on: WHICH tensors sit in each group (a swap within equal-sized groups) and whether each
+        # is trainable (a later p.requires_grad_(False) must send the step back to torch: the fused step would keep applying weight
+        # decay and momentum to a frozen tensor) -- two tuple builds over ~370 parameters per step, ~50 us
+        key = (id(eng), tuple(tuple(id(p) for p in x["params"]) for x in g), tuple(p.requires_grad for x in g for p in x["params"]))
         if getattr(self, "_fusable_cache", (None, None))[0] != key:
             names = {id(p): k for k, p in self._net.named_parameters()}
             groups = [{names.get(id(p)) for p in x["params"]} for x in g]

@@ -8,6 +8,7 @@ a GPU the forward raises.
 """
 import math
 import os
+import threading
 import warnings
 from collections import OrderedDict
 
@@ -115,6 +116,21 @@ class _EngineLossFn(torch.autograd.Function):
         return (None, None, None, None, None, None) + grads
 
 
+def _new_shared(image_dtype):
+    return _SharedState(image_dtype=image_dtype, lock=threading.RLock())
+
+
+class _SharedState(dict):
+    """Per-network state that DataParallel.replicate's shallow module copies share (one dict object behind every replica): the
+    operand type of the inference engines and the lock that guards a fallback.  Copies / pickles get a fresh lock."""
+
+    def __deepcopy__(self, memo):
+        return _new_shared(self["image_dtype"])
+
+    def __reduce__(self):
+        return (_new_shared, (self["image_dtype"],))
+
+
 class LSeg(BaseModel):
     def __init__(self, head, features=256, backbone="clip_vitl16_384", readout="project",
                  channels_last=False, use_bn=False, **kwargs):
@@ -145,7 +161,9 @@ class LSeg(BaseModel):
         # MFMA operand type of the image tower.  The reference's tower is fp32; of the two 16-bit types fp16 (11 significand bits) is 8x
         # closer to it than bf16 (8) at the same MFMA rate (DESIGN.md par. 4, bench.py `dtype_selection`).  Training engines are bf16:
         # the per-logit gradient of a mean over 1.8 M pixels is ~1e-7 and would flush to zero in fp16.
-        self.image_dtype = kwargs.get("image_dtype", default_image_dtype())
+        # (kept in a dict that DataParallel.replicate's shallow copies SHARE -- like `_engines` -- so that a loud bf16 fallback taken by one
+        # replica thread holds for all of them and survives the next replicate: additional_utils/encoding_models.py:43)
+        self._shared = _new_shared(kwargs.get("image_dtype", default_image_dtype()))
         # fp16 inference engines check their 16-bit activations for overflow (65504) on the first forward after every (re)pack and on
         # demand (`check_overflow`): a network whose activations leave the fp16 range falls back to bf16 LOUDLY (warning + rebuild),
         # never to inf / NaN masks (lseg_get_overflow)
@@ -165,6 +183,14 @@ class LSeg(BaseModel):
 
     # ---- engine plumbing -----------------------------------------------------------------------
 
+    @property
+    def image_dtype(self):
+        return self._shared["image_dtype"]
+
+    @image_dtype.setter
+    def image_dtype(self, value):
+        self._shared["image_dtype"] = value
+
     def _engine(self, B, H, W, K, device, train=False):
         """One engine per (image size, device, train/eval): each holds its own packed weights + activation plan (~1 GB for ViT-L/16
         in eval mode).  The cache is bounded (callers with varying image sizes: lseg_app, `evaluate` on uncropped images): the least
@@ -172,7 +198,8 @@ class LSeg(BaseModel):
         gradients, possibly referenced by a live autograd graph) are never evicted.  Replicas made by DataParallel.replicate
         (additional_utils/encoding_models.py:43) share this dict object; the device index in the key keeps their engines apart."""
         from lseg_hip.engine import HipEngine
-        key = (H, W, device.index, bool(train))
+        # the operand type is part of the key: after a fallback (fp16 -> bf16) an fp16 engine is never picked up again, on any device
+        key = (H, W, device.index, bool(train), "bf16" if train else self.image_dtype)
         eng = self._engines.get(key)
         if eng is not None:
             self._engines.move_to_end(key)
@@ -340,6 +367,37 @@ class LSeg(BaseModel):
         eng, keys, params = self._train_inputs(x, labelset)
         return _EngineLossFn.apply(x.float(), target, self, eng, keys, int(ignore_index), *params)
 
+    def _range_guard(self, eng, device):
+        """fp16 MFMA operands saturate at 65504 where the reference's fp32 tower cannot (lseg_vit.py:196-197).  Checked on the first
+        forward after every (re)pack of the weights (overflow_fallback="always": on every forward, one synchronising ~1 ms scan; the
+        default leaves an input-dependent overflow on a LATER image of the same weights to that mode): any inf / NaN in a 16-bit
+        activation buffer of an fp16 engine -> this network -- every replica sharing `_shared` -- switches to bf16 operands (same
+        speed, fp32 range), LOUDLY, and the caller re-runs.  A bf16 engine that still shows non-finite values (the head map g is fp16
+        in every mode: DESIGN par. 3.4) raises -- never inf / NaN masks without an error.  Returns True when the caller must re-run.
+        Only THIS device's fp16 eval engines are closed, under the shared lock: under DataParallel-style threaded replicas
+        (additional_utils/models.py:229-238) another thread may be inside forward() on its own device's engine."""
+        mode = getattr(self, "overflow_fallback", True)
+        if not mode or (mode != "always" and getattr(eng, "_range_stamp", None) == eng._stamp):
+            return False
+        eng._range_stamp = eng._stamp
+        r = eng.check_range()
+        if r["nonfinite"] > 0 and eng.image_dtype == "fp16":
+            warnings.warn(f"LSeg: {r['nonfinite']} non-finite values in the fp16 image tower's activations (largest finite |x| "
+                          f"{r['max_abs']:.3g}; fp16 saturates at 65504): this network's activations leave the fp16 range -- "
+                          "falling back to bf16 MFMA operands for all further forwards (image_dtype='bf16')", RuntimeWarning, stacklevel=3)
+            with self._shared["lock"]:
+                self._shared["image_dtype"] = "bf16"
+                for key in [k_ for k_ in self._engines if not k_[3] and k_[2] == device.index and k_[4] == "fp16"]:
+                    self._engines.pop(key).close()
+            self._last_engine = None
+            return True
+        if r["nonfinite"] > 0:
+            raise RuntimeError(f"LSeg: {r['nonfinite']} non-finite values in the image tower's 16-bit activations with {eng.image_dtype} operands "
+                               f"(largest finite |x| {r['max_abs']:.3g}): the head feature map leaves the fp16 range, or the input / weights "
+                               "are not finite; image_dtype='strict' keeps fp32-class range and precision")
+        self.last_range_check = r
+        return False
+
     def forward(self, x, labelset="", _want_logits=True):
         if labelset == "":
             text = self.text
@@ -359,29 +417,8 @@ class LSeg(BaseModel):
         self._set_tokens(eng, text, labelset)
         self._last_engine = eng
         out = eng.forward(x.float(), want_logits=_want_logits)
-        mode = getattr(self, "overflow_fallback", True)
-        if mode and (mode == "always" or getattr(eng, "_range_stamp", None) != eng._stamp):
-            # fp16 MFMA operands saturate at 65504 where the reference's fp32 tower cannot (lseg_vit.py:196-197).  Checked on the first
-            # forward after every (re)pack of the weights ("always": on every forward, one synchronising ~1 ms scan): any inf / NaN in
-            # a 16-bit activation buffer of an fp16 engine -> this network switches to bf16 operands (same speed, fp32 range), LOUDLY,
-            # and re-runs.  A bf16 engine that still shows non-finite values (the head map g is fp16 in every mode: DESIGN par. 3.4)
-            # raises -- never inf / NaN masks without an error.
-            eng._range_stamp = eng._stamp
-            r = eng.check_range()
-            if r["nonfinite"] > 0 and eng.image_dtype == "fp16":
-                warnings.warn(f"LSeg: {r['nonfinite']} non-finite values in the fp16 image tower's activations (largest finite |x| "
-                              f"{r['max_abs']:.3g}; fp16 saturates at 65504): this network's activations leave the fp16 range -- "
-                              "falling back to bf16 MFMA operands for all further forwards (image_dtype='bf16')", RuntimeWarning, stacklevel=2)
-                self.image_dtype = "bf16"
-                for key in [k_ for k_ in self._engines if not k_[3]]:
-                    self._engines.pop(key).close()
-                self._last_engine = None
-                return self.forward(x, labelset, _want_logits)
-            if r["nonfinite"] > 0:
-                raise RuntimeError(f"LSeg: {r['nonfinite']} non-finite values in the image tower's 16-bit activations with {eng.image_dtype} operands "
-                                   f"(largest finite |x| {r['max_abs']:.3g}): the head feature map leaves the fp16 range, or the input / weights "
-                                   "are not finite; image_dtype='strict' keeps fp32-class range and precision")
-            self.last_range_check = r
+        if self._range_guard(eng, x.device):
+            return self.forward(x, labelset, _want_logits)              # fell back to bf16: run again on a bf16 engine
         return out
 
 

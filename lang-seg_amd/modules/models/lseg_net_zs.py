@@ -18,7 +18,7 @@ import torch.nn as nn
 from lseg_hip.config import get_config
 from lseg_hip.tokenizer import tokenize
 from .lseg_blocks import Interpolate, _make_encoder
-from .lseg_net import BaseModel, default_image_dtype, LSeg as _LSegShared, _make_fusion_block
+from .lseg_net import BaseModel, default_image_dtype, LSeg as _LSegShared, _make_fusion_block, _new_shared
 
 
 class LSeg(_LSegShared):
@@ -47,7 +47,8 @@ class LSeg(_LSegShared):
         self.texts = [tokenize(["others", name], self.cfg.text.ctx, self.cfg.text.vocab) for name in self.label_list]
         self._engines = OrderedDict()
         self.max_engines = kwargs.get("max_engines", 4)
-        self.image_dtype = kwargs.get("image_dtype", default_image_dtype())
+        self._shared = _new_shared(kwargs.get("image_dtype", default_image_dtype()))
+        self.overflow_fallback = kwargs.get("overflow_fallback", True)      # fp16 range check + loud bf16 fallback, as LSegNet (lseg_net.py)
         self.cache_text = kwargs.get("cache_text", False)
         self.autograd_grads = False
         self.sync_batchnorm = False
@@ -70,7 +71,10 @@ class LSeg(_LSegShared):
             eng.set_tokens(text, labels_per_image=2)
             eng._tok = tkey
         eng.set_text_cache(bool(self.cache_text))
-        return eng.forward(x.float())                                         # [B, 2, H, W]
+        out = eng.forward(x.float())                                          # [B, 2, H, W]
+        if self._range_guard(eng, x.device):
+            return self.forward(x, class_info)                                # fp16 overflowed: again on bf16 operands (loud)
+        return out
 
 
 class LSegNetZS(LSeg):

@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 
 from lseg_hip.config import get_config                      # noqa: E402
 from lseg_hip.engine import HipEngine                       # noqa: E402
-from lseg_hip.synth import (synthetic_state_dict, synthetic_tokens, synthetic_images,   # noqa: E402
+from lseg_hip.synth import (synthetic_state_dict, fixture_state_dict, outlier_state_dict, synthetic_tokens, synthetic_images,   # noqa: E402
                             read_labels)
 from oracle.lseg_oracle import lseg_forward                  # noqa: E402
 from oracle import make_golden as MG                        # noqa: E402
@@ -376,7 +376,7 @@ def test_engine_matches_the_reference_at_the_baseline_configs(name, dtype, golde
     g = torch.load(os.path.join(golden_dir, name + ".pt"))
     bb, H, W, B, K, seed, arch, depth = g["spec"]
     cfg = get_config(bb, arch_option=arch, block_depth=depth, activation="lrelu")
-    sd = synthetic_state_dict(cfg, seed=seed)
+    sd = fixture_state_dict(cfg, seed, g)          # `*_outlier` fixtures: realistic-statistics weights (outlier_state_dict)
     x = synthetic_images(B, H, W, seed=seed)
     eng = HipEngine(cfg, H, W, max_batch=B, max_labels=K, image_dtype=dtype)
     eng.load_state_dict(sd)
@@ -429,6 +429,11 @@ MASK480_CAPS = {150: {"bf16": (0.035, 0.15), "fp16": (0.005, 0.02), "strict": (0
                 1000: {"bf16": (0.14, 0.15), "fp16": (0.026, 0.025), "strict": (0.013, 0.008)}}
 
 
+# the realistic-statistics fixture (residual outliers ~1e3 next to O(1) channels; the reference's median top-2 margin there is 0.45, so a
+# flip needs a larger logit error than on the N(0, 0.02) net): measured r5 -- see profiles/r05_parity_table.txt
+MASK480_CAPS_BY_NAME = {"ref_full_vitl16_480x480_k150_outlier": {"bf16": (0.035, 0.15), "fp16": (0.005, 0.02), "strict": (0.003, 0.006)}}
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "fp16", "strict"])
 @pytest.mark.parametrize("name", _REF_FULL)
 def test_engine_masks_match_the_reference_at_480x480(name, dtype, golden_dir):
@@ -444,7 +449,7 @@ def test_engine_masks_match_the_reference_at_480x480(name, dtype, golden_dir):
     bb, H, W, B, K, seed, arch, depth = g["spec"]
     cfg = get_config(bb, arch_option=arch, block_depth=depth, activation="lrelu")
     eng = HipEngine(cfg, H, W, max_batch=B, max_labels=K, image_dtype=dtype)
-    eng.load_state_dict(synthetic_state_dict(cfg, seed=seed))
+    eng.load_state_dict(fixture_state_dict(cfg, seed, g))
     eng.set_tokens(g["tokens"])
     x = synthetic_images(B, H, W, seed=seed).cuda()
     out = eng.forward(x)
@@ -456,7 +461,7 @@ def test_engine_masks_match_the_reference_at_480x480(name, dtype, golden_dir):
     mism = am != ref_am
     frac = mism.float().mean().item()
     worst = ref_margin[mism].max().item() if mism.any() else 0.0
-    cap_frac, cap_margin = MASK480_CAPS[K][dtype]
+    cap_frac, cap_margin = MASK480_CAPS_BY_NAME.get(name, MASK480_CAPS[K])[dtype]
     print(f"{name}[{dtype}] 480x480: argmax mismatch fraction {frac:.5f} (cap {cap_frac}), max reference margin at a mismatch {worst:.4f} "
           f"(cap {cap_margin}), max|dlogit| at the reference's label {err:.4f}")
     out_dir = os.path.join(os.path.dirname(golden_dir), "..", "gpurun_out")
@@ -475,23 +480,7 @@ def test_engine_masks_match_the_reference_at_480x480(name, dtype, golden_dir):
     eng.close()
 
 
-def _outlier_state_dict(cfg, seed, level):
-    """A synthetic state dict with the statistics real ViT / DPT checkpoints are known for and N(0, 0.02)-style random weights are not:
-    a few residual-stream OUTLIER CHANNELS carried by mlp.fc2 / attn.proj rows (x level), LayerNorm gains up to 10 on them, BatchNorm
-    layers with small running variances (large effective scales).  level 1e2: fp16 must survive."""
-    sd = synthetic_state_dict(cfg, seed=seed)
-    g = torch.Generator().manual_seed(seed + 99)
-    ch = torch.randperm(cfg.dim, generator=g)[:3]
-    for k in sd:
-        if k.endswith(("mlp.fc2.weight", "attn.proj.weight")) and k.startswith("pretrained.model.blocks."):
-            sd[k][ch] *= level ** 0.5
-        if k.endswith(("norm1.weight", "norm2.weight")) and k.startswith("pretrained.model.blocks."):
-            sd[k][ch] = 10.0
-        if k.endswith("mlp.fc1.weight") and k.startswith("pretrained.model.blocks."):
-            sd[k][:, ch] *= level ** 0.5
-        if k.endswith("running_var") and ".bn1." in k:
-            sd[k][::17] *= 0.01                       # x10 effective scale on every 17th channel
-    return sd
+_outlier_state_dict = outlier_state_dict            # (moved to lseg_hip.synth: the reference-run `*_outlier` fixture is made from it too)
 
 
 def test_fp16_range_check_and_loud_bf16_fallback():

@@ -211,3 +211,45 @@ def test_engine_cache_is_bounded_and_keeps_replicas_on_their_own_device(monkeypa
     assert e_b is not e_a and e_b.key == (64, 64, 1)
     assert net._engine(1, 64, 64, 2, d0) is e_a         # device 1's engines never evict device 0's
     assert closed == [(96, 64, 0)]
+
+
+def test_fp16_fallback_is_per_device_locked_and_shared_by_replicas(monkeypatch):
+    """the loud fp16 -> bf16 fallback (i) closes only THIS device's fp16 eval engines -- another replica thread may be inside
+    forward() on its own device's engine --, (ii) is recorded on the state the replicas share, so every replica (and the next
+    replicate()) builds bf16 engines from then on, (iii) the operand type is part of the engine key: an fp16 engine is never reused."""
+    import copy
+    import lseg_hip.engine as E
+    from modules.models.lseg_net import LSegNet
+    closed = []
+
+    class FakeEngine:
+        def __init__(self, cfg, H, W, max_batch, max_labels, device=None, image_dtype="bf16", **kw):
+            self.key = (H, W, device.index, image_dtype)
+            self.max_batch, self.max_labels, self.training, self.image_dtype = max_batch, max_labels, False, image_dtype
+            self.bad = 0
+
+        def load_state_dict(self, sd):
+            pass
+
+        def check_range(self):
+            return {"nonfinite": self.bad, "max_abs": 7e4, "scanned": 1, "near": 0}
+
+        def close(self):
+            closed.append(self.key)
+
+    monkeypatch.setattr(E, "HipEngine", FakeEngine)
+    net = LSegNet(labels=["a", "b"], backbone="tiny16", features=64, arch_option=0, block_depth=0, activation="lrelu", image_dtype="fp16")
+    replica = copy.copy(net)
+    d0, d1 = torch.device("cuda", 0), torch.device("cuda", 1)
+    e0, e0b, e1 = net._engine(1, 64, 64, 2, d0), net._engine(1, 96, 64, 2, d0), replica._engine(1, 64, 64, 2, d1)
+    assert e0.image_dtype == e1.image_dtype == "fp16"
+    assert not net._range_guard(e0, d0)                               # clean: no fallback, checked once per pack
+    e0b.bad = 3
+    with pytest.warns(RuntimeWarning, match="falling back to bf16"):
+        assert net._range_guard(e0b, d0)
+    assert sorted(closed) == [(64, 64, 0, "fp16"), (96, 64, 0, "fp16")]              # device 1's engine is untouched (maybe mid-forward)
+    assert net.image_dtype == "bf16" and replica.image_dtype == "bf16" and copy.copy(net).image_dtype == "bf16"
+    assert replica._engine(1, 64, 64, 2, d1).image_dtype == "bf16" and replica._engine(1, 64, 64, 2, d1) is not e1
+    assert net._engine(1, 64, 64, 2, d0).image_dtype == "bf16"
+    again = copy.deepcopy(net._shared)                                # copies / pickles get their own lock
+    assert again["image_dtype"] == "bf16" and again["lock"] is not net._shared["lock"]

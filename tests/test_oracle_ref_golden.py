@@ -12,7 +12,7 @@ import pytest
 import torch
 
 from lseg_hip.config import get_config
-from lseg_hip.synth import synthetic_state_dict, synthetic_images
+from lseg_hip.synth import synthetic_state_dict, fixture_state_dict, synthetic_images
 from oracle.lseg_oracle import lseg_forward
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -72,7 +72,7 @@ def test_oracle_matches_reference_code_at_the_baseline_configs(name):
     g = torch.load(os.path.join(GOLD, name + ".pt"))
     bb, H, W, B, K, seed, arch, depth = g["spec"]
     cfg = get_config(bb, arch_option=arch, block_depth=depth, activation="lrelu")
-    sd = synthetic_state_dict(cfg, seed=seed)
+    sd = fixture_state_dict(cfg, seed, g)                 # `*_outlier`: realistic-statistics weights (lseg_hip.synth.outlier_state_dict)
     x = synthetic_images(B, H, W, seed=seed)
     tf = g["text_features"].float() if K > 150 else None
     with torch.no_grad():
