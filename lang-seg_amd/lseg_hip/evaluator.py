@@ -51,14 +51,36 @@ def _pad_image(img, mean, std, crop_size):          # encoding_models.py:144-155
     return out
 
 
+class ModuleSurface(torch.nn.Module):
+    """The part of LSegModule's surface the evaluators use (modules/lseg_module.py:29-93: evaluate / evaluate_random, base_size, crop_size,
+    mean, std, _up_kwargs) around a bare LSegNet -- for callers that hold a network and no Lightning module (bench.py, tools)."""
+
+    def __init__(self, net, crop_size=480, base_size=520, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5)):
+        super().__init__()
+        self.net, self.crop_size, self.base_size = net, crop_size, base_size
+        self.mean, self.std = list(mean), list(std)
+        self._up_kwargs = {"mode": "bilinear", "align_corners": True}
+
+    def evaluate(self, x, target=None):
+        return self.net(x)
+
+    def evaluate_random(self, x, labelset, target=None):
+        return self.net(x, labelset)
+
+
 class BatchedMultiEval(torch.nn.Module):
     """Drop-in for `MultiEvalModule(module, nclass, scales=..., flip=...)` on one GPU.
 
     `module` needs .evaluate(x) / .evaluate_random(x, labels), .base_size, .crop_size, .mean, .std,
     ._up_kwargs (the LSegModule surface, modules/lseg_module.py:29-93)."""
 
-    def __init__(self, module, nclass, flip=True, scales=(0.5, 0.75, 1.0, 1.25, 1.5, 1.75), max_batch=16):
+    def __init__(self, module, nclass, flip=True, scales=(0.5, 0.75, 1.0, 1.25, 1.5, 1.75), max_batch=16, cache_text=True):
+        """cache_text: encode a label set ONCE per evaluator call chain instead of once per crop batch (the reference re-runs the CLIP text
+        tower inside every one of its ~36 forwards per image, lseg_net.py:183 -- the same tokens through the same frozen weights: exact).
+        Applied to the wrapped network (`module.net`, an LSegNet) for the duration of a forward and restored afterwards; the engine
+        re-encodes whenever the tokens or the weights change (LSegNet._set_tokens / _stamp)."""
         super().__init__()
+        self.cache_text = cache_text
         self.module = module
         self.nclass = nclass
         self.base_size = module.base_size
@@ -126,7 +148,20 @@ class BatchedMultiEval(torch.nn.Module):
     @torch.no_grad()
     def forward(self, image: torch.Tensor, label_set=None) -> torch.Tensor:
         if image.is_cuda:
-            return self._forward_device(image, label_set)
+            net = getattr(self.module, "net", None)
+            if not self.cache_text or net is None or not hasattr(net, "cache_text"):
+                return self._forward_device(image, label_set)
+            was = net.cache_text
+            net.cache_text = True
+            try:
+                return self._forward_device(image, label_set)
+            finally:
+                net.cache_text = was
+        return self._forward_torch(image, label_set)
+
+    @torch.no_grad()
+    def _forward_torch(self, image: torch.Tensor, label_set=None) -> torch.Tensor:
+        """The torch statement of the schedule (host tensors; the definition the device kernels are tested against)."""
         batch, _, h, w = image.shape
         assert batch == 1
         nclass = self.nclass if label_set is None else len(label_set)
@@ -163,3 +198,27 @@ class BatchedMultiEval(torch.nn.Module):
                 outputs = (outputs / count_norm)[:, :, :height, :width]
             scores += F.interpolate(outputs, (h, w), **up)
         return scores
+
+
+class SequentialMultiEval(BatchedMultiEval):
+    """The reference's own schedule on the same module: every crop and its mirrored twin as separate B = 1 forwards, each re-encoding the
+    label set (encoding_models.py:100-131,133-139), torch ops for the data movement.  What `test_lseg.py` costs per image when nothing is
+    batched -- the baseline of bench.py's `eval_multiscale` leg and of the crop-480 parity test; never the default."""
+
+    def __init__(self, module, nclass, flip=True, scales=(0.5, 0.75, 1.0, 1.25, 1.5, 1.75)):
+        super().__init__(module, nclass, flip=flip, scales=scales, max_batch=1, cache_text=False)
+
+    def _infer(self, crops, label_set):
+        ev = (lambda x: self.module.evaluate(x)) if label_set is None else (lambda x: self.module.evaluate_random(x, label_set))
+        outs = []
+        for i in range(crops.shape[0]):
+            x = crops[i:i + 1].contiguous()
+            o = ev(x)
+            if self.flip:
+                o = o + torch.flip(ev(torch.flip(x, dims=[3]).contiguous()), dims=[3])
+            outs.append(o)
+        return torch.cat(outs, dim=0)
+
+    @torch.no_grad()
+    def forward(self, image, label_set=None):
+        return self._forward_torch(image, label_set)
