@@ -257,6 +257,17 @@ int lseg_op_seg_stats(const float* d_scores, const int64_t* d_target, int B, int
 int lseg_op_seg_stats_lowres(const float* d_low, const int64_t* d_target, int B, int K, int h, int w, int ignore_index,
                              int64_t* d_counts, double* d_nll, uint8_t* d_argmax, void* stream);
 
+/* The pixel x text correlation on the engine's commuted schedule (DESIGN.md par. 3.4), one dedicated kernel (csrc/corr.hip).
+ * replaces: `logits_per_image = self.logit_scale * image_features.half() @ text_features.t()` (modules/models/lseg_net.py:194) together
+ *   with the norm of lseg_net.py:190 -- as label planes R[b, k, p] = t_k . g_p on the quarter-resolution map g (the combined
+ *   head1 o out_conv 1x1 conv output, padded NHWC fp16) and the five dot products of every 2x2 cell of g that the norm of the
+ *   x2-up-sampled feature is made of; the scale / fp16 rounding / upsample kernels consume both.
+ * d_g16pad fp16 [B, H+2, W+2, C] (C = 512); d_text16 fp16 [K, C] (K x (2C + 16) bytes must fit the 160 KB LDS: K <= 157);
+ * d_planes fp32 [B, K, (H+2)(W+2)] -- interior pixels written; d_gram fp32 [B, H, W, 5] = {g.g, g.g(x+1), g.g(y+1), g.g(y+1,x+1),
+ * g(x+1).g(y+1)} or NULL (planes only).  LSEG_ERR_UNSUPPORTED for other C / larger K (the engine then takes its generic GEMM). */
+int lseg_op_corr_planes(const void* d_g16pad, const void* d_text16, float* d_planes, float* d_gram, int B, int K, int H, int W, int C,
+                        void* stream);
+
 /* Device side of the multi-scale / flip sliding-window evaluator that calls the forward (additional_utils/encoding_models.py:54-155
  * MultiEvalModule.forward, module_inference, pad_image, crop_image, flip_image; additional_utils/models.py:55-140).  Per scale:
  *   lseg_op_eval_make_crops  d_img fp32 [C,height,width] (the resized image, C <= 3) -> d_crops fp32 [(1+flip)*n, C, crop, crop], n =

@@ -319,6 +319,13 @@ int lseg_op_seg_stats_lowres(const float* d_low, const int64_t* d_target, int B,
                                d_argmax, 1, h, w, (hipStream_t)stream);
 }
 
+int lseg_op_corr_planes(const void* d_g16pad, const void* d_text16, float* d_planes, float* d_gram, int B, int K, int H, int W, int C,
+                        void* stream) {
+    int r = require_device(); if (r) return r;
+    if (!d_g16pad || !d_text16 || !d_planes) return set_error(LSEG_ERR_INVALID, "corr_planes: NULL pointer");
+    return launch_corr_planes(d_g16pad, d_text16, d_planes, d_gram, B, K, H, W, C, (hipStream_t)stream);
+}
+
 int lseg_op_upsample_ce_backward_rows(const float* d_low, const int64_t* d_target, int B, int K, int h, int w, int ignore_index,
                                       double* d_nll, float* d_lse_ws, void* d_rows, int ldk, int out_dtype, void* stream) {
     int r = require_device(); if (r) return r;

@@ -889,9 +889,15 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
         g.A = t2_[0]; g.W = headc_.w; g.bias = headc_.b; g.M = B * hp * wp;
         g.C = g16pad_; g.out_dtype = DT_F16; g.ldc = c.out_c; g.map_mode = MAP_LINEAR;
         TRY(igemm(g, st));
-        TRY(launch_pixel_gram(g16pad_, gram_, B, lh_[0], lw_[0], c.out_c, st));
+        // the dedicated kernel (corr.hip): T resident in LDS, g streamed once, label planes and cell dot products from the same registers;
+        // per-image label sets (zero-shot), other widths and label sets that do not fit the LDS take the generic GEMM + pixel_gram pair
+        static const bool corr_generic = getenv("LSEG_CORR_GENERIC") != nullptr;    // A/B switch (tools, tests): the round-4 pair
+        const bool corr_fused = !corr_generic && group_k == 0 && corr_planes_supported(K_, c.out_c);
+        if (corr_fused) TRY(launch_corr_planes(g16pad_, tnorm_, rpl_, gram_, B, K_, lh_[0], lw_[0], c.out_c, st));
+        else TRY(launch_pixel_gram(g16pad_, gram_, B, lh_[0], lw_[0], c.out_c, st));
         TRY(launch_norm_scale_plane(gram_, nscale_, B, lh_[0], lw_[0], logit_scale, st));
-        if (group_k > 0) {
+        if (corr_fused) {
+        } else if (group_k > 0) {
             // lseg_net_zs.py:198-208: image b against its own k text rows -- B small GEMMs [k, out_c] x [out_c, hp*wp]
             for (int b = 0; b < B; ++b) {
                 gemm_args_init(g);

@@ -115,6 +115,9 @@ int launch_bn_bwd_stats(const void* dy, const void* x, const float* stats, float
                         double count, int dtype, hipStream_t st, float* det_ws = nullptr, size_t det_cap = 0);
 int launch_bn_bwd_apply(const void* dy, const void* x, const float* stats, const float* bstats, const float* gamma, void* dx,
                         int B, int H, int W, int C, float eps, double count, int dtype, hipStream_t st);
+// corr.hip: dedicated pixel x text correlation on the commuted schedule (label planes + cell dot products of g from one pass)
+bool corr_planes_supported(int K, int C);
+int launch_corr_planes(const void* g16pad, const void* T16, float* R, float* gram, int B, int K, int H, int W, int C, hipStream_t st);
 int launch_bn_running_update(const float* stats, float* rmean, float* rvar, int C, double count, float momentum, hipStream_t st);
 int launch_gelu_forward(const void* pre, void* out, size_t n, int dtype, hipStream_t st);
 int launch_unpad_rows(const void* in, void* out, int B, int H, int W, int C, hipStream_t st);

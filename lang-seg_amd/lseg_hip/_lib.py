@@ -77,6 +77,7 @@ SIGNATURES = {
     "lseg_set_bn_sync": (_i, [_vp, _vp, _vp, _i]),
     "lseg_set_bucket_callback": (_i, [_vp, _vp, _vp]),
     "lseg_sgd_step": (_i, [_vp, _f, _f, _f, _f, _vp]),
+    "lseg_op_corr_planes": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "lseg_op_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "lseg_op_gemm_vit": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "lseg_op_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),

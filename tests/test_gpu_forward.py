@@ -672,3 +672,46 @@ def test_text_features_handed_in_replace_the_text_tower():
     assert (out - logits).abs().max().item() <= 2e-2
     eng2.set_tokens(tok)
     assert torch.equal(eng2.forward(x.cuda()), logits)
+
+
+def test_dedicated_correlation_kernel_equals_the_generic_pair(tmp_path):
+    """The engine's correlation on the commuted schedule runs as ONE kernel (csrc/corr.hip: T resident in LDS, g streamed once, label planes
+    + cell dot products) where round 4 ran the generic GEMM + pixel_gram_kernel (LSEG_CORR_GENERIC=1, read once per process -> a second
+    interpreter).  The label planes use the same MFMA instruction, operand roles and k order as the GEMM they replace; the cell dot products
+    are summed in another order (MFMA instead of fp32 FMAs + shuffles), which can move a logit by ONE fp16 rounding step of the reference's
+    own `half @ half` rounding: BASELINE configs[1]'s shape (ViT-L/16, 480 x 480, K = 150, B = 2) and a small K (other instantiation)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from lseg_hip.config import get_config; from lseg_hip.engine import HipEngine\n"
+        "from lseg_hip.synth import synthetic_state_dict, synthetic_tokens, synthetic_images, read_labels\n"
+        "cfg = get_config('clip_vitl16_384'); sd = synthetic_state_dict(cfg, seed=0)\n"
+        "outs = []\n"
+        "for B, K, S in ((2, 150, 480), (1, 7, 160)):\n"
+        "    tok = synthetic_tokens(read_labels(%r)[:K], cfg.text.vocab, cfg.text.ctx)\n"
+        "    eng = HipEngine(cfg, S, S, max_batch=B, max_labels=K, image_dtype='fp16'); eng.load_state_dict(sd); eng.set_tokens(tok)\n"
+        "    x = synthetic_images(B, S, S, seed=1).cuda()\n"
+        "    eng.forward(x); torch.cuda.synchronize()\n"
+        "    outs.append(eng.intermediate('lowres', (B, K, S // 2, S // 2)).cpu())\n"
+        "    eng.close()\n"
+        "torch.save(outs, sys.argv[1])\n"
+    ) % (os.path.join(root, "lang-seg_amd"), root, MG.LABELS)
+    res = {}
+    for tag, generic in (("fused", False), ("generic", True)):
+        env = dict(os.environ)
+        env.pop("LSEG_CORR_GENERIC", None)
+        if generic:
+            env["LSEG_CORR_GENERIC"] = "1"
+        out = str(tmp_path / (tag + ".pt"))
+        subprocess.run([sys.executable, "-c", code, out], check=True, env=env, timeout=600)
+        res[tag] = torch.load(out)
+    for a, b in zip(res["fused"], res["generic"]):
+        assert a.shape == b.shape and torch.isfinite(a).all()
+        d = (a - b).abs()
+        ulp = 2.0 ** (torch.floor(torch.log2(b.abs().clamp_min(2.0 ** -14))) - 10)          # fp16 spacing at the generic path's value
+        frac = (d > 0).float().mean().item()
+        print(f"fused vs generic correlation: {frac:.2e} of the low-resolution logits differ, max |d| {d.max().item():.2e}")
+        assert (d <= ulp * 1.001).all(), (d / ulp).max().item()                              # never more than one fp16 step
+        assert frac <= 2e-3, frac

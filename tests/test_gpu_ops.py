@@ -501,3 +501,55 @@ def test_batchnorm_train_forward_backward(lib, B, H, W, Cc):
     _lib.check(lib.lseg_op_relu_backward(P(dyp), P(xp), P(m), xp.numel(), stream()))
     torch.cuda.synchronize()
     assert torch.equal(m, torch.where(xp.float() > 0, dyp, torch.zeros_like(dyp)))
+
+
+@pytest.mark.parametrize("with_gram", [True, False])
+@pytest.mark.parametrize("B,K,H,W", [(2, 150, 120, 120), (1, 5, 24, 24), (3, 37, 30, 17), (1, 157, 5, 3), (2, 80, 9, 31), (1, 33, 4, 15)])
+def test_corr_planes_kernel(lib, B, K, H, W, with_gram):
+    """csrc/corr.hip (lseg_op_corr_planes): the pixel x text correlation on the commuted schedule -- label planes R[b, k, p] = t_k . g_p
+    on the padded quarter-resolution map and the five 2x2-cell dot products of g, one pass over g, T resident in LDS.  Against fp64
+    torch on the same fp16 operands (what is left: fp32 accumulation order inside the MFMAs).  Shapes: BASELINE configs[1]'s map
+    (120 x 120, K = 150), every label-block instantiation (K <= 32 / <= 80 / <= 157), ragged tile edges in both directions, the largest
+    K the LDS takes; interior pixels of R and every gram record must be written, nothing outside the buffers touched (guard words)."""
+    Cc = 512
+    HP, WP = H + 2, W + 2
+    g = rnd((B, HP, WP, Cc), torch.float16, 11 + K, 0.5)
+    T = rnd((K, Cc), torch.float16, 12 + K, 1.0)
+    T = (T.float() / T.float().norm(dim=-1, keepdim=True)).half()
+    guard = 64
+    Rbuf = torch.full((B * K * HP * WP + 2 * guard,), float("nan"), dtype=torch.float32).cuda()
+    Gbuf = torch.full((B * H * W * 5 + 2 * guard,), float("nan"), dtype=torch.float32).cuda()
+    R = Rbuf[guard:guard + B * K * HP * WP].view(B, K, HP, WP)
+    G = Gbuf[guard:guard + B * H * W * 5].view(B, H, W, 5)
+    _lib.check(lib.lseg_op_corr_planes(P(g), P(T), C.c_void_p(R.data_ptr()), C.c_void_p(G.data_ptr()) if with_gram else None,
+                                       B, K, H, W, Cc, stream()))
+    torch.cuda.synchronize()
+    assert torch.isnan(Rbuf[:guard]).all() and torch.isnan(Rbuf[-guard:]).all() and torch.isnan(Gbuf[:guard]).all() and torch.isnan(Gbuf[-guard:]).all()
+    gd = g.double()
+    ref = torch.einsum("kc,byxc->bkyx", T.double(), gd)
+    got = R[:, :, 1:H + 1, 1:W + 1]
+    assert torch.isfinite(got).all(), "an interior pixel of R was not written"
+    err = (got.double() - ref[:, :, 1:H + 1, 1:W + 1]).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+    border = torch.ones((HP, WP), dtype=torch.bool)
+    border[1:H + 1, 1:W + 1] = False
+    assert torch.isnan(R[:, :, border.cuda()]).all()                 # the border is never read by the upsample and never written here
+    if with_gram:
+        a = gd[:, 1:H + 1, 1:W + 1]                                  # q = (y, x)
+        r_ = gd[:, 1:H + 1, 2:W + 2]                                 # (y, x+1)
+        d_ = gd[:, 2:H + 2, 1:W + 1]                                 # (y+1, x)
+        dr = gd[:, 2:H + 2, 2:W + 2]                                 # (y+1, x+1)
+        gref = torch.stack([(a * a).sum(-1), (a * r_).sum(-1), (a * d_).sum(-1), (a * dr).sum(-1), (r_ * d_).sum(-1)], dim=-1)
+        assert torch.isfinite(G).all(), "a gram record was not written"
+        gerr = (G.double() - gref).abs().max().item()
+        assert gerr <= 2e-5 * max(1.0, gref.abs().max().item()), gerr
+    else:
+        assert torch.isnan(Gbuf).all()
+
+
+def test_corr_planes_rejects_what_the_lds_cannot_hold(lib):
+    g = rnd((1, 6, 6, 512), torch.float16, 1)
+    T = rnd((200, 512), torch.float16, 2)
+    R = torch.zeros((1, 200, 6, 6)).cuda()
+    assert lib.lseg_op_corr_planes(P(g), P(T), P(R), None, 1, 200, 4, 4, 512, stream()) == -5          # LSEG_ERR_UNSUPPORTED: K x 1040 B > 160 KB
+    assert lib.lseg_op_corr_planes(P(g), P(T), P(R), None, 1, 8, 4, 4, 768, stream()) == -5            # other widths: the generic GEMM
