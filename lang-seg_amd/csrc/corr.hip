@@ -23,6 +23,10 @@
 //   * gram: the g fragments are A and B operand alike (same register layout), so the cell dot products are 8 more MFMAs per k-step on
 //     operands that are already there: row r with itself (diagonal: g_q.g_q, first super-diagonal: g_q.g_(x+1)) and with row r+1 (diagonal:
 //     g_q.g_(y+1,x), super: g_q.g_(y+1,x+1), sub: g_(x+1).g_(y+1,x)) -- the five records of elementwise.hip's norm_scale_plane_kernel.
+//   * MEMORY-LEVEL PARALLELISM decides the rate (lease B of round 5: with one wave per SIMD holding all 10 label blocks the kernel ran at
+//     2.0 TB/s of reads -- 1024 waves x 10 KB in flight against ~5 us of loaded latency): for K > 80 a tile is shared by TWO waves (8 per
+//     workgroup, 2 per SIMD), each taking half of the label blocks (and half of the gram products: one the row-with-itself, the other
+//     the row-with-the-row-below MFMAs) on its own register copy of the tile's g fragments (the second copy comes from L1 / L2).
 //   * tiles are dealt so that neighbours in the image run at the same time on the same XCD (its L2 serves the halo re-reads): XCD x takes
 //     the x-th eighth of the tile list, its 128 waves walk it with stride 128, the 4 waves of a workgroup hold 4 horizontally adjacent tiles.
 #include "ops.h"
@@ -30,24 +34,39 @@
 #include "../../include/lseg_hip.h"
 
 #include <atomic>
+#include <type_traits>
+#include <utility>
 
 namespace lseg {
 namespace {
 
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 constexpr int CORR_C = 512;                 // channels (out_c of clip_vitl16_384 / clip_vitb32_384); other widths take the generic GEMM
 constexpr int CORR_KS = CORR_C / 32;        // k-steps of 32 channels
+constexpr int CORR_NG = CORR_KS / 2;        // groups of two k-steps (= one 128-byte line of every pixel)
 constexpr int CORR_PITCH = CORR_C * 2 + 16; // LDS row pitch of T in bytes
+constexpr int CORR_TR = 2;                  // image rows of a wave's tile
 typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));    // a 16-byte plane store at a 4-byte aligned address (x0 = 1 + ...)
 
+// NLB = label blocks of 16 (K <= 16 NLB)
 template <int NLB, bool GRAM>
 __global__ __launch_bounds__(256, 1) void corr_planes_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ T,
                                                             float* __restrict__ R, float* __restrict__ gram, int B, int K, int H, int W,
                                                             int tiles_y, int tiles_x) {
     extern __shared__ __attribute__((aligned(16))) char tlds[];
-    constexpr int ROWS = GRAM ? 5 : 4;            // fragments per k-step: 4 tile rows (+ the halo row below)
+    constexpr int TR = CORR_TR;
+    constexpr int ROWS = GRAM ? TR + 1 : TR;      // fragments per k-step: the tile rows (+ the halo row below)
     constexpr int XSTRIDE = GRAM ? 15 : 16;       // owned columns per tile
     const int HP = H + 2, WP = W + 2;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, kg = lane >> 4;
 
     // ---- T -> LDS, once ----------------------------------------------------------------------------------------------------------
@@ -63,7 +82,7 @@ __global__ __launch_bounds__(256, 1) void corr_planes_kernel(const uint16_t* __r
         t_off[lb] = (lab < K ? lab : K - 1) * CORR_PITCH + kg * 16;
     }
 
-    // ---- this wave's tiles: XCD-contiguous chunks, stride 128 inside --------------------------------------------------------------
+    // ---- this wave's tiles: XCD-contiguous chunks, stride (waves of the XCD) inside ---------------------------------------------------
     const int ntiles = B * tiles_y * tiles_x;                                            // (launcher: < 2^31)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;      // gridDim.x is a multiple of 8
     const int chunk = (ntiles + 7) / 8;
@@ -71,90 +90,102 @@ __global__ __launch_bounds__(256, 1) void corr_planes_kernel(const uint16_t* __r
     const int step = nslot * 4;
     int t = t_begin + slot * 4 + wave;
 
-    // per-lane pointers (16-bit elements) of the ROWS fragment rows of tile `tt`; rows / columns clamped into the padded map.  The tile
-    // index is wave-uniform: one 32-bit decode per tile on the scalar unit
-    auto frag_ptrs = [&](int tt, const uint16_t* (&out)[ROWS]) {
+    // per-lane BYTE OFFSETS into g (32-bit: the launcher checks the map is < 4 GB; offsets from the kernel argument keep the loads in the
+    // global address space -- loop-carried pointers came out as flat_load, which counts on vmcnt AND lgkmcnt and drained both) of the ROWS
+    // fragment rows of tile `tt`; rows / columns clamped into the padded map.  The tile index is wave-uniform: one 32-bit decode per tile on
+    // the scalar unit
+    const char* gbase = reinterpret_cast<const char*>(g);
+    auto frag_offs = [&](int tt, uint32_t (&out)[ROWS]) {
         const unsigned ut = (unsigned)__builtin_amdgcn_readfirstlane(tt);
         const unsigned q = ut / (unsigned)tiles_x, tx = ut - q * (unsigned)tiles_x;
         const unsigned b = q / (unsigned)tiles_y, ty = q - b * (unsigned)tiles_y;
         int x = 1 + XSTRIDE * (int)tx + c;
         x = x < WP - 1 ? x : WP - 1;
-        const uint16_t* col = g + ((size_t)b * HP * WP + x) * CORR_C + kg * 8;
+        const uint32_t col = ((uint32_t)b * (uint32_t)(HP * WP) + (uint32_t)x) * (CORR_C * 2) + (uint32_t)kg * 16u;
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) {
-            int y = 1 + 4 * (int)ty + r;
+            int y = 1 + TR * (int)ty + r;
             y = y < HP - 1 ? y : HP - 1;
-            out[r] = col + (size_t)y * WP * CORR_C;
+            out[r] = col + (uint32_t)(y * WP) * (CORR_C * 2);
         }
     };
+    auto gload = [&](uint32_t off, int ks) { return *reinterpret_cast<const i32x4_t*>(gbase + off + ks * 64); };
 
-    i32x4_t buf[2][2][ROWS];                      // [group parity][k-step of the group][fragment row]
-    const uint16_t* fp[ROWS];
+    // The WHOLE tile lives in registers: buf[group][k-step of the group][fragment row].  Group j of the next tile is requested as soon as
+    // group j of the current tile has been consumed, so a wave always has one full tile (16 x ROWS KB) in flight.
+    i32x4_t buf[CORR_NG][2][ROWS];
+    uint32_t fp[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) fp[r] = 0;
     if (t < t_end) {
-        frag_ptrs(t, fp);
+        frag_offs(t, fp);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int grp = 0; grp < CORR_NG; ++grp)
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) buf[0][kk][r] = *reinterpret_cast<const i32x4_t*>(fp[r] + kk * 32);
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) buf[grp][kk][r] = gload(fp[r], grp * 2 + kk);
     }
 
     for (; t < t_end; t += step) {
-        f32x4_t acc[NLB][4];
-        f32x4_t sg[GRAM ? 4 : 1], xg[GRAM ? 4 : 1];
+        f32x4_t acc[NLB][TR];
+        f32x4_t ga[GRAM ? TR : 1], gb[GRAM ? TR : 1];            // ga[r] = row r . row r, gb[r] = row r . row r + 1 (16 x 16 pixel blocks)
 #pragma unroll
         for (int lb = 0; lb < NLB; ++lb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[lb][r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < TR; ++r) acc[lb][r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < (GRAM ? 4 : 1); ++r) { sg[r] = f32x4_t{0.f, 0.f, 0.f, 0.f}; xg[r] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+        for (int r = 0; r < (GRAM ? TR : 1); ++r) { ga[r] = f32x4_t{0.f, 0.f, 0.f, 0.f}; gb[r] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
         const int tn = t + step;
         const bool more = tn < t_end;
-        const uint16_t* np[ROWS];
+        uint32_t np[ROWS];
 #pragma unroll
         for (int r = 0; r < ROWS; ++r) np[r] = fp[r];
-        if (more) frag_ptrs(tn, np);
+        if (more) frag_offs(tn, np);
 
+        // T fragments run TD - 1 steps ahead of their MFMAs in a small register ring (a step = one label block of one k-step: one
+        // ds_read_b128, TR MFMAs): with ONE wave per SIMD nothing else hides the LDS latency
+        constexpr int TD = 4, NSTEP = CORR_KS * NLB;
+        i32x4_t tf[TD];
+        auto tread = [&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            return *reinterpret_cast<const i32x4_t*>(tlds + t_off[u % NLB] + (u / NLB) * 64);
+        };
+        static_for<0, TD - 1>([&](auto uc) { tf[decltype(uc)::value] = tread(uc); });
+        static_for<0, CORR_NG>([&](auto gc) {
+            constexpr int grp = decltype(gc)::value;
+            static_for<0, 2>([&](auto kc) {
+                constexpr int kk = decltype(kc)::value, ks = grp * 2 + kk;
+                static_for<0, NLB>([&](auto lc) {
+                    constexpr int lb = decltype(lc)::value, u = ks * NLB + lb;
+                    if constexpr (u + TD - 1 < NSTEP) tf[(u + TD - 1) % TD] = tread(std::integral_constant<int, u + TD - 1>{});
 #pragma unroll
-        for (int grp = 0; grp < CORR_KS / 2; ++grp) {
-            // request the next group (the next tile's first group during the last one) before this group's MFMAs
-            if (grp + 1 < CORR_KS / 2) {
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int r = 0; r < ROWS; ++r)
-                        buf[(grp + 1) & 1][kk][r] = *reinterpret_cast<const i32x4_t*>(fp[r] + ((grp + 1) * 2 + kk) * 32);
-            } else if (more) {
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int r = 0; r < ROWS; ++r) buf[0][kk][r] = *reinterpret_cast<const i32x4_t*>(np[r] + kk * 32);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int ks = grp * 2 + kk;
-#pragma unroll
-                for (int lb = 0; lb < NLB; ++lb) {
-                    const i32x4_t tf = *reinterpret_cast<const i32x4_t*>(tlds + t_off[lb] + ks * 64);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[lb][r] = mfma16<F16>(buf[grp & 1][kk][r], tf, acc[lb][r]);
-                }
+                    for (int r = 0; r < TR; ++r) acc[lb][r] = mfma16<F16>(buf[grp][kk][r], tf[u % TD], acc[lb][r]);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
                 if constexpr (GRAM) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        sg[r] = mfma16<F16>(buf[grp & 1][kk][r], buf[grp & 1][kk][r], sg[r]);
-                        xg[r] = mfma16<F16>(buf[grp & 1][kk][r], buf[grp & 1][kk][r + 1], xg[r]);
+                    for (int r = 0; r < TR; ++r) {
+                        ga[r] = mfma16<F16>(buf[grp][kk][r], buf[grp][kk][r], ga[r]);
+                        gb[r] = mfma16<F16>(buf[grp][kk][r], buf[grp][kk][r + 1], gb[r]);
                     }
                 }
-            }
+            });
             __builtin_amdgcn_sched_barrier(0);
-        }
+            // this group's registers are free: the same group of the NEXT tile is requested (of this tile again after the wave's last one --
+            // an unconditional load keeps the waits counted: behind a branch hipcc assumes nothing was issued and drains to vmcnt(0))
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) buf[grp][kk][r] = gload(np[r], grp * 2 + kk);
+            __builtin_amdgcn_sched_barrier(0);
+        });
 
         // ---- stores: label planes (interior pixels only: the x2 upsample reads nothing else), then the gram records ----------------
         const unsigned ut_ = (unsigned)__builtin_amdgcn_readfirstlane(t);
         const unsigned q_ = ut_ / (unsigned)tiles_x, tx = ut_ - q_ * (unsigned)tiles_x;
         const unsigned b = q_ / (unsigned)tiles_y, ty = q_ - b * (unsigned)tiles_y;
-        const int y0 = 1 + 4 * (int)ty, x0 = 1 + XSTRIDE * (int)tx;
+        const int y0 = 1 + TR * (int)ty, x0 = 1 + XSTRIDE * (int)tx;
         const size_t plane = (size_t)HP * WP;
         const int xs = x0 + 4 * kg;                                   // first of this lane's 4 pixels (D rows 4 kg .. 4 kg + 3)
 #pragma unroll
@@ -163,7 +194,7 @@ __global__ __launch_bounds__(256, 1) void corr_planes_kernel(const uint16_t* __r
             if (lab >= K) continue;
             float* pl = R + ((size_t)b * K + lab) * plane;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < TR; ++r) {
                 const int y = y0 + r;
                 if (y > H) continue;
                 float* dst = pl + (size_t)y * WP + xs;
@@ -180,7 +211,7 @@ __global__ __launch_bounds__(256, 1) void corr_planes_kernel(const uint16_t* __r
         if constexpr (GRAM) {
             // D[m][n] = g(row a, column m) . g(row b, column n); this lane: n = c, m = 4 kg + e
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < TR; ++r) {
                 const int y = y0 + r;
                 if (y > H) continue;
                 float* grow = gram + ((size_t)b * H + (y - 1)) * W * 5;
@@ -189,11 +220,11 @@ __global__ __launch_bounds__(256, 1) void corr_planes_kernel(const uint16_t* __r
                     const int m = 4 * kg + e;
                     if (m <= 14 && x0 + m <= W) {                     // records of the owned pixel (y, x0 + m)
                         float* rec = grow + (size_t)(x0 + m - 1) * 5;
-                        if (c == m) { rec[0] = sg[r][e]; rec[2] = xg[r][e]; }
-                        if (c == m + 1) { rec[1] = sg[r][e]; rec[3] = xg[r][e]; }
+                        if (c == m) { rec[0] = ga[r][e]; rec[2] = gb[r][e]; }
+                        if (c == m + 1) { rec[1] = ga[r][e]; rec[3] = gb[r][e]; }
                     }
                     if (c == m - 1 && c <= 14 && x0 + c <= W)          // g(y, x+1) . g(y+1, x) belongs to the pixel in column n = c
-                        grow[(size_t)(x0 + c - 1) * 5 + 4] = xg[r][e];
+                        grow[(size_t)(x0 + c - 1) * 5 + 4] = gb[r][e];
                 }
             }
         }
@@ -206,9 +237,10 @@ template <int NLB, bool GRAM>
 int launch_corr(const void* g, const void* T, float* R, float* gram, int B, int K, int H, int W, hipStream_t st) {
     int dev = 0;
     LSEG_HIP_TRY(hipGetDevice(&dev));
-    const int tiles_y = (H + 3) / 4, tiles_x = GRAM ? (W + 14) / 15 : (W + 15) / 16;
+    const int tiles_y = (H + CORR_TR - 1) / CORR_TR, tiles_x = GRAM ? (W + 14) / 15 : (W + 15) / 16;
     const long ntiles = (long)B * tiles_y * tiles_x;
-    if (ntiles >= (1L << 31)) return set_error(LSEG_ERR_UNSUPPORTED, "corr_planes: %ld tiles", ntiles);
+    if (ntiles >= (1L << 31) || (size_t)B * (H + 2) * (W + 2) * CORR_C * 2 >= ((size_t)1 << 32))
+        return set_error(LSEG_ERR_UNSUPPORTED, "corr_planes: B=%d %dx%d exceeds the kernel's 32-bit offsets", B, H, W);
     int grid = device_cu_count(dev) & ~7;
     if (grid < 8) grid = 8;
     const long want = ((ntiles + 3) / 4 + 7) / 8 * 8;                // no more workgroups than tiles / 4 (each copies T into its LDS)

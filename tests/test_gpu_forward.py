@@ -310,6 +310,11 @@ _REF_FULL = sorted(f[:-3] for f in os.listdir(_GOLD) if f.startswith("ref_full_"
 # reference) already differ by 0.002-0.004 (tests/test_oracle_ref_golden.py)
 REF_TOL = {"bf16": 0.30, "fp16": 0.06, "strict": 0.012}
 STAGE_TOL = {"bf16": 0.10, "fp16": 0.015, "strict": 2e-3}
+# the realistic-statistics fixture (`*_outlier`: residual outlier channels ~1e3 next to O(1) ones, LayerNorm gains of 10, x10 BatchNorm
+# scales; oracle/make_ref_golden.py): the 16-bit towers lose 1.5-2.5x more per stage and per logit there -- measured, lease B of round 5
+# (profiles/r05_parity_table.txt): hooked activations rel. rms bf16 0.136 / fp16 0.016, max |dlogit| bf16 0.200 / fp16 0.064 / strict 0.0049
+REF_TOL_BY_NAME = {"ref_full_vitl16_480x480_k150_outlier": {"bf16": 0.35, "fp16": 0.11, "strict": 0.012}}
+STAGE_TOL_BY_NAME = {"ref_full_vitl16_480x480_k150_outlier": {"bf16": 0.22, "fp16": 0.03, "strict": 2e-3}}
 
 
 def assert_argmax_mismatches_are_ties(out_low_or_logits, ref_argmax, ref_margin, err, what):
@@ -384,7 +389,8 @@ def test_engine_matches_the_reference_at_the_baseline_configs(name, dtype, golde
     eng.set_debug(True)
     out = eng.forward(x.cuda())
     torch.cuda.synchronize()
-    stage_tol = STAGE_TOL[dtype]
+    stage_tol = STAGE_TOL_BY_NAME.get(name, STAGE_TOL)[dtype]
+    ref_tol = REF_TOL_BY_NAME.get(name, REF_TOL)[dtype]
     ntok = cfg.tokens(H, W)
     for l in range(4):
         a = eng.intermediate(f"act{l + 1}", (B, ntok, cfg.dim)).cpu()[:, ::8, :]
@@ -405,7 +411,7 @@ def test_engine_matches_the_reference_at_the_baseline_configs(name, dtype, golde
     err_top2 = (low.gather(1, g["top2_idx"].long()) - g["top2_val"].float()).abs().max().item()
     err = max(err, err_top2)
     print(f"{name}[{dtype}]: lowres max|d| {err:.4f}, logits max|d| {err_out:.4f} (range {g['lowres_absmax']:.2f})")
-    assert err <= REF_TOL[dtype] and err_out <= REF_TOL[dtype], (name, dtype, err, err_out)
+    assert err <= ref_tol and err_out <= ref_tol, (name, dtype, err, err_out)
     frac = assert_argmax_mismatches_are_ties(low, g["argmax_lowres"].long(), g["margin_lowres"].float(), err, f"{name}[{dtype}]")
     out_dir = os.path.join(os.path.dirname(golden_dir), "..", "gpurun_out")
     if os.path.isdir(out_dir):                     # the parity table of DESIGN.md §4 is made from these lines
@@ -431,7 +437,8 @@ MASK480_CAPS = {150: {"bf16": (0.035, 0.15), "fp16": (0.005, 0.02), "strict": (0
 
 # the realistic-statistics fixture (residual outliers ~1e3 next to O(1) channels; the reference's median top-2 margin there is 0.45, so a
 # flip needs a larger logit error than on the N(0, 0.02) net): measured r5 -- see profiles/r05_parity_table.txt
-MASK480_CAPS_BY_NAME = {"ref_full_vitl16_480x480_k150_outlier": {"bf16": (0.035, 0.15), "fp16": (0.005, 0.02), "strict": (0.003, 0.006)}}
+# (bf16 0.164 % / 0.070, fp16 0.056 % / 0.021, strict 0.015 % / 0.0021: fewer flips than on the N(0, 0.02) net at LARGER logit errors)
+MASK480_CAPS_BY_NAME = {"ref_full_vitl16_480x480_k150_outlier": {"bf16": (0.004, 0.12), "fp16": (0.0015, 0.04), "strict": (0.0005, 0.005)}}
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16", "strict"])
@@ -468,7 +475,7 @@ def test_engine_masks_match_the_reference_at_480x480(name, dtype, golden_dir):
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "parity_table.txt"), "a") as f:
             f.write(f"{name} {dtype} 480x480: max|dlogit| {err:.5f}  argmax mismatch fraction {frac:.6f}  max reference margin at a mismatch {worst:.5f}\n")
-    assert err <= REF_TOL[dtype], (name, dtype, err)
+    assert err <= REF_TOL_BY_NAME.get(name, REF_TOL)[dtype], (name, dtype, err)
     assert worst <= 2 * err + 1e-6 and worst <= cap_margin and frac <= cap_frac, (name, dtype, frac, worst, err)
     if K <= 256:
         only = eng.forward(x, want_logits=False, want_argmax=True)
