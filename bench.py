@@ -72,13 +72,12 @@ def parse():
                     help="multi-GPU training leg with SyncBatchNorm (the reference's utils.py:34: 56 tiny all-reduces per step); default "
                          "for N > 1 is per-GPU statistics = no collective besides the gradient all-reduce (BASELINE north_star)")
     ap.add_argument("--cpu-threads", type=int, default=0,
-                    help="threads for the CPU baseline (0 = all host cores, os.cpu_count(); the 32-thread figure is timed next to it)")
+                    help="threads for the CPU baseline (0 = 32 and 64 threads, the faster is reported)")
     ap.add_argument("--no-pmc-traffic", action="store_true",
                     help="do not collect FETCH_SIZE / WRITE_SIZE of the dominant kernel in this run (two rocprofv3 --pmc child passes over 2 "
                          "forwards each, N = 1 only, ~1 min, outside the timed region); roofline.traffic then replays profiles/rNN_traffic.json "
                          "and says so")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)     # the workload of one counter pass: 1 + 2 forwards
-    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)   # one thread count of the CPU baseline
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous check without a GPU (tests): every rank joins a gloo group, rank 0 prints {n_gpus, ranks} and leaves")
     return ap.parse_args()
@@ -232,66 +231,27 @@ def _cpu_forward_times(cfg, sd, tok, size, threads, samples):
     return times
 
 
-def numa_node0_cpus():
-    """CPU ids of NUMA node 0 (sysfs), or None."""
-    try:
-        ids = []
-        for part in open("/sys/devices/system/node/node0/cpulist").read().strip().split(","):
-            a, _, b = part.partition("-")
-            ids += list(range(int(a), int(b or a) + 1))
-        return ids or None
-    except Exception:                                     # noqa: BLE001
-        return None
-
-
-def cpu_baseline_child(args):
-    """One thread count of the CPU baseline in its own process (bounded by the parent's timeout), pinned to NUMA node 0's cores when
-    --cpu-threads equals their number: prints the sample times."""
-    from lseg_hip.config import get_config
-    from lseg_hip.synth import synthetic_state_dict, synthetic_tokens, read_labels
-    node0 = numa_node0_cpus()
-    if node0 and len(node0) == args.cpu_threads and hasattr(os, "sched_setaffinity"):
-        try:
-            os.sched_setaffinity(0, set(node0))
-        except OSError:
-            pass
-    cfg = get_config(args.backbone)
-    labels = read_labels(os.path.join(ROOT, "lang-seg_amd", "label_files", "ade20k_objectInfo150.txt"))[: args.labels]
-    tok = synthetic_tokens(labels, cfg.text.vocab, cfg.text.ctx)
-    print(json.dumps({"cpu_times": _cpu_forward_times(cfg, synthetic_state_dict(cfg, seed=0), tok, args.size, args.cpu_threads, args.cpu_samples)}), flush=True)
-
-
 def cpu_baseline(cfg, sd, tok, size, threads, samples=3, args=None):
     """The CPU oracle (a port of the reference forward, oracle/lseg_oracle.py) timed on this box's host cores.  BOUNDED sample: B = 1
     forwards of the same workload (fp32 image tower + fp16-emulated text tower recomputed, reference semantics); the median is reported.
-    SURVEY.md par. 8d asks for os.cpu_count() threads, but torch CPU GEMMs thrash across the sockets of a many-core host: in round 4 two
-    forwards at all 256 cores did not finish in 90 s (and cost the driver's run those 90 s) against 3.3 s at 32 threads.  So: 32 threads
-    in this process, and ONE NUMA NODE's cores (pinned, child process, 45 s limit, 2 samples) next to it; `value` is the faster of the two
-    with its own `cores`, both are listed under `by_threads`."""
-    import subprocess
+    SURVEY.md par. 8d asks for os.cpu_count() threads, but torch's CPU GEMMs thrash far below the core count of a two-socket 256-core host:
+    two forwards did not finish in 90 s at all 256 cores (round 4) nor in 45 s pinned to one NUMA node's 128 (round 5, lease B), against
+    1.9 s at 32 threads.  So: 32 threads (`samples` forwards) and 64 threads (2 forwards), both in this process; `value` is the faster of
+    the two with its own `cores`; both are listed under `by_threads`.  ~10-15 s in total."""
     ncpu = os.cpu_count() or 1
     base = threads or min(32, ncpu)
     by = {base: {"seconds": [round(t, 2) for t in _cpu_forward_times(cfg, sd, tok, size, base, samples)]}}
-    node0 = numa_node0_cpus()
-    nn = len(node0) if node0 else 0
-    if not threads and nn > base and nn < ncpu and args is not None:
-        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--cpu-threads", str(nn), "--cpu-samples", "2",
-               "--labels", str(args.labels), "--size", str(args.size), "--backbone", args.backbone]
-        try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=45, env={**os.environ, "CUDA_VISIBLE_DEVICES": "", "HIP_VISIBLE_DEVICES": ""})
-            line = next((l for l in r.stdout.splitlines() if l.startswith("{")), None)
-            by[nn] = {"seconds": [round(t, 2) for t in json.loads(line)["cpu_times"]], "pinned_to": "NUMA node 0"} if line else {"error": (r.stderr or "no output")[-200:]}
-        except subprocess.TimeoutExpired:
-            by[nn] = {"timeout_s": 45, "note": "2 forwards on NUMA node 0's cores did not finish in 45 s"}
+    if not threads and ncpu >= 64:
+        by[64] = {"seconds": [round(t, 2) for t in _cpu_forward_times(cfg, sd, tok, size, 64, 2)]}
     med = {n: sorted(v["seconds"])[len(v["seconds"]) // 2] for n, v in by.items() if v.get("seconds")}
     best = min(med, key=med.get)
     for n in med:
         by[n]["images_per_sec"] = round(1.0 / med[n], 4)
     return {"value": round(1.0 / med[best], 4), "unit": "images/sec", "cores": best, "kind": "port",
-            "by_threads": {str(n): v for n, v in by.items()}, "host_cores": ncpu, "numa_node0_cores": nn or None,
+            "by_threads": {str(n): v for n, v in by.items()}, "host_cores": ncpu,
             "sample": f"median of the timed B=1 forwards of the same workload (torch-CPU oracle, text tower recomputed): {len(by[base]['seconds'])} at "
-                      f"{base} threads in-process" + (f", 2 on NUMA node 0's {nn} cores in a pinned child process (45 s limit)" if nn in by else "") +
-                      "; value = the faster thread count; all-cores runs thrash (round 4: > 90 s for 2 forwards at 256 threads) and are not attempted"}
+                      f"{base} threads" + (", 2 at 64 threads" if 64 in by else "") + ", in-process; value = the faster thread count; larger thread "
+                      "counts thrash on this host (128 pinned to one NUMA node: > 45 s for 2 forwards; 256: > 90 s) and are not attempted"}
 
 
 def build_id():
@@ -495,8 +455,6 @@ def latest_traffic_file():
 
 def main():
     args = parse()
-    if args.cpu_baseline_child:
-        return cpu_baseline_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))          # N ranks, one per GPU; this process only waits for them
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
