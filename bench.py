@@ -538,7 +538,7 @@ def main():
     eng = engines[chosen]
 
     # ---- which kernel symbol dominates: one untimed pass with every family bracketed by HIP events ---------------------------------
-    fams = ["mlp_fc1", "mlp_fc2", "attn_proj", "attn_qkv", "attention", "layernorm"]
+    fams = ["mlp_fc1", "mlp_fc2", "attn_proj", "attn_qkv", "attention", "layernorm", "correlation"]
     eng.set_profiling(["forward"] + fams)
     for _ in range(2):
         eng.forward(x)
@@ -629,7 +629,15 @@ def main():
             if not p_["launches"]:
                 continue
             avg = p_["total_ms"] / p_["launches"]
-            if f == "layernorm":
+            if f == "correlation":
+                # csrc/corr.hip: label planes + cell dot products in one pass; the family's "flops" slot carries its ALGORITHMIC BYTES
+                # (g read once, planes + gram records written, T once: DESIGN par. 3.4)
+                gb = p_["flops_per_launch"] / 1e9
+                kern[f] = {"bound": "hbm", "kernel": "corr_planes_kernel (pixel x text label planes + 2x2-cell dot products of g, one pass)",
+                           "avg_launch_ms": round(avg, 5), "algorithmic_MB": round(gb * 1e3, 1), "achieved_GBps": round(gb / (avg * 1e-3), 1),
+                           "frac": round(gb / (avg * 1e-3) / 8000.0, 4),
+                           "mfma_TFLOPs": round(2.0 * K * 512 * B * (args.size // 4 + 2) ** 2 / (avg * 1e-3) / 1e12, 1)}
+            elif f == "layernorm":
                 gb = Mtok * cfg.dim * (4 + 2) / 1e9          # fp32 row in, 16-bit row out
                 kern[f] = {"bound": "hbm", "avg_launch_ms": round(avg, 5), "achieved_GBps": round(gb / (avg * 1e-3), 1),
                            "frac": round(gb / (avg * 1e-3) / 8000.0, 4)}

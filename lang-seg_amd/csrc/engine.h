@@ -239,7 +239,7 @@ private:
 
     // ---- profiling: HIP-event pairs around kernel families on the caller's stream (lseg_set_profiling mask bit = family index) --------
 public:
-    enum ProfFamily { PF_FWD = 0, PF_FC1, PF_FC2, PF_PROJ, PF_QKV, PF_ATTN, PF_LN, PF_N };
+    enum ProfFamily { PF_FWD = 0, PF_FC1, PF_FC2, PF_PROJ, PF_QKV, PF_ATTN, PF_LN, PF_CORR, PF_N };
     unsigned prof_mask = 0;
     int reserve_events(int n);
     int events_per_forward() const;

@@ -633,9 +633,9 @@ void Engine::prof_end(int fam, hipEvent_t e0, double flops, hipStream_t st) {
 // event pairs one forward records under the current mask (sizing of the pre-created pool)
 int Engine::events_per_forward() const {
     int n = 0;
-    const int per_block[PF_N] = {0, 1, 1, 1, 1, 1, 2};
+    const int per_block[PF_N] = {0, 1, 1, 1, 1, 1, 2, 0};
     for (int f = 0; f < PF_N; ++f)
-        if ((prof_mask >> f) & 1u) n += f == PF_FWD ? 1 : per_block[f] * cfg.depth;
+        if ((prof_mask >> f) & 1u) n += (f == PF_FWD || f == PF_CORR) ? 1 : per_block[f] * cfg.depth;
     return n;
 }
 
@@ -672,7 +672,7 @@ int Engine::check_range(unsigned long long* host_out4, hipStream_t st) {
 
 int Engine::get_profile(const char* family, double* ms, int64_t* launches, double* flops) {
     TRY(flush_events());
-    static const char* names[PF_N] = {"forward", "mlp_fc1", "mlp_fc2", "attn_proj", "attn_qkv", "attention", "layernorm"};
+    static const char* names[PF_N] = {"forward", "mlp_fc1", "mlp_fc2", "attn_proj", "attn_qkv", "attention", "layernorm", "correlation"};
     ProfileSlot* s = nullptr;
     for (int f = 0; f < PF_N; ++f)
         if (!strcmp(family, names[f])) s = &pf_[f].slot;
@@ -893,8 +893,11 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
         // per-image label sets (zero-shot), other widths and label sets that do not fit the LDS take the generic GEMM + pixel_gram pair
         static const bool corr_generic = getenv("LSEG_CORR_GENERIC") != nullptr;    // A/B switch (tools, tests): the round-4 pair
         const bool corr_fused = !corr_generic && group_k == 0 && corr_planes_supported(K_, c.out_c);
+        hipEvent_t pc = prof_begin(PF_CORR, st);       // "correlation": label planes + cell dot products (the dedicated kernel; algorithmic BYTES in flops)
         if (corr_fused) TRY(launch_corr_planes(g16pad_, tnorm_, rpl_, gram_, B, K_, lh_[0], lw_[0], c.out_c, st));
         else TRY(launch_pixel_gram(g16pad_, gram_, B, lh_[0], lw_[0], c.out_c, st));
+        if (corr_fused) prof_end(PF_CORR, pc, (double)B * hp * wp * c.out_c * 2.0 + (double)B * K_ * lh_[0] * lw_[0] * 4.0 + (double)B * lh_[0] * lw_[0] * 20.0 +
+                                              (double)K_ * c.out_c * 2.0, st);
         TRY(launch_norm_scale_plane(gram_, nscale_, B, lh_[0], lw_[0], logit_scale, st));
         if (corr_fused) {
         } else if (group_k > 0) {

@@ -371,7 +371,7 @@ class HipEngine:
         return {"nonfinite": int(out[0]), "near_fp16_limit": int(out[1]),
                 "max_abs": struct.unpack("f", struct.pack("I", int(out[2]) & 0xffffffff))[0], "scanned": int(out[3])}
 
-    PROFILE_FAMILIES = ("forward", "mlp_fc1", "mlp_fc2", "attn_proj", "attn_qkv", "attention", "layernorm")
+    PROFILE_FAMILIES = ("forward", "mlp_fc1", "mlp_fc2", "attn_proj", "attn_qkv", "attention", "layernorm", "correlation")
 
     def set_profiling(self, enabled):
         """True = HIP-event timing of the whole forward + the MLP fc1 GEMM; a list of family names (PROFILE_FAMILIES) = exactly those;

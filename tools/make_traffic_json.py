@@ -8,7 +8,7 @@ import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "profiles", "summary.json")
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 36
-dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r04_traffic.json")
+dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r05_traffic.json")
 dtype = sys.argv[4] if len(sys.argv) > 4 else "fp16"
 commit = sys.argv[5] if len(sys.argv) > 5 else None
 S = json.load(open(src))
@@ -70,6 +70,9 @@ entry("qkv_gemm", g(4, 0), 2 * (M * D + 3 * D * D + M * 3 * D), 2.0 * M * 3 * D 
 entry("attention", lambda k: "lseg_attention_kernel<" + T + ", 4, 2, true>" in k, 2 * 4 * B * 16 * 1024 * 64, 4.0 * B * ntok * ntok * D)
 # ---- HBM-bound kernels of the head: algorithmic bytes = what the schedule must move once
 P122, P120 = B * 122 * 122, B * 120 * 120
+# round 5: ONE dedicated kernel (csrc/corr.hip) for the label planes AND the cell dot products: g read once, interior planes + gram records
+# written, T once (the entries below it are the round-4 pair, present only under LSEG_CORR_GENERIC=1)
+entry("correlation", lambda k: "corr_planes_kernel<10, true>" in k, 2 * P122 * 512 + 2 * K * 512 + 4 * K * P120 + 4 * 5 * P120, 2.0 * K * P122 * 512, bound="hbm")
 entry("correlation_label_planes", lambda k: "lseg_gemm_kernel<lseg::F16" in k and "TileCfg<160, 128" in k,
       2 * P122 * 512 + 2 * K * 512 + 4 * K * P122, 2.0 * K * P122 * 512, bound="hbm")
 entry("upsample4x_logits", lambda k: "upsample4x_planes_scaled_kernel" in k, 4 * K * P122 + 4 * B * 240 * 240 + 4 * B * K * 480 * 480, bound="hbm")

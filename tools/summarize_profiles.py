@@ -36,8 +36,8 @@ for f in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), 
             pm.setdefault("|".join(k), {})[c] = sum(v) / len(v)
             pm["|".join(k)]["_launches"] = len(v)
 print("\n== PMC per-launch averages for the largest GEMM / attention instances")
-nbig = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-big = sorted((k for k in pm if "gemm_kernel" in k or "attention" in k or "attn_" in k), key=lambda k: -pm[k].get("GRBM_GUI_ACTIVE", pm[k].get("FETCH_SIZE", 0)))[:nbig]
+nbig = int(sys.argv[2]) if len(sys.argv) > 2 else 9
+big = sorted((k for k in pm if "gemm_kernel" in k or "attention" in k or "attn_" in k or "corr_planes" in k), key=lambda k: -pm[k].get("GRBM_GUI_ACTIVE", pm[k].get("FETCH_SIZE", 0)))[:nbig]
 for k in big:
     print(short(k)[:150])
     for c, v in sorted(pm[k].items()):
