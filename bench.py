@@ -351,7 +351,7 @@ def boundary_leg(args, cfg, sd, labels, dtype, x, sync):
 
 def eval_leg(args, cfg, sd, labels, dtype, sync):
     """the workload test_lseg.py runs per image (additional_utils/encoding_models.py:54-139): 6 scales + flip, crop 480 /
-    base 520, one 512x683 image, ViT-L/16, K = 150 -- BatchedMultiEval (crops + mirrored twins of a scale in one batch, data movement in
+    base 520, one 512x683 image, ViT-L/16, K = 150 -- BatchedMultiEval (ALL crops of ALL scales + their mirrored twins in one batch-36 forward, data movement in
     csrc/evaluator.hip, label set encoded once) beside the reference's literal schedule on the same network (36 B = 1 forwards, each
     re-encoding the labels, torch ops for pad / crop / flip / accumulate)."""
     import warnings
@@ -367,7 +367,7 @@ def eval_leg(args, cfg, sd, labels, dtype, sync):
     crops = [scale_geometry(512, 683, s_, 520, 480)[4] * scale_geometry(512, 683, s_, 520, 480)[5] for s_ in scales]
     res = {}
     with torch.no_grad():
-        for tag, ev, n in (("batched", BatchedMultiEval(mod, len(labels), flip=True, scales=scales, max_batch=16), 3),
+        for tag, ev, n in (("batched", BatchedMultiEval(mod, len(labels), flip=True, scales=scales), 3),
                            ("sequential_reference_schedule", SequentialMultiEval(mod, len(labels), flip=True, scales=scales), 2)):
             got = ev(img)
             sync()
@@ -382,7 +382,7 @@ def eval_leg(args, cfg, sd, labels, dtype, sync):
     res["max_abs_score_difference"] = round(d, 5)
     res["argmax_agreement"] = round((a.argmax(1) == b.argmax(1)).float().mean().item(), 6)
     res["speedup"] = round(res["batched"]["images_per_sec"] / res["sequential_reference_schedule"]["images_per_sec"], 2)
-    res["forwards_per_image"] = {"crops_per_scale": crops, "reference_b1_forwards": 2 * sum(crops), "batched_forwards": len(scales)}
+    res["forwards_per_image"] = {"crops_per_scale": crops, "reference_b1_forwards": 2 * sum(crops), "batched_forwards": 1}
     res["what"] = ("one 512x683 image, scales 0.5-1.75 + flip, crop 480 / base 520, K = 150, " + dtype + " operands; scores = sum over scales of "
                    "the count-normalised overlap-added crop logits (not bit-equal between the two: split-K at small batches and torch-vs-device "
                    "resize round differently; tests/test_gpu_evaluator.py holds the batch-invariant schedule to 1e-5)")

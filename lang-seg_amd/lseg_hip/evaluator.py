@@ -74,7 +74,7 @@ class BatchedMultiEval(torch.nn.Module):
     `module` needs .evaluate(x) / .evaluate_random(x, labels), .base_size, .crop_size, .mean, .std,
     ._up_kwargs (the LSegModule surface, modules/lseg_module.py:29-93)."""
 
-    def __init__(self, module, nclass, flip=True, scales=(0.5, 0.75, 1.0, 1.25, 1.5, 1.75), max_batch=16, cache_text=True):
+    def __init__(self, module, nclass, flip=True, scales=(0.5, 0.75, 1.0, 1.25, 1.5, 1.75), max_batch=36, cache_text=True):
         """cache_text: encode a label set ONCE per evaluator call chain instead of once per crop batch (the reference re-runs the CLIP text
         tower inside every one of its ~36 forwards per image, lseg_net.py:183 -- the same tokens through the same frozen weights: exact).
         Applied to the wrapped network (`module.net`, an LSegNet) for the duration of a forward and restored afterwards; the engine
@@ -130,6 +130,11 @@ class BatchedMultiEval(torch.nn.Module):
         pad = (C.c_float * 3)(*[float(v) for v in (-np.array(self.module.mean) / np.array(self.module.std))])
         image = image.contiguous()
         scores = image.new_zeros((1, nclass, h, w))
+        # EVERY crop of EVERY scale is crop x crop: all of them (and their mirrored twins) go through the network as ONE stack, in chunks of
+        # max_batch -- a 4:3 ADE image is 36 crops = one batch-36 forward where the per-scale form ran six forwards of 2 .. 12 crops, each at
+        # the low-occupancy end of the engine's batch sweep (DESIGN par. 3.8).  Crops are independent in the engine, so the per-crop logits
+        # are those of the per-scale form (bit for bit under the batch-invariant schedule).
+        geo, stacks = [], []
         for scale in self.scales:
             height, width, ph, pw, h_grids, w_grids, stride = scale_geometry(h, w, scale, self.base_size, crop)
             cur = image.new_empty((ch, height, width))
@@ -137,8 +142,15 @@ class BatchedMultiEval(torch.nn.Module):
             n = h_grids * w_grids
             crops = image.new_empty(((2 if self.flip else 1) * n, ch, crop, crop))
             _lib.check(lib.lseg_op_eval_make_crops(P(cur), P(crops), ch, height, width, crop, stride, h_grids, w_grids, int(self.flip), pad, st))
-            outs = self._module_eval(crops, label_set).contiguous()              # one batched pass per scale (chunks of max_batch)
-            assert outs.shape == (crops.shape[0], nclass, crop, crop) and outs.dtype == torch.float32
+            geo.append((height, width, ph, pw, h_grids, w_grids, stride, crops.shape[0]))
+            stacks.append(crops)
+        allc = torch.cat(stacks, dim=0) if len(stacks) > 1 else stacks[0]
+        outs_all = self._module_eval(allc, label_set).contiguous()
+        assert outs_all.shape == (allc.shape[0], nclass, crop, crop) and outs_all.dtype == torch.float32
+        o0 = 0
+        for (height, width, ph, pw, h_grids, w_grids, stride, nc) in geo:
+            outs = outs_all[o0:o0 + nc]                                       # a contiguous slice: this scale's crops (+ twins)
+            o0 += nc
             smap = image.new_empty((nclass, height, width))
             _lib.check(lib.lseg_op_eval_accumulate(P(outs), P(smap), nclass, height, width, ph, pw, crop, stride, h_grids, w_grids,
                                                    int(self.flip), st))

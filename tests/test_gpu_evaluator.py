@@ -141,7 +141,7 @@ def test_batched_evaluator_at_crop_480_vitl16_equals_the_sequential_schedule(dty
     scales = [0.5, 0.75, 1.0, 1.25, 1.5, 1.75]
     with torch.no_grad():
         ref = _reference_schedule(mod, img, len(labels), scales, flip=True)
-        got = BatchedMultiEval(mod, len(labels), flip=True, scales=scales, max_batch=16)(img)
+        got = BatchedMultiEval(mod, len(labels), flip=True, scales=scales)(img)
         seq = SequentialMultiEval(mod, len(labels), flip=True, scales=scales)(img) if dtype == "fp16" else None
     assert got.shape == ref.shape == (1, 150, 512, 683)
     scale = ref.abs().max().item()
