@@ -314,7 +314,9 @@ STAGE_TOL = {"bf16": 0.10, "fp16": 0.015, "strict": 2e-3}
 # scales; oracle/make_ref_golden.py): the 16-bit towers lose 1.5-2.5x more per stage and per logit there -- measured, lease B of round 5
 # (profiles/r05_parity_table.txt): hooked activations rel. rms bf16 0.136 / fp16 0.016, max |dlogit| bf16 0.200 / fp16 0.064 / strict 0.0049
 REF_TOL_BY_NAME = {"ref_full_vitl16_480x480_k150_outlier": {"bf16": 0.35, "fp16": 0.11, "strict": 0.012}}
-STAGE_TOL_BY_NAME = {"ref_full_vitl16_480x480_k150_outlier": {"bf16": 0.22, "fp16": 0.06, "strict": 2e-3}}     # fp16: act1 0.016, act2 0.041 (lease C)
+# (hooked activations, fp16 operands: act1 0.016, act2 0.041, act3 0.060 -- the error of the three x1000 outlier channels dominates the rms and
+# grows with depth; bf16: act2 0.136, all four <= 0.22; leases B-D of round 5.  Bars ~2x the largest measured.)
+STAGE_TOL_BY_NAME = {"ref_full_vitl16_480x480_k150_outlier": {"bf16": 0.30, "fp16": 0.12, "strict": 2e-3}}
 
 
 def assert_argmax_mismatches_are_ties(out_low_or_logits, ref_argmax, ref_margin, err, what):
@@ -395,6 +397,7 @@ def test_engine_matches_the_reference_at_the_baseline_configs(name, dtype, golde
     for l in range(4):
         a = eng.intermediate(f"act{l + 1}", (B, ntok, cfg.dim)).cpu()[:, ::8, :]
         r = relrms(a, g["acts_sub"][l].float())
+        print(f"{name}[{dtype}] act{l + 1}: relative rms error {r:.5f} (bar {stage_tol})")
         assert r <= stage_tol, (f"act{l + 1}", r)
     p1 = eng.intermediate("path1", (B, cfg.features, H // 2, W // 2)).cpu()[:, :, ::8, ::8]
     assert relrms(p1, g["path_1_sub8"].float()) <= stage_tol
