@@ -110,9 +110,9 @@ int Engine::init() {
     const size_t M = B * ntok_;
     ALLOC(x_, float, M * D);
     // split-K partial slabs of the residual GEMMs / deep convs at small batches (forward(): "split-K"): ns K-ranges of M rows each.  16 384
-    // rows (64 MB at D = 1024) hold what Engine::split_residual's cost model asks for up to B = 8 (2 ranges of 7 208 rows: 256 x 256 tiles,
-    // mlp.fc2 110 -> 89 us by the model) and 4 ranges at B = 4; round 4's 8 192 rows capped B = 4 at 2 ranges and B >= 5 at none
-    // (profiles/r05_small_batch_traces.txt).  LSEG_SPLIT_ROWS: A/B switch (tools)
+    // rows (64 MB at D = 1024) hold 4 ranges at B = 4 -- what Engine::split_residual's cost model asks for there (256 x 256 tiles for
+    // mlp.fc2); round 4's 8 192 rows capped B = 4 at 2 ranges.  Measured, lease F of round 5 (tools/step_probe.py, fp16, two interleaved
+    // rounds): B = 4 633 -> 654 img/s, B = 6 721 -> 718, B = 2 / 8 / 12 unchanged.  LSEG_SPLIT_ROWS: A/B switch (tools)
     static const long split_rows_env = getenv("LSEG_SPLIT_ROWS") ? atol(getenv("LSEG_SPLIT_ROWS")) : 0;
     ws_split_rows_ = split_rows_env > 0 ? (size_t)split_rows_env : 16384;
     ALLOC(ws_split_, float, ws_split_rows_ * D);
