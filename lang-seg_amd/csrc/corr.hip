@@ -34,7 +34,6 @@
 #include "../../include/lseg_hip.h"
 
 #include <atomic>
-#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -56,12 +55,9 @@ constexpr int CORR_PITCH = CORR_C * 2 + 16; // LDS row pitch of T in bytes
 constexpr int CORR_TR = 2;                  // image rows of a wave's tile
 typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));    // a 16-byte plane store at a 4-byte aligned address (x0 = 1 + ...)
 
-// NLB = label blocks of 16 PER WAVE, LSPLIT = waves per tile (K <= 16 NLB LSPLIT): with LSPLIT = 2 a workgroup has 8 waves, two per SIMD, and
-// the two waves of a tile each take half of the label blocks and half of the gram products on their own register copy of the tile's g
-// fragments (the second copy comes out of L1 / L2).  One wave per SIMD with all 10 label blocks was LATENCY / ISSUE-bound: 284 us at 1.12x
-// traffic = 3.4 TB/s of fabric traffic, 12 % MFMA (profiles/r05_traffic.json) -- nothing overlaps a lone wave's LDS waits, epilogue and stores.
-template <int NLB, int LSPLIT, bool GRAM>
-__global__ __launch_bounds__(256 * LSPLIT, LSPLIT) void corr_planes_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ T,
+// NLB = label blocks of 16 (K <= 16 NLB)
+template <int NLB, bool GRAM>
+__global__ __launch_bounds__(256, 1) void corr_planes_kernel(const uint16_t* __restrict__ g, const uint16_t* __restrict__ T,
                                                             float* __restrict__ R, float* __restrict__ gram, int B, int K, int H, int W,
                                                             int tiles_y, int tiles_x) {
     extern __shared__ __attribute__((aligned(16))) char tlds[];
@@ -70,12 +66,11 @@ __global__ __launch_bounds__(256 * LSPLIT, LSPLIT) void corr_planes_kernel(const
     constexpr int XSTRIDE = GRAM ? 15 : 16;       // owned columns per tile
     const int HP = H + 2, WP = W + 2;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = wv / LSPLIT, half = wv - wave * LSPLIT;      // tile slot of the workgroup (0 .. 3); share of the labels / gram products
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, kg = lane >> 4;
 
     // ---- T -> LDS, once ----------------------------------------------------------------------------------------------------------
-    for (int i = tid; i < K * (CORR_C / 8); i += 256 * LSPLIT) {
+    for (int i = tid; i < K * (CORR_C / 8); i += 256) {
         const int row = i / (CORR_C / 8), ch = i - row * (CORR_C / 8);
         *reinterpret_cast<i32x4_t*>(tlds + row * CORR_PITCH + ch * 16) = *reinterpret_cast<const i32x4_t*>(T + (size_t)row * CORR_C + ch * 8);
     }
@@ -83,7 +78,7 @@ __global__ __launch_bounds__(256 * LSPLIT, LSPLIT) void corr_planes_kernel(const
     int t_off[NLB];                               // this lane's T row (label 16 lb + c, clamped: rows >= K are computed and dropped)
 #pragma unroll
     for (int lb = 0; lb < NLB; ++lb) {
-        const int lab = (half * NLB + lb) * 16 + c;
+        const int lab = lb * 16 + c;
         t_off[lb] = (lab < K ? lab : K - 1) * CORR_PITCH + kg * 16;
     }
 
@@ -116,18 +111,16 @@ __global__ __launch_bounds__(256 * LSPLIT, LSPLIT) void corr_planes_kernel(const
     };
     auto gload = [&](uint32_t off, int ks) { return *reinterpret_cast<const i32x4_t*>(gbase + off + ks * 64); };
 
-    // A ring of NR two-k-step groups in registers: buf[slot][k-step of the group][fragment row], group j in slot j % NR.  As soon as group j
-    // has been consumed, group j + NR (of this tile, or group j + NR - 8 of the NEXT tile) is requested into its slot: NR groups = NR x 2 x
-    // ROWS KB in flight per wave.  LSPLIT = 1: the whole tile (NR = 8); LSPLIT = 2: half a tile per wave, the same bytes per CU.
-    constexpr int NR = LSPLIT == 1 ? CORR_NG : CORR_NG / 2;
-    i32x4_t buf[NR][2][ROWS];
+    // The WHOLE tile lives in registers: buf[group][k-step of the group][fragment row].  Group j of the next tile is requested as soon as
+    // group j of the current tile has been consumed, so a wave always has one full tile (16 x ROWS KB) in flight.
+    i32x4_t buf[CORR_NG][2][ROWS];
     uint32_t fp[ROWS];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) fp[r] = 0;
     if (t < t_end) {
         frag_offs(t, fp);
 #pragma unroll
-        for (int grp = 0; grp < NR; ++grp)
+        for (int grp = 0; grp < CORR_NG; ++grp)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -136,17 +129,13 @@ __global__ __launch_bounds__(256 * LSPLIT, LSPLIT) void corr_planes_kernel(const
 
     for (; t < t_end; t += step) {
         f32x4_t acc[NLB][TR];
-        // gram accumulators (16 x 16 pixel blocks).  LSPLIT = 1: ga[r] = row r . row r, gb[r] = row r . row r + 1.  LSPLIT = 2: ga only -- the
-        // wave with half = 0 forms the row-with-itself products in it, the other wave the row-with-the-row-below products
-        f32x4_t ga[GRAM ? TR : 1], gb[GRAM && LSPLIT == 1 ? TR : 1];
+        f32x4_t ga[GRAM ? TR : 1], gb[GRAM ? TR : 1];            // ga[r] = row r . row r, gb[r] = row r . row r + 1 (16 x 16 pixel blocks)
 #pragma unroll
         for (int lb = 0; lb < NLB; ++lb)
 #pragma unroll
             for (int r = 0; r < TR; ++r) acc[lb][r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < (GRAM ? TR : 1); ++r) ga[r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < (GRAM && LSPLIT == 1 ? TR : 1); ++r) gb[r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < (GRAM ? TR : 1); ++r) { ga[r] = f32x4_t{0.f, 0.f, 0.f, 0.f}; gb[r] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
         const int tn = t + step;
         const bool more = tn < t_end;
         uint32_t np[ROWS];
@@ -171,36 +160,24 @@ __global__ __launch_bounds__(256 * LSPLIT, LSPLIT) void corr_planes_kernel(const
                     constexpr int lb = decltype(lc)::value, u = ks * NLB + lb;
                     if constexpr (u + TD - 1 < NSTEP) tf[(u + TD - 1) % TD] = tread(std::integral_constant<int, u + TD - 1>{});
 #pragma unroll
-                    for (int r = 0; r < TR; ++r) acc[lb][r] = mfma16<F16>(buf[grp % NR][kk][r], tf[u % TD], acc[lb][r]);
+                    for (int r = 0; r < TR; ++r) acc[lb][r] = mfma16<F16>(buf[grp][kk][r], tf[u % TD], acc[lb][r]);
                     __builtin_amdgcn_sched_barrier(0);
                 });
                 if constexpr (GRAM) {
-                    if constexpr (LSPLIT == 1) {
 #pragma unroll
-                        for (int r = 0; r < TR; ++r) {
-                            ga[r] = mfma16<F16>(buf[grp % NR][kk][r], buf[grp % NR][kk][r], ga[r]);
-                            gb[r] = mfma16<F16>(buf[grp % NR][kk][r], buf[grp % NR][kk][r + 1], gb[r]);
-                        }
-                    } else if (half == 0) {                      // (wave-uniform; no memory operation on either side of the branch)
-#pragma unroll
-                        for (int r = 0; r < TR; ++r) ga[r] = mfma16<F16>(buf[grp % NR][kk][r], buf[grp % NR][kk][r], ga[r]);
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < TR; ++r) ga[r] = mfma16<F16>(buf[grp % NR][kk][r], buf[grp % NR][kk][r + 1], ga[r]);
+                    for (int r = 0; r < TR; ++r) {
+                        ga[r] = mfma16<F16>(buf[grp][kk][r], buf[grp][kk][r], ga[r]);
+                        gb[r] = mfma16<F16>(buf[grp][kk][r], buf[grp][kk][r + 1], gb[r]);
                     }
                 }
             });
             __builtin_amdgcn_sched_barrier(0);
-            // this group's registers are free: group grp + NR is requested into them -- of this tile, or (past its end) of the NEXT tile (of this
-            // tile again after the wave's last one: an unconditional load keeps the waits counted: behind a branch hipcc assumes nothing was
-            // issued and drains to vmcnt(0))
+            // this group's registers are free: the same group of the NEXT tile is requested (of this tile again after the wave's last one --
+            // an unconditional load keeps the waits counted: behind a branch hipcc assumes nothing was issued and drains to vmcnt(0))
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-                for (int r = 0; r < ROWS; ++r) {
-                    if constexpr (grp + NR < CORR_NG) buf[grp % NR][kk][r] = gload(fp[r], (grp + NR) * 2 + kk);
-                    else buf[grp % NR][kk][r] = gload(np[r], (grp + NR - CORR_NG) * 2 + kk);
-                }
+                for (int r = 0; r < ROWS; ++r) buf[grp][kk][r] = gload(np[r], grp * 2 + kk);
             __builtin_amdgcn_sched_barrier(0);
         });
 
@@ -213,7 +190,7 @@ __global__ __launch_bounds__(256 * LSPLIT, LSPLIT) void corr_planes_kernel(const
         const int xs = x0 + 4 * kg;                                   // first of this lane's 4 pixels (D rows 4 kg .. 4 kg + 3)
 #pragma unroll
         for (int lb = 0; lb < NLB; ++lb) {
-            const int lab = (half * NLB + lb) * 16 + c;
+            const int lab = lb * 16 + c;
             if (lab >= K) continue;
             float* pl = R + ((size_t)b * K + lab) * plane;
 #pragma unroll
@@ -241,15 +218,13 @@ __global__ __launch_bounds__(256 * LSPLIT, LSPLIT) void corr_planes_kernel(const
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int m = 4 * kg + e;
-                    const bool do_self = LSPLIT == 1 || half == 0, do_below = LSPLIT == 1 || half != 0;
-                    const float vs = ga[r][e], vb = LSPLIT == 1 ? gb[r][e] : ga[r][e];   // (LSPLIT = 2: ga holds whichever set this wave formed)
                     if (m <= 14 && x0 + m <= W) {                     // records of the owned pixel (y, x0 + m)
                         float* rec = grow + (size_t)(x0 + m - 1) * 5;
-                        if (c == m) { if (do_self) rec[0] = vs; if (do_below) rec[2] = vb; }
-                        if (c == m + 1) { if (do_self) rec[1] = vs; if (do_below) rec[3] = vb; }
+                        if (c == m) { rec[0] = ga[r][e]; rec[2] = gb[r][e]; }
+                        if (c == m + 1) { rec[1] = ga[r][e]; rec[3] = gb[r][e]; }
                     }
-                    if (do_below && c == m - 1 && c <= 14 && x0 + c <= W)   // g(y, x+1) . g(y+1, x) belongs to the pixel in column n = c
-                        grow[(size_t)(x0 + c - 1) * 5 + 4] = vb;
+                    if (c == m - 1 && c <= 14 && x0 + c <= W)          // g(y, x+1) . g(y+1, x) belongs to the pixel in column n = c
+                        grow[(size_t)(x0 + c - 1) * 5 + 4] = gb[r][e];
                 }
             }
         }
@@ -258,7 +233,7 @@ __global__ __launch_bounds__(256 * LSPLIT, LSPLIT) void corr_planes_kernel(const
     }
 }
 
-template <int NLB, int LSPLIT, bool GRAM>
+template <int NLB, bool GRAM>
 int launch_corr(const void* g, const void* T, float* R, float* gram, int B, int K, int H, int W, hipStream_t st) {
     int dev = 0;
     LSEG_HIP_TRY(hipGetDevice(&dev));
@@ -271,14 +246,14 @@ int launch_corr(const void* g, const void* T, float* R, float* gram, int B, int 
     const long want = ((ntiles + 3) / 4 + 7) / 8 * 8;                // no more workgroups than tiles / 4 (each copies T into its LDS)
     if (want < grid) grid = (int)want;
     const size_t lds = (size_t)K * CORR_PITCH;
-    auto kern = corr_planes_kernel<NLB, LSPLIT, GRAM>;
+    auto kern = corr_planes_kernel<NLB, GRAM>;
     static std::atomic<unsigned long long> attr_done{0};             // per-device opt-in to > 64 KB of dynamic LDS (cf. gemm.hip)
     const unsigned long long bit = 1ull << (dev & 63);
     if (!(attr_done.load(std::memory_order_acquire) & bit)) {
         LSEG_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * LSPLIT), lds, st, (const uint16_t*)g, (const uint16_t*)T, R, gram, B, K, H, W, tiles_y, tiles_x);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, (const uint16_t*)g, (const uint16_t*)T, R, gram, B, K, H, W, tiles_y, tiles_x);
     LSEG_HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -291,12 +266,10 @@ bool corr_planes_supported(int K, int C) { return C == CORR_C && K >= 1 && (size
 int launch_corr_planes(const void* g, const void* T, float* R, float* gram, int B, int K, int H, int W, int C, hipStream_t st) {
     if (!corr_planes_supported(K, C)) return set_error(LSEG_ERR_UNSUPPORTED, "corr_planes: K=%d C=%d (C must be 512, K x 1040 B must fit the LDS)", K, C);
     if (B < 1 || H < 1 || W < 1) return set_error(LSEG_ERR_INVALID, "corr_planes: B=%d H=%d W=%d", B, H, W);
-#define CORR_GO(NLB, LS) (gram ? launch_corr<NLB, LS, true>(g, T, R, gram, B, K, H, W, st) : launch_corr<NLB, LS, false>(g, T, R, nullptr, B, K, H, W, st))
-    static const bool one_wave = getenv("LSEG_CORR_ONE_WAVE") != nullptr;       // A/B switch (tools): round-5 lease C's one-wave-per-tile form
-    if (K <= 32) return CORR_GO(2, 1);
-    if (K <= 80) return CORR_GO(5, 1);
-    if (one_wave) return CORR_GO(10, 1);
-    return CORR_GO(5, 2);                         // up to 160 label rows: two waves per tile, 5 label blocks each
+#define CORR_GO(NLB) (gram ? launch_corr<NLB, true>(g, T, R, gram, B, K, H, W, st) : launch_corr<NLB, false>(g, T, R, nullptr, B, K, H, W, st))
+    if (K <= 32) return CORR_GO(2);
+    if (K <= 80) return CORR_GO(5);
+    return CORR_GO(10);
 #undef CORR_GO
 }
 
