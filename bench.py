@@ -727,6 +727,18 @@ def main():
         sweep[str(B)] = round(world * B * args.steps / dt, 1)
         for e in engines.values():
             e.close()
+        if headline and B == 36:        # one point ABOVE the headline batch (its own engine: the plan is sized by max_batch), for information
+            try:
+                e2 = HipEngine(cfg, args.size, args.size, max_batch=2 * B, max_labels=K, image_dtype=chosen)
+                e2.load_state_dict(sd)
+                e2.set_tokens(tok)
+                x2 = torch.cat([x, synthetic_images(B, args.size, args.size, seed=1000 + rank).cuda()], dim=0)
+                t2 = D.max_over_ranks(time_forward(e2, x2, 5, 2, sync), device="cuda")
+                sweep[str(2 * B)] = round(world * 2 * B / t2, 1)
+                e2.close()
+                del x2
+            except Exception as e:                       # noqa: BLE001
+                sweep[str(2 * B)] = f"{type(e).__name__}: {e}"
         if headline:
             try:
                 k1000 = k1000_leg(cfg, sd, args.size, 4, sync, D, chosen)
