@@ -95,7 +95,8 @@ typedef struct {
                                * bit 3 (training): deterministic reductions -- the bias-gradient and BatchNorm column sums write partial
                                * rows summed in a fixed order instead of fp32 atomics: two runs of the same step on the same inputs
                                * give BIT-identical gradients (what torch.use_deterministic_algorithms buys the reference's
-                               * training loop, modules/lsegmentation_module.py:66-81); one small extra launch per sum */
+                               * training loop, modules/lsegmentation_module.py:66-81); one small extra launch per sum, no measurable cost per step (the
+                               * Python front sets it by default: lseg_hip/engine.py, LSEG_DETERMINISTIC=0 clears it) */
 } lseg_config;
 
 typedef struct lseg_engine* lseg_handle;
