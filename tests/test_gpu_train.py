@@ -7,7 +7,7 @@ lseg_set_train / lseg_forward (train mode) / lseg_backward / lseg_sgd_step, agai
   * oracle.lseg_oracle.training_step (fp32 autograd restatement of modules/lsegmentation_module.py:66-81, itself pinned by the
     reference-made fixtures in tests/test_oracle_train_ref_golden.py): loss and EVERY gradient tensor;
   * itself: the same step twice is BIT-identical under deterministic reductions (lseg_config.flags bit 3; the whole parity suite runs
-    with them, tests/conftest.py), and the default fp32-atomics sums stay within rounding of the deterministic ones.
+    with them -- the engine's default --, tests/conftest.py), and the fp32-atomics sums (LSEG_DETERMINISTIC=0) stay within rounding of them.
 
 The element-wise comparison on the seeded random network (the most chaotic one) lives in tests/test_zz_gpu_random_net_gradients.py,
 which pytest collects last.
@@ -208,7 +208,7 @@ def test_bucket_rule_and_gradient_accumulation():
 
 
 def test_atomic_sums_stay_within_rounding_of_the_deterministic_ones():
-    """The default (fast) column sums use fp32 atomics: same numbers up to the summation order.  A last-bit difference in a BatchNorm
+    """The column sums on fp32 atomics (deterministic=False; rounds 2-4's only form): same numbers up to the summation order.  A last-bit difference in a BatchNorm
     batch sum flips a bf16 rounding somewhere, which the layers above amplify on the seeded random net: measured median 0.5 %, worst
     1.7 % per tensor (lease A of round 5) -- the run-to-run noise of the atomics path itself (profiles/r05_train_spread.txt: +-0.8 points on the
     oracle comparison), an order of magnitude below either engine's distance to the fp32 oracle on those tensors."""
