@@ -204,3 +204,80 @@ def test_x4_upsample_bands_cover_every_output_row_once_and_rolling_rows_hold_the
             if ye > ys:
                 assert formed <= (ye - ys) // 2 + 2
     assert (written == 1).all()
+
+
+# ---- csrc/corr.hip: tile decomposition, ownership of the label-plane pixels and of the gram records, LDS pitch -------------------------
+def _corr_tiles(H, W, gram):
+    """The kernel's geometry (corr.hip: CORR_TR = 2 rows x 16 columns per wave tile; with the gram a halo row below and a 16th halo
+    column: 15 owned columns).  Yields (y0, x0) of every tile of one image."""
+    tr, xs = 2, (15 if gram else 16)
+    tiles_y, tiles_x = (H + tr - 1) // tr, ((W + 14) // 15 if gram else (W + 15) // 16)
+    for ty in range(tiles_y):
+        for tx in range(tiles_x):
+            yield 1 + tr * ty, 1 + xs * tx
+
+
+@pytest.mark.parametrize("H,W", [(120, 120), (24, 24), (30, 17), (5, 3), (9, 31), (4, 15), (1, 1), (7, 16)])
+@pytest.mark.parametrize("gram", [True, False])
+def test_corr_kernel_tiles_cover_every_plane_pixel_and_gram_record(H, W, gram):
+    """Restates corr_planes_kernel's store conditions on integers.  Label planes: every interior pixel (1..H, 1..W of the padded map) is
+    written, nothing else, and a pixel is written twice only as a tile's 16th (halo) column = the next tile's first.  Gram: every one of the
+    five records of every interior pixel is written exactly once, and every fragment the tile reads lies inside the padded map."""
+    HP, WP = H + 2, W + 2
+    planes = np.zeros((HP, WP), dtype=np.int32)
+    recs = np.zeros((H, W, 5), dtype=np.int32)
+    for y0, x0 in _corr_tiles(H, W, gram):
+        rows = 3 if gram else 2
+        for r in range(rows):                                   # loads: rows / columns clamped into the padded map (frag_offs)
+            y = min(y0 + r, HP - 1)
+            for c in range(16):
+                x = min(x0 + c, WP - 1)
+                assert 0 <= y < HP and 0 <= x < WP
+        for r in range(2):                                      # label planes: lane (c, kg) holds pixels xs .. xs + 3 of row y0 + r
+            y = y0 + r
+            if y > H:
+                continue
+            for kg in range(4):
+                xs = x0 + 4 * kg
+                for e in range(4):
+                    if xs + e <= W:                             # (vector store when xs + 3 <= W, masked scalars otherwise: same pixels)
+                        planes[y, xs + e] += 1
+        if gram:
+            for r in range(2):
+                y = y0 + r
+                if y > H:
+                    continue
+                for kg in range(4):
+                    for e in range(4):
+                        m = 4 * kg + e
+                        for c in range(16):                     # the lane's column n = c of the 16 x 16 product block
+                            if m <= 14 and x0 + m <= W:
+                                if c == m:
+                                    recs[y - 1, x0 + m - 1, 0] += 1; recs[y - 1, x0 + m - 1, 2] += 1
+                                if c == m + 1:
+                                    recs[y - 1, x0 + m - 1, 1] += 1; recs[y - 1, x0 + m - 1, 3] += 1
+                            if c == m - 1 and c <= 14 and x0 + c <= W:
+                                recs[y - 1, x0 + c - 1, 4] += 1
+    interior = np.zeros((HP, WP), dtype=bool)
+    interior[1:H + 1, 1:W + 1] = True
+    assert (planes[interior] >= 1).all() and (planes[~interior] == 0).all()
+    if gram:
+        assert planes.max() <= 2                                # the halo column only
+        twice = np.argwhere(planes == 2)
+        assert all((x - 1) % 15 == 0 and x > 1 for _, x in twice), twice[:5]      # = column 0 of the next tile
+        assert (recs == 1).all(), np.argwhere(recs != 1)[:5]
+    else:
+        assert planes.max() == 1
+
+
+def test_corr_kernel_text_tile_pitch_is_bank_conflict_free_and_fits_the_lds():
+    """T in LDS at a pitch of 1024 + 16 bytes: the 16 rows one ds_read_b128 fragment read touches per k-group land on 16 different 16-byte
+    bank groups of a 256-byte LDS line (and on 8 different ones of a 128-byte line per 8 lanes); 157 rows are the most that fit 160 KB."""
+    pitch = 512 * 2 + 16
+    for kg in range(4):
+        for ks in range(16):
+            offs = [r * pitch + ks * 64 + kg * 16 for r in range(16)]
+            assert len({(o % 256) // 16 for o in offs}) == 16
+            for half in (offs[:8], offs[8:]):
+                assert len({(o % 128) // 16 for o in half}) == 8
+    assert 157 * pitch <= 160 * 1024 < 158 * pitch
