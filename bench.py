@@ -34,6 +34,9 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
+# synthetic weights (data: "synthetic"): stand-in token ids are legitimate HERE and nowhere near a real checkpoint (lseg_hip/tokenizer.py)
+os.environ.setdefault("LSEG_SYNTHETIC_TOKENS", "1")
+
 GF_IMAGE = lambda K: 799.4 + 0.05898 * K        # image tower GF / image
 GF_TEXT = lambda K: 5.959 * K                   # CLIP text tower GF / forward call, the reference's 77-position schedule
 # executed by the engine: refinenet1.out_conv (7.55 GF) and head1 (15.10 GF) at 240x240 are replaced by ONE combined 1x1 conv on the

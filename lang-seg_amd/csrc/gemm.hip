@@ -1462,6 +1462,8 @@ int launch_gemm(const GemmArgs& g_in, int ab_dtype, hipStream_t stream) {
     static const int dbg = getenv("LSEG_GEMM_DBG") ? atoi(getenv("LSEG_GEMM_DBG")) : 0;
     g.dbg = dbg;
     g.group_m = 8;                            // row-blocks per rasterisation group (2 .. 32 measured within noise in round 2)
+    static const int grid_cap = getenv("LSEG_GEMM_MAXGRID") ? atoi(getenv("LSEG_GEMM_MAXGRID")) : 0;     // tools: every launch on part of the chip
+    if (grid_cap >= 8 && !g.max_grid) g.max_grid = grid_cap;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return set_error(LSEG_ERR_INVALID, "gemm: empty problem %dx%dx%d", g.M, g.N, g.K);
     if ((g.C_pre || g.dgelu_pre) && !gemm_fuses_gelu(g, ab_dtype))
         return set_error(LSEG_ERR_UNSUPPORTED, "gemm: C_pre / dgelu_pre need the specialised 16-bit MAP_LINEAR epilogue (N %% 128 == 0, a bias, 16-byte rows)");

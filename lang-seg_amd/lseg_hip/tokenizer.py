@@ -115,6 +115,19 @@ class BPETokenizer:
 
 
 _bpe = None
+_allow_synth = None          # None: read LSEG_SYNTHETIC_TOKENS
+
+
+def allow_synthetic_tokens(enabled: bool = True) -> None:
+    """Opt in to (or out of) hash-based stand-in token ids when no real CLIP tokenizer is available (synthetic-weight runs only)."""
+    global _allow_synth
+    _allow_synth = bool(enabled)
+
+
+def synthetic_tokens_allowed() -> bool:
+    if _allow_synth is not None:
+        return _allow_synth
+    return os.environ.get("LSEG_SYNTHETIC_TOKENS", "") not in ("", "0")
 
 
 def tokenize(texts: Union[str, Sequence[str]], context_length: int = 77, vocab: int = 49408) -> torch.Tensor:
@@ -141,7 +154,13 @@ def tokenize(texts: Union[str, Sequence[str]], context_length: int = 77, vocab: 
                     raise RuntimeError(f"Input {t} is too long for context length {context_length}")
                 out[i, :len(ids)] = torch.tensor(ids)
             return out
-        warnings.warn("neither the `clip` package nor the CLIP BPE vocabulary (LSEG_BPE_VOCAB) is available: "
-                      "using hash-based synthetic token ids -- fine for synthetic weights, WRONG for real "
-                      "checkpoints", RuntimeWarning)
+        # No real tokenizer here.  Hash-based ids are only meaningful with SYNTHETIC weights (tests, bench.py, smoke: random-init
+        # towers): with a real checkpoint they would score nonsense prompts and produce wrong masks without any error.  So this is a
+        # hard failure unless the caller opted in (allow_synthetic_tokens(True) / LSEG_SYNTHETIC_TOKENS=1), never a warning.
+        if not synthetic_tokens_allowed():
+            raise RuntimeError(
+                "clip.tokenize is unavailable: neither the `clip` package nor CLIP's BPE vocabulary (bpe_simple_vocab_16e6.txt.gz; set "
+                "LSEG_BPE_VOCAB or place it next to lseg_hip/tokenizer.py) was found.  Refusing to fall back to hash-based synthetic token "
+                "ids: with a real checkpoint they give wrong masks.  For synthetic-weight runs call "
+                "lseg_hip.tokenizer.allow_synthetic_tokens(True) or set LSEG_SYNTHETIC_TOKENS=1.")
     return synthetic_tokens(texts, vocab, context_length)

@@ -57,17 +57,30 @@ def test_synthetic_tokens_contract():
     assert t[1].argmax() == 3 and not torch.equal(t[0], t[1])
 
 
-def test_tokenize_falls_back_with_warning():
+def test_tokenize_refuses_hash_ids_unless_opted_in():
+    """without `clip` and without the BPE vocabulary tokenize() must RAISE -- a real checkpoint scored with hash ids
+    gives wrong masks silently -- unless the caller opted in to synthetic ids (synthetic-weight runs: tests, bench, smoke)."""
     from lseg_hip import tokenizer
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter("always")
-        t = tokenizer.tokenize(["cat", "grass"])
-    assert t.shape == (2, 77)
     try:
         import clip  # noqa: F401
+        pytest.skip("the clip package is installed: tokenize() never falls back")
     except ImportError:
-        if tokenizer._vocab_path() is None:
-            assert any("synthetic token ids" in str(x.message) for x in w)
+        pass
+    if tokenizer._vocab_path() is not None:
+        pytest.skip("the CLIP vocabulary is on this machine: tokenize() never falls back")
+    prev = tokenizer._allow_synth
+    try:
+        tokenizer.allow_synthetic_tokens(False)
+        with pytest.raises(RuntimeError, match="Refusing to fall back"):
+            tokenizer.tokenize(["cat", "grass"])
+        tokenizer.allow_synthetic_tokens(True)
+        t = tokenizer.tokenize(["cat", "grass"])
+        assert t.shape == (2, 77)
+        # small synthetic vocabularies (tiny16 twin) never had a real tokenizer: always the stand-in ids
+        tokenizer.allow_synthetic_tokens(False)
+        assert tokenizer.tokenize(["cat"], 16, 512).shape == (1, 16)
+    finally:
+        tokenizer._allow_synth = prev
 
 
 @pytest.mark.parametrize("backbone", ["clip_vitl16_384", "clip_vitb32_384", "tiny16"])

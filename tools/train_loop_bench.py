@@ -7,6 +7,7 @@ import argparse, os, sys, time, warnings
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "lang-seg_amd")); sys.path.insert(0, ROOT)
 import torch
+os.environ.setdefault("LSEG_SYNTHETIC_TOKENS", "1")     # synthetic weights: stand-in token ids (lseg_hip/tokenizer.py)
 warnings.simplefilter("ignore")
 from modules.lseg_module import LSegModule
 from lseg_hip.synth import synthetic_state_dict, synthetic_images
