@@ -198,6 +198,13 @@ int lseg_op_gemm(const void* d_A, const void* d_W, const float* d_bias, const fl
  * max_grid > 0 caps the persistent grid (tools/epilogue_table.py).  d_bias fp32 [N] is required. */
 int lseg_op_gemm_vit(const void* d_A, const void* d_W, const float* d_bias, void* d_Cq, void* d_Ck, void* d_Cv, int M, int N, int K,
                      int ab_dtype, int kind, int ntok, int npad, int max_grid, void* stream);
+/* The residual form alone -- d_C (fp32 [rows_alloc, N], rows_alloc >= M) += A W^T + bias, in place: attn.proj / mlp.fc2 of a timm Block
+ * (lseg_vit.py:196-197) -- with the caller stating how many rows of d_A and d_C are ALLOCATED.  When they reach the next multiple of 256
+ * the launch takes the hand-scheduled 256 x 128 kernel (csrc/gemm_asm.hip: whole tiles, no masks; rows >= M of d_C are overwritten with
+ * values nobody should read); impl = 0 forces the generic kernel family, 1 requires the hand-scheduled one (LSEG_ERR_UNSUPPORTED when the
+ * shape does not qualify), -1 lets the launcher choose like the engine does.  max_grid > 0 caps the persistent grid. */
+int lseg_op_gemm_res32(const void* d_A, const void* d_W, const float* d_bias, float* d_C, int M, int N, int K, int rows_alloc,
+                       int ab_dtype, int impl, int max_grid, void* stream);
 /* LayerNorm over the last dim: in fp32|fp16 [M,D] -> out bf16|fp16 [M,D] */
 int lseg_op_layernorm(const void* d_in, int in_dtype, const float* d_gamma, const float* d_beta,
                       void* d_out, int out_dtype, int M, int D, float eps, void* stream);

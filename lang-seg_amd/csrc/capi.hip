@@ -207,6 +207,25 @@ int lseg_op_gemm_vit(const void* A, const void* W, const float* bias, void* Cq, 
     return launch_gemm(g, ab, (hipStream_t)stream);
 }
 
+int lseg_op_gemm_res32(const void* A, const void* W, const float* bias, float* C, int M, int N, int K, int rows_alloc, int ab_dtype, int impl,
+                       int max_grid, void* stream) {
+    int r = require_device(); if (r) return r;
+    int ab;
+    if ((r = op_dt(ab_dtype, &ab))) return r;
+    if (!bias || M < 1 || rows_alloc < M) return set_error(LSEG_ERR_INVALID, "lseg_op_gemm_res32: needs a bias and rows_alloc >= M");
+    GemmArgs g;
+    gemm_args_init(g);
+    g.A = (const uint16_t*)A; g.W = (const uint16_t*)W; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K;
+    g.bias = bias; g.C = C; g.ldc = N; g.map_mode = MAP_LINEAR; g.max_grid = max_grid;
+    g.res_mode = RES_DEST; g.res = C; g.res_dtype = DT_F32; g.out_dtype = DT_F32;
+    g.rows_alloc = impl == 0 ? 0 : rows_alloc;
+    if (impl == 1) {
+        if (!gemm_res32_asm_eligible(g, ab)) return set_error(LSEG_ERR_UNSUPPORTED, "lseg_op_gemm_res32: shape / padding does not qualify for the hand-scheduled kernel");
+        return launch_gemm_res32_asm(g, ab, (hipStream_t)stream);
+    }
+    return launch_gemm(g, ab, (hipStream_t)stream);
+}
+
 int lseg_op_layernorm(const void* in, int in_dtype, const float* gamma, const float* beta, void* out, int out_dtype,
                       int M, int D, float eps, void* stream) {
     int r = require_device(); if (r) return r;

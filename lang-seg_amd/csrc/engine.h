@@ -130,6 +130,7 @@ private:
 
     // derived geometry
     int gh_, gw_, np_, ntok_, npad_, img_dt_;
+    int rows_alloc_ = 0;                        // allocated rows of x_ / ln_ / att_ / mlp_: max_batch * ntok rounded up to 256 (gemm_asm.hip)
     bool strict_ = false;                       // split-precision mode (lseg_config.image_dtype == LSEG_F16_SPLIT)
     std::map<const void*, size_t> plane_;       // 16-bit buffer -> element offset of its lo plane
     size_t pl(const void* p) const { auto it = plane_.find(p); return it == plane_.end() ? 0 : it->second; }

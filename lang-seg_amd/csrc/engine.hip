@@ -108,7 +108,11 @@ int Engine::init() {
 
     const size_t B = c.max_batch, D = c.dim, F = c.features;
     const size_t M = B * ntok_;
-    ALLOC(x_, float, M * D);
+    // the token-major buffers of the ViT blocks reach the next multiple of 256 rows: the hand-scheduled residual GEMM (gemm_asm.hip) works on
+    // whole 256-row tiles without masks -- the padding rows are zero-initialised, computed along and never read
+    const size_t Mp = (M + 255) / 256 * 256;
+    rows_alloc_ = (int)Mp;
+    ALLOC(x_, float, Mp * D);
     // split-K partial slabs of the residual GEMMs / deep convs at small batches (forward(): "split-K"): ns K-ranges of M rows each.  16 384
     // rows (64 MB at D = 1024) hold 4 ranges at B = 4 -- what Engine::split_residual's cost model asks for there (256 x 256 tiles for
     // mlp.fc2); round 4's 8 192 rows capped B = 4 at 2 ranges.  Measured, lease F of round 5 (tools/step_probe.py, fp16, two interleaved
@@ -116,12 +120,12 @@ int Engine::init() {
     static const long split_rows_env = getenv("LSEG_SPLIT_ROWS") ? atol(getenv("LSEG_SPLIT_ROWS")) : 0;
     ws_split_rows_ = split_rows_env > 0 ? (size_t)split_rows_env : 16384;
     ALLOC(ws_split_, float, ws_split_rows_ * D);
-    ALLOC16(ln_, M * D);
+    ALLOC16(ln_, Mp * D);
     ALLOC16(q_, B * c.heads * npad_ * 64);
     ALLOC16(k_, B * c.heads * npad_ * 64);
     ALLOC16(vt_, B * c.heads * 64 * npad_);
-    ALLOC16(att_, M * D);
-    ALLOC16(mlp_, M * 4 * D);
+    ALLOC16(att_, Mp * D);
+    ALLOC16(mlp_, Mp * 4 * D);
     ALLOC16(patchA_, B * np_ * 3 * c.patch * c.patch);
     ALLOC16(catA_, B * np_ * 2 * D);
     ALLOC16(ro_, B * np_ * D);
@@ -793,7 +797,7 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
         gemm_args_init(g);
         g.A = att_; g.W = b.proj.w; g.M = M; g.N = D; g.K = D; g.lda = D; g.ldw = D;
         g.bias = b.proj.b; g.res_mode = RES_DEST; g.res = x_; g.res_dtype = DT_F32;
-        g.C = x_; g.out_dtype = DT_F32; g.ldc = D; g.map_mode = MAP_LINEAR;
+        g.C = x_; g.out_dtype = DT_F32; g.ldc = D; g.map_mode = MAP_LINEAR; g.rows_alloc = rows_alloc_;
         pend_ns = split_residual(g, M, D, D);                 // small batches: partial slabs, summed into x_ by the LayerNorm that follows
         pend_bias = b.proj.b;
         pe = prof_begin(PF_PROJ, st);
@@ -814,7 +818,7 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
         gemm_args_init(g);
         g.A = mlp_; g.W = b.fc2.w; g.M = M; g.N = D; g.K = 4 * D; g.lda = 4 * D; g.ldw = 4 * D;
         g.bias = b.fc2.b; g.res_mode = RES_DEST; g.res = x_; g.res_dtype = DT_F32;
-        g.C = x_; g.out_dtype = DT_F32; g.ldc = D; g.map_mode = MAP_LINEAR;
+        g.C = x_; g.out_dtype = DT_F32; g.ldc = D; g.map_mode = MAP_LINEAR; g.rows_alloc = rows_alloc_;
         pend_ns = split_residual(g, M, D, 4 * D);
         pend_bias = b.fc2.b;
         pe = prof_begin(PF_FC2, st);

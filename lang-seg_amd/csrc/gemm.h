@@ -83,6 +83,9 @@ struct GemmArgs {
     // ReLU(x)).  Needs kconv_cin % 128 == 0 (a 128-wide column tile lies inside one tap).
     int kconv_cin, kconv_wp;
     int max_grid;               // tools: cap of the persistent grid (workgroups, multiple of 8; 0 = the whole chip)
+    int rows_alloc;             // rows of A and of C / res that are ALLOCATED (>= M; 0 = exactly M).  A caller whose buffers reach the next
+                                // multiple of 256 rows lets the residual GEMMs run on the hand-scheduled kernel (gemm_asm.hip), which computes
+                                // whole 256-row tiles and never masks: rows >= M are garbage in, garbage out, nobody reads them
     int tile_hint;              // 0: the launcher's cost model picks the tile; 2 = 128x128, 6 = 256x256 (callers that plan tile and split-K together)
 };
 
@@ -96,5 +99,9 @@ bool gemm_epilogue_is_pad16(const GemmArgs& g, int ab_dtype);
 bool gemm_qkv_scales_q(const GemmArgs& g, int ab_dtype);
 // true when launch_gemm would honour g.C_pre / g.dgelu_pre (it refuses them otherwise)
 bool gemm_fuses_gelu(const GemmArgs& g, int ab_dtype);
+// gemm_asm.hip: C (fp32, in place) += A W^T + bias on the hand-scheduled 256 x 128 kernel; launch_gemm takes it when eligible AND enabled (LSEG_GEMM_ASM=1)
+bool gemm_res32_asm_eligible(const GemmArgs& g, int ab_dtype);
+bool gemm_res32_asm_enabled();          // LSEG_GEMM_ASM=1
+int launch_gemm_res32_asm(const GemmArgs& g, int ab_dtype, hipStream_t stream);
 
 }  // namespace lseg

@@ -1483,6 +1483,8 @@ int launch_gemm(const GemmArgs& g_in, int ab_dtype, hipStream_t stream) {
         if (a_bytes >= 4.0e9 || (double)g.N * g.ldw * 2 >= 4.0e9)
             return set_error(LSEG_ERR_UNSUPPORTED, "gemm: operand larger than 4 GB (32-bit lane offsets)");
     }
+    // the residual Linears of the ViT block: the hand-scheduled kernel (gemm_asm.hip) when asked for (LSEG_GEMM_ASM=1) and the buffers are tile-padded
+    if (gemm_res32_asm_enabled() && gemm_res32_asm_eligible(g, ab_dtype)) return launch_gemm_res32_asm(g, ab_dtype, stream);
     if (ab_dtype == DT_BF16) return dispatch<BF16>(g, stream);
     if (ab_dtype == DT_F16) return dispatch<F16>(g, stream);
     return set_error(LSEG_ERR_INVALID, "gemm: operand dtype %d", ab_dtype);

@@ -113,6 +113,46 @@ def test_vit_block_gemm_forms(lib, dtype, B, ntok, max_grid):
     assert (q[:, ntok:] == 7).all() and (k[:, ntok:] == 7).all() and (vt[:, :, ntok:] == 7).all()
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 1024), (700, 256, 1024), (1500, 384, 1280), (2 * 901, 1024, 4096), (9 * 901, 1024, 1024)])
+def test_hand_scheduled_residual_gemm(lib, dtype, M, N, K):
+    """C (fp32, in place) += A W^T + bias -- attn.proj / mlp.fc2 of a timm Block (lseg_vit.py:196-197) -- on the hand-scheduled 256 x 128
+    kernel (csrc/gemm_asm.hip, impl = 1) against fp64 torch on the rounded operands and against the generic kernel family (impl = 0):
+    ragged M (the buffers reach the next multiple of 256 rows, the contract of rows_alloc), one to several tiles per workgroup, K = 1024
+    (the unrolled head of a tile only) and longer (the plain-step loop)."""
+    rows = (M + 255) // 256 * 256
+    A = rnd((rows, K), dtype, 31)
+    W = rnd((N, K), dtype, 32, 1 / math.sqrt(K))
+    bias = rnd((N,), torch.float32, 33)
+    C0 = rnd((rows, N), torch.float32, 34, 3.0)
+    ref = C0[:M].double() + A[:M].double() @ W.double().t() + bias.double()
+    out = {}
+    for impl in (1, 0):
+        Cb = C0.clone()
+        _lib.check(lib.lseg_op_gemm_res32(P(A), P(W), P(bias), P(Cb), M, N, K, rows, DT[dtype], impl, 0, stream()))
+        torch.cuda.synchronize()
+        out[impl] = Cb
+    big = max(1.0, ref.abs().max().item())
+    e_asm = (out[1][:M].double() - ref).abs().max().item()
+    e_gen = (out[0][:M].double() - ref).abs().max().item()
+    # fp32 accumulation of exact 16-bit products: both kernels sit at fp32 round-off of the result (the hand-scheduled one accumulates ON the
+    # residual, the generic one adds it last: a few ulp of |C| apart)
+    assert e_gen < 1e-5 * big and e_asm < 2e-5 * big * max(1.0, (K / 1024) ** 0.5), (e_asm, e_gen, big)
+    assert torch.isfinite(out[1]).all()
+
+
+def test_hand_scheduled_residual_gemm_refuses_unpadded_buffers(lib):
+    """rows_alloc below the next multiple of 256: the kernel would touch rows that do not exist -- impl = 1 must refuse, impl = -1 falls back"""
+    M, N, K = 300, 128, 1024
+    A, W, bias = rnd((M, K), torch.float16, 1), rnd((N, K), torch.float16, 2, 0.03), rnd((N,), torch.float32, 3)
+    Cb = rnd((M, N), torch.float32, 4)
+    ref = Cb + A.float() @ W.float().t() + bias
+    assert lib.lseg_op_gemm_res32(P(A), P(W), P(bias), P(Cb), M, N, K, M, DT[torch.float16], 1, 0, stream()) == -5      # LSEG_ERR_UNSUPPORTED
+    _lib.check(lib.lseg_op_gemm_res32(P(A), P(W), P(bias), P(Cb), M, N, K, M, DT[torch.float16], -1, 0, stream()))
+    torch.cuda.synchronize()
+    assert (Cb - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
+
+
 def test_gemm_transpose_detecting(lib):
     """A = I (padded), asymmetric W: catches a swapped C layout (cdna guide G9)."""
     M = N = K = 64
