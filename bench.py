@@ -440,8 +440,49 @@ def train_leg(cfg, sd, tok, size, B, rank, sync, D, sync_bn=True):
            "what": f"train-mode forward + fused x2-upsample/CE + backward + {exch} + fused SGD; bf16 MFMA operands, fp32 masters/gradients; "
                    "synthetic images and masks",
            "tflops_3x_forward_convention": round(tr.world * 3 * B * GF_IMAGE(tok.shape[0]) / dt / 1e3, 1)}
+    if tr.world > 1:
+        out["exchange"] = exchange_report(tr, x, t, base_lr, sync, D, dt)
     eng.close()
     return out
+
+
+def exchange_report(tr, x, t, base_lr, sync, D, dt_with):
+    """What the first multi-GPU run must show about the gradient exchange, outside the timed steps: the world size as
+    the process group reports it, every bucket's all-reduce time on the exchange stream and its bus bandwidth (ring convention:
+    2 (N - 1) / N x bytes / time), and the step time with the exchange switched off -- the difference is the EXPOSED communication."""
+    import torch.distributed as dist
+    ex = tr.exchange
+    rep = {"backend": dist.get_backend(ex.group), "world_size_reported_by_group": dist.get_world_size(ex.group),
+           "reduce_op": "avg (ncclAvg, no extra launch)" if ex._avg_op else "sum + one multi-tensor divide", "buckets": len(ex)}
+    ex.timing = True
+    tr.step(x, t, base_lr, 10 * base_lr)
+    sync()
+    times = ex.bucket_times_ms()
+    ex.timing = False
+    n = ex.world
+    rows = []
+    for i in sorted(times):
+        mb = ex.buckets[i].numel() * 4 / 1e6
+        ms = times[i]
+        rows.append({"bucket": i, "MB": round(mb, 1), "ms": round(ms, 3), "bus_GBps": round(2 * (n - 1) / n * mb / max(ms, 1e-6), 1)})
+    rep["per_bucket"] = rows
+    rep["allreduce_ms_total"] = round(sum(r["ms"] for r in rows), 3)
+    # the same step without the collectives (callbacks detached; gradients stay local): exposed communication = with - without
+    world, ex.world = ex.world, 1
+    try:
+        tr.step(x, t, base_lr, 10 * base_lr)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            tr.step(x, t, base_lr, 10 * base_lr)
+        sync()
+        dt_without = D.max_over_ranks((time.perf_counter() - t0) / 3, device="cuda")
+    finally:
+        ex.world = world
+    rep["ms_per_step_exchange_off"] = round(dt_without * 1e3, 2)
+    rep["exposed_exchange_ms"] = round((dt_with - dt_without) * 1e3, 2)
+    rep["overlap_fraction"] = round(1.0 - max(0.0, dt_with - dt_without) * 1e3 / max(rep["allreduce_ms_total"], 1e-6), 3)
+    return rep
 
 
 def k1000_leg(cfg, sd, size, B, sync, D, dtype):

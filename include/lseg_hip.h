@@ -205,6 +205,19 @@ int lseg_op_gemm_vit(const void* d_A, const void* d_W, const float* d_bias, void
  * shape does not qualify), -1 lets the launcher choose like the engine does.  max_grid > 0 caps the persistent grid. */
 int lseg_op_gemm_res32(const void* d_A, const void* d_W, const float* d_bias, float* d_C, int M, int N, int K, int rows_alloc,
                        int ab_dtype, int impl, int max_grid, void* stream);
+/* Column reductions of the training step, standalone (the bias gradients of every Linear / conv and the BatchNorm batch statistics of
+ * the DPT residual units: autograd of nn.Linear / nn.Conv2d / nn.BatchNorm2d under modules/lsegmentation_module.py:66-81).
+ *   lseg_op_colsum:       d_out[c] (+)= sum_r in[r, c], in 16-bit [R, ld] row-major, C <= ld columns, fp32 out
+ *   lseg_op_bn_stats:     d_stats[c] = sum x, d_stats[C + c] = sum x^2 over a padded NHWC map [B, H+2, W+2, C] (zero border)
+ *   lseg_op_bn_bwd_stats: d_bstats[c] = sum dy, d_bstats[C + c] = sum dy (x - mean_c) rstd_c, mean / rstd from d_stats over `count` = B H W
+ * d_det_ws (optional, det_cap_floats floats): the DETERMINISTIC form (lseg_config.flags bit 3) -- one partial row per row block, summed in
+ * a fixed order -- instead of fp32 atomics.  Same values up to summation order; two runs of the deterministic form are bit-identical. */
+int lseg_op_colsum(const void* d_in, int dtype, float* d_out, int R, int C, int ld, int accumulate, float* d_det_ws, size_t det_cap_floats,
+                   void* stream);
+int lseg_op_bn_stats(const void* d_x_padded, float* d_stats, int B, int H, int W, int C, int dtype, float* d_det_ws, size_t det_cap_floats,
+                     void* stream);
+int lseg_op_bn_bwd_stats(const void* d_dy_padded, const void* d_x_padded, const float* d_stats, float* d_bstats, int B, int H, int W, int C,
+                         float eps, int dtype, float* d_det_ws, size_t det_cap_floats, void* stream);
 /* LayerNorm over the last dim: in fp32|fp16 [M,D] -> out bf16|fp16 [M,D] */
 int lseg_op_layernorm(const void* d_in, int in_dtype, const float* d_gamma, const float* d_beta,
                       void* d_out, int out_dtype, int M, int D, float eps, void* stream);

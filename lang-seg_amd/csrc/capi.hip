@@ -226,6 +226,31 @@ int lseg_op_gemm_res32(const void* A, const void* W, const float* bias, float* C
     return launch_gemm(g, ab, (hipStream_t)stream);
 }
 
+int lseg_op_colsum(const void* in, int dtype, float* out, int R, int C, int ld, int accumulate, float* det_ws, size_t det_cap, void* stream) {
+    int r = require_device(); if (r) return r;
+    int dt;
+    if ((r = op_dt(dtype, &dt))) return r;
+    if (!in || !out || R < 1 || C < 1 || ld < C) return set_error(LSEG_ERR_INVALID, "lseg_op_colsum: R, C >= 1, ld >= C");
+    return launch_colsum16(in, dt, out, R, C, ld, (hipStream_t)stream, accumulate, det_ws, det_ws ? det_cap : 0);
+}
+
+int lseg_op_bn_stats(const void* x, float* stats, int B, int H, int W, int C, int dtype, float* det_ws, size_t det_cap, void* stream) {
+    int r = require_device(); if (r) return r;
+    int dt;
+    if ((r = op_dt(dtype, &dt))) return r;
+    if (!x || !stats || (C % 8)) return set_error(LSEG_ERR_INVALID, "lseg_op_bn_stats: C must be a multiple of 8");
+    return launch_bn_stats(x, stats, B, H, W, C, dt, (hipStream_t)stream, 0, det_ws, det_ws ? det_cap : 0);
+}
+
+int lseg_op_bn_bwd_stats(const void* dy, const void* x, const float* stats, float* bstats, int B, int H, int W, int C, float eps, int dtype,
+                         float* det_ws, size_t det_cap, void* stream) {
+    int r = require_device(); if (r) return r;
+    int dt;
+    if ((r = op_dt(dtype, &dt))) return r;
+    if (!dy || !x || !stats || !bstats || (C % 8)) return set_error(LSEG_ERR_INVALID, "lseg_op_bn_bwd_stats: C must be a multiple of 8");
+    return launch_bn_bwd_stats(dy, x, stats, bstats, B, H, W, C, eps, (double)B * H * W, dt, (hipStream_t)stream, det_ws, det_ws ? det_cap : 0);
+}
+
 int lseg_op_layernorm(const void* in, int in_dtype, const float* gamma, const float* beta, void* out, int out_dtype,
                       int M, int D, float eps, void* stream) {
     int r = require_device(); if (r) return r;

@@ -8,27 +8,25 @@
 // every tile, K-loop / epilogue serialised in one workgroup per CU: 0.32 of the HBM rate) and pixel_gram_kernel (every g row read twice:
 // 1.52x traffic, 0.36).
 //
-// Structure (one workgroup = 4 waves = one CU, persistent):
+// Structure of the shipped kernel (v2; one workgroup = 4 waves = one per SIMD = one CU, persistent):
 //   * T (the normalised text features, fp16 [K, 512]) is copied to LDS ONCE per workgroup and stays there for its life: K x 1040 bytes
-//     (pitch 1024 + 16: the 16 rows of a fragment read fall on 16 different 16-byte bank groups -> conflict-free ds_read_b128),
-//     156 000 B of the CU's 160 KB at K = 150.  LDS holds nothing else.
-//   * g is STREAMED ONCE from HBM straight into MFMA operand registers: a wave's tile = 4 image rows x 16 columns of the padded map
-//     (+ the row below and a 16th column as halo when the gram is wanted: 15 owned columns), a fragment = 16 pixels x 32 channels, lane
-//     (pixel c, k-group kg) loads the 16 bytes g[pixel, 32 ks + 8 kg ..] -- two k-steps of a pixel = one 128-byte line, issued back to back.
-//     Loads run two k-steps ahead of the MFMAs in a register double buffer (the next tile's first group is requested during the last
-//     group of the current one); with one wave per SIMD the wave owns 512 registers: 160 (+32) accumulators, 80 of prefetch.
+//     (pitch 1024 + 16), 156 000 B of the CU's 160 KB at K = 150.  LDS holds nothing else.  Fragments of T run three k-steps ahead of their
+//     MFMAs in a TD = 4 deep register ring (counted lgkmcnt waits).
+//   * g is STREAMED ONCE from HBM straight into MFMA operand registers: a wave's tile = CORR_TR = 2 image rows x 16 columns of the padded map
+//     (+ the row below and a 16th column as halo when the gram is wanted: 15 owned columns); a fragment = 16 pixels x 32 channels, lane
+//     (pixel c, k-group kg) loads the 16 bytes g[pixel, 32 ks + 8 kg ..].  ONE wave per tile holds all NLB (<= 10) label blocks:
+//     acc[NLB][2] accumulators, and a WHOLE tile of prefetch -- buf[8][2 (+1 halo)][..]: the 8 two-k-step groups of the NEXT tile are
+//     requested group by group as the current tile's groups are consumed (counted vmcnt), ~416 of the wave's 512 registers.
 //   * v_mfma_f32_16x16x32_f16 with the PIXELS as rows: a lane's 4 accumulator registers are 4 consecutive pixels of one label plane ->
 //     16-byte plane stores, and the SAME instruction / operand roles / k order as the generic GEMM it replaces (csrc/gemm.hip,
 //     MAP_LABELPLANES) -> the same bits.
-//   * gram: the g fragments are A and B operand alike (same register layout), so the cell dot products are 8 more MFMAs per k-step on
+//   * gram: the g fragments are A and B operand alike (same register layout), so the cell dot products are 4 more MFMAs per k-step on
 //     operands that are already there: row r with itself (diagonal: g_q.g_q, first super-diagonal: g_q.g_(x+1)) and with row r+1 (diagonal:
 //     g_q.g_(y+1,x), super: g_q.g_(y+1,x+1), sub: g_(x+1).g_(y+1,x)) -- the five records of elementwise.hip's norm_scale_plane_kernel.
-//   * MEMORY-LEVEL PARALLELISM decides the rate (lease B of round 5: with one wave per SIMD holding all 10 label blocks the kernel ran at
-//     2.0 TB/s of reads -- 1024 waves x 10 KB in flight against ~5 us of loaded latency): for K > 80 a tile is shared by TWO waves (8 per
-//     workgroup, 2 per SIMD), each taking half of the label blocks (and half of the gram products: one the row-with-itself, the other
-//     the row-with-the-row-below MFMAs) on its own register copy of the tile's g fragments (the second copy comes from L1 / L2).
-//   * tiles are dealt so that neighbours in the image run at the same time on the same XCD (its L2 serves the halo re-reads): XCD x takes
-//     the x-th eighth of the tile list, its 128 waves walk it with stride 128, the 4 waves of a workgroup hold 4 horizontally adjacent tiles.
+//   * tiles are dealt so that neighbours in the image run at the same time on the same XCD (its L2 serves the halo re-reads).
+// Measured and reverted (profiles/r05_corr_kernel.txt): v1 -- 4-row tiles, one two-k-step group of prefetch, all registers in accumulators:
+// 357 us at B = 36 (latency-bound: 1024 waves x 10 KB in flight); TWO waves per tile for K > 80 (2 per SIMD, half the label blocks each on their
+// own copy of the fragments): 40 % slower -- the pair loads the same bytes and the UNIQUE bytes in flight per CU halve.
 #include "ops.h"
 #include "gemm.h"
 #include "../../include/lseg_hip.h"

@@ -902,7 +902,9 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
         // per-image label sets (zero-shot), other widths and label sets that do not fit the LDS take the generic GEMM + pixel_gram pair
         static const bool corr_generic = getenv("LSEG_CORR_GENERIC") != nullptr;    // A/B switch (tools, tests): the round-4 pair
         const bool corr_fused = !corr_generic && group_k == 0 && corr_planes_supported(K_, c.out_c);
-        hipEvent_t pc = prof_begin(PF_CORR, st);       // "correlation": label planes + cell dot products (the dedicated kernel; algorithmic BYTES in flops)
+        // "correlation" family = the dedicated kernel only (label planes + cell dot products; algorithmic BYTES in the flops slot): the generic
+        // pair is not bracketed, so no event is taken that would never be paired (the pool is sized per family and forward)
+        hipEvent_t pc = corr_fused ? prof_begin(PF_CORR, st) : nullptr;
         if (corr_fused) TRY(launch_corr_planes(g16pad_, tnorm_, rpl_, gram_, B, K_, lh_[0], lw_[0], c.out_c, st));
         else TRY(launch_pixel_gram(g16pad_, gram_, B, lh_[0], lw_[0], c.out_c, st));
         if (corr_fused) prof_end(PF_CORR, pc, (double)B * hp * wp * c.out_c * 2.0 + (double)B * K_ * lh_[0] * lw_[0] * 4.0 + (double)B * lh_[0] * lw_[0] * 20.0 +

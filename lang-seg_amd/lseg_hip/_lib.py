@@ -81,6 +81,9 @@ SIGNATURES = {
     "lseg_op_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "lseg_op_gemm_vit": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "lseg_op_gemm_res32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "lseg_op_colsum": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, C.c_size_t, _vp]),
+    "lseg_op_bn_stats": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, C.c_size_t, _vp]),
+    "lseg_op_bn_bwd_stats": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, C.c_size_t, _vp]),
     "lseg_op_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "lseg_op_attention": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp]),
     "lseg_op_attention_prescaled": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

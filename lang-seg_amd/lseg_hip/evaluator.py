@@ -144,17 +144,35 @@ class BatchedMultiEval(torch.nn.Module):
             _lib.check(lib.lseg_op_eval_make_crops(P(cur), P(crops), ch, height, width, crop, stride, h_grids, w_grids, int(self.flip), pad, st))
             geo.append((height, width, ph, pw, h_grids, w_grids, stride, crops.shape[0]))
             stacks.append(crops)
-        allc = torch.cat(stacks, dim=0) if len(stacks) > 1 else stacks[0]
-        outs_all = self._module_eval(allc, label_set).contiguous()
-        assert outs_all.shape == (allc.shape[0], nclass, crop, crop) and outs_all.dtype == torch.float32
-        o0 = 0
-        for (height, width, ph, pw, h_grids, w_grids, stride, nc) in geo:
-            outs = outs_all[o0:o0 + nc]                                       # a contiguous slice: this scale's crops (+ twins)
-            o0 += nc
-            smap = image.new_empty((nclass, height, width))
-            _lib.check(lib.lseg_op_eval_accumulate(P(outs), P(smap), nclass, height, width, ph, pw, crop, stride, h_grids, w_grids,
-                                                   int(self.flip), st))
-            _lib.check(lib.lseg_op_eval_resize(P(smap), P(scores), nclass, height, width, h, w, 1, st))
+        # ... grouped so that at most `max_stack` crops (and their [n, K, crop, crop] fp32 logits: 138 MB per crop at K = 150, crop 480) are
+        # alive at once: consecutive scales share a forward while they fit -- a 4:3 ADE image (36 crops) is still ONE batch -- and a larger
+        # image / longer scale list runs as several stacks instead of one unbounded allocation
+        max_stack = int(getattr(self, "max_stack", 48))
+        groups, cur_g, cur_n = [], [], 0
+        for i, g_ in enumerate(geo):
+            if cur_g and cur_n + g_[7] > max_stack:
+                groups.append(cur_g)
+                cur_g, cur_n = [], 0
+            cur_g.append(i)
+            cur_n += g_[7]
+        if cur_g:
+            groups.append(cur_g)
+        for grp in groups:
+            allc = torch.cat([stacks[i] for i in grp], dim=0) if len(grp) > 1 else stacks[grp[0]]
+            outs_all = self._module_eval(allc, label_set).contiguous()
+            assert outs_all.shape == (allc.shape[0], nclass, crop, crop) and outs_all.dtype == torch.float32
+            o0 = 0
+            for i in grp:
+                height, width, ph, pw, h_grids, w_grids, stride, nc = geo[i]
+                outs = outs_all[o0:o0 + nc]                                   # a contiguous slice: this scale's crops (+ twins)
+                o0 += nc
+                smap = image.new_empty((nclass, height, width))
+                _lib.check(lib.lseg_op_eval_accumulate(P(outs), P(smap), nclass, height, width, ph, pw, crop, stride, h_grids, w_grids,
+                                                       int(self.flip), st))
+                _lib.check(lib.lseg_op_eval_resize(P(smap), P(scores), nclass, height, width, h, w, 1, st))
+            del outs_all, allc
+            for i in grp:
+                stacks[i] = None
         return scores
 
     @torch.no_grad()

@@ -8,9 +8,10 @@ utils.py:20-22,34) around `LSegmentationModule.training_step` (modules/lsegmenta
     back, the bucket's RCCL all-reduce is launched IN PLACE on a side stream (ordered behind the compute stream by an event) and
     runs under the remaining backward GEMMs.  Buckets = DPT head | ViT block 23 | ... | ViT block 0 + embeddings (12.6 M
     parameters = 50 MB fp32 per block: bandwidth-bound on the 7 x ~153 GB/s xGMI links).  No flatten / scatter copies.
-  * SyncBatchNorm  ->  `bn_sync`: the 2C per-layer sums are all-reduced between the statistics and the normalisation kernels
-    (forward) and between the gradient sums and the dx kernel (backward): 56 x 2 KB latency-bound collectives per step, exactly
-    the reference's semantics.  `sync_bn=False` keeps per-GPU statistics (a declared deviation: no collective besides the
+  * SyncBatchNorm  ->  `bn_sync`: the 2C per-layer sums are all-reduced IN PLACE on the engine's buffers between the statistics and the
+    normalisation kernels (forward) and between the gradient sums and the dx kernel (backward): 56 x 2 KB latency-bound collectives per
+    step -- each BatchNorm's statistics feed the next conv of the same unit, so they cannot be batched without changing the reference's
+    semantics (torch SyncBatchNorm issues one collective per layer and direction as well).  `sync_bn=False` keeps per-GPU statistics (a declared deviation: no collective besides the
     gradient all-reduce, as BASELINE.json's north_star words it).
   * SGD(momentum 0.9, weight decay 1e-4) with the two learning-rate groups of configure_optimizers (:119-127,165-171)
     ->  the engine's fused `lseg_sgd_step` on the fp32 masters (torch.optim works too: the gradients are ordinary tensors).
@@ -55,6 +56,14 @@ class BucketExchange:
         self._dev = next((b.device for b in buckets if b.is_cuda), None)
         self._stream = torch.cuda.Stream(device=self._dev) if cuda else None
         self._event = torch.cuda.Event() if cuda else None
+        # DDP's mean: RCCL reduces with ncclAvg directly (no extra launch); gloo (the CPU tests) has no AVG, there the sums are divided once,
+        # all buckets in ONE multi-tensor launch (25 separate div_ kernels per step before)
+        backend = dist.get_backend(group) if dist.is_initialized() else ""
+        self._avg_op = backend == "nccl" and hasattr(dist.ReduceOp, "AVG")
+        self.op = dist.ReduceOp.AVG if self._avg_op else dist.ReduceOp.SUM
+        # measurement (bench.py --gpus N): per-bucket start / end events on the exchange stream when enabled
+        self.timing = False
+        self._tev = {}
 
     def __len__(self):
         return len(self.buckets)
@@ -71,9 +80,16 @@ class BucketExchange:
             self._event.record(torch.cuda.current_stream(flat.device))
             self._stream.wait_event(self._event)
             with torch.cuda.stream(self._stream):
-                self._work[i] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self.timing:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self._stream)
+                self._work[i] = dist.all_reduce(flat, op=self.op, group=self.group, async_op=True)
+                if self.timing:
+                    self._work[i].wait()                  # stream-ordered wait (no host block): the end event lands behind the collective
+                    e1.record(self._stream)
+                    self._tev[i] = (e0, e1)
         else:
-            self._work[i] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._work[i] = dist.all_reduce(flat, op=self.op, group=self.group, async_op=True)
 
     def finish(self):
         """Every bucket must have been readied this step (ranks that disagree would hang on mismatched collectives): wait,
@@ -81,20 +97,31 @@ class BucketExchange:
         missing = [i for i, r in enumerate(self._ready) if not r]
         if missing:
             raise RuntimeError(f"gradient buckets {missing} were never readied this step")
-        for i, flat in enumerate(self.buckets):
-            w = self._work[i]
-            if w is not None:
-                if self._stream is not None:
-                    with torch.cuda.stream(self._stream):
-                        w.wait()
-                        flat.div_(self.world)
-                else:
-                    w.wait()
-                    flat.div_(self.world)
-                self._work[i] = None
+        pending = [i for i, w in enumerate(self._work) if w is not None]
+        if self._stream is not None:
+            with torch.cuda.stream(self._stream):
+                for i in pending:
+                    self._work[i].wait()
+                if pending and not self._avg_op:
+                    torch._foreach_div_([self.buckets[i] for i in pending], float(self.world))
+        else:
+            for i in pending:
+                self._work[i].wait()
+            if pending and not self._avg_op:
+                torch._foreach_div_([self.buckets[i] for i in pending], float(self.world))
+        for i in pending:
+            self._work[i] = None
         if self._stream is not None and self.world > 1:
             torch.cuda.current_stream(self._dev).wait_stream(self._stream)
         self._ready = [False] * len(self.buckets)
+
+    def bucket_times_ms(self):
+        """{bucket: milliseconds of its all-reduce on the exchange stream} of the last step run with timing = True (synchronises)."""
+        out = {}
+        for i, (e0, e1) in self._tev.items():
+            e1.synchronize()
+            out[i] = e0.elapsed_time(e1)
+        return out
 
     def abort(self):
         """Forget a step that failed half-way (an exception between ready() calls): wait for what was launched, clear the flags."""
@@ -111,16 +138,21 @@ class BnSync:
 
     def __init__(self, engine, world: int, group=None):
         self.eng, self.group = engine, group
-        self._buf = torch.zeros(1 << 16, dtype=torch.float32, device=engine.device)
+        self._views = {}
         engine.set_bn_sync(self, world)
 
+    class _Raw:
+        """the engine's 2C floats as a zero-copy tensor (CUDA array interface): the collective runs on the engine's memory itself"""
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
     def __call__(self, ptr: int, n: int):
-        from .engine import _HipMemcpy
-        st = torch.cuda.current_stream(self.eng.device).cuda_stream
-        buf = self._buf[:n]
-        _HipMemcpy.copy(buf.data_ptr(), ptr, 4 * n, st)
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-        _HipMemcpy.copy(ptr, buf.data_ptr(), 4 * n, st)
+        v = self._views.get((ptr, n))
+        if v is None:
+            v = torch.as_tensor(self._Raw(ptr, n), device=self.eng.device)
+            assert v.data_ptr() == ptr and v.numel() == n
+            self._views[(ptr, n)] = v
+        dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)      # ordered on the current stream (RCCL), blocking on gloo
 
 
 class DataParallelTrainer:

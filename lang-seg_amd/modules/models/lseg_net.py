@@ -198,35 +198,38 @@ class LSeg(BaseModel):
         gradients, possibly referenced by a live autograd graph) are never evicted.  Replicas made by DataParallel.replicate
         (additional_utils/encoding_models.py:43) share this dict object; the device index in the key keeps their engines apart."""
         from lseg_hip.engine import HipEngine
-        # the operand type is part of the key: after a fallback (fp16 -> bf16) an fp16 engine is never picked up again, on any device
-        key = (H, W, device.index, bool(train), "bf16" if train else self.image_dtype)
-        eng = self._engines.get(key)
-        if eng is not None:
-            self._engines.move_to_end(key)
-        else:
-            mine = [k for k in self._engines if k[2] == device.index and not k[3] and self._engines[k] is not getattr(self, "_last_engine", None)]
-            n_eval = len([k for k in self._engines if k[2] == device.index and not k[3]])
-            while mine and n_eval >= max(1, self.max_engines):
-                self._engines.pop(mine.pop(0)).close()
-                n_eval -= 1
-        if eng is None or eng.max_batch < B or eng.max_labels < K:
-            carried = None
+        # cache look-up, eviction and insert under the lock the range guard iterates under: DataParallel replicas (one thread per device)
+        # share this dict (ADVICE r5)
+        with self._shared["lock"]:
+            # the operand type is part of the key: after a fallback (fp16 -> bf16) an fp16 engine is never picked up again, on any device
+            key = (H, W, device.index, bool(train), "bf16" if train else self.image_dtype)
+            eng = self._engines.get(key)
             if eng is not None:
-                if train and getattr(eng, "_ts", None) is not None and eng._ts.sgd_steps > 0:
-                    # a bigger batch on a training engine: rebuild it, but the optimizer state moves over
-                    carried = ({k: eng.get_momentum(k) for k in eng.grads}, eng._ts.sgd_steps)
-                    torch.cuda.current_stream(device).synchronize()
-                eng.close()
-            eng = HipEngine(self.cfg, H, W, max_batch=max(B, eng.max_batch if eng else 1),
-                            max_labels=max(K, eng.max_labels if eng else 1), device=device,
-                            image_dtype="bf16" if train else self.image_dtype,
-                            exact_head_grad=bool(getattr(self, "exact_head_grad", False)),
-                            batch_invariant=bool(getattr(self, "batch_invariant", False)))
-            eng._stamp = None
-            eng._tok = None
-            eng._ts = None
-            eng._carried = carried
-            self._engines[key] = eng
+                self._engines.move_to_end(key)
+            else:
+                mine = [k for k in self._engines if k[2] == device.index and not k[3] and self._engines[k] is not getattr(self, "_last_engine", None)]
+                n_eval = len([k for k in self._engines if k[2] == device.index and not k[3]])
+                while mine and n_eval >= max(1, self.max_engines):
+                    self._engines.pop(mine.pop(0)).close()
+                    n_eval -= 1
+            if eng is None or eng.max_batch < B or eng.max_labels < K:
+                carried = None
+                if eng is not None:
+                    if train and getattr(eng, "_ts", None) is not None and eng._ts.sgd_steps > 0:
+                        # a bigger batch on a training engine: rebuild it, but the optimizer state moves over
+                        carried = ({k: eng.get_momentum(k) for k in eng.grads}, eng._ts.sgd_steps)
+                        torch.cuda.current_stream(device).synchronize()
+                    eng.close()
+                eng = HipEngine(self.cfg, H, W, max_batch=max(B, eng.max_batch if eng else 1),
+                                max_labels=max(K, eng.max_labels if eng else 1), device=device,
+                                image_dtype="bf16" if train else self.image_dtype,
+                                exact_head_grad=bool(getattr(self, "exact_head_grad", False)),
+                                batch_invariant=bool(getattr(self, "batch_invariant", False)))
+                eng._stamp = None
+                eng._tok = None
+                eng._ts = None
+                eng._carried = carried
+                self._engines[key] = eng
         stamp = self._stamp()
         if eng._stamp != stamp:                       # first use, load_state_dict, torch.optim step, .cuda(), a fused step on another engine ...
             eng.load_state_dict(self.state_dict())

@@ -153,6 +153,67 @@ def test_hand_scheduled_residual_gemm_refuses_unpadded_buffers(lib):
     assert (Cb - ref).abs().max().item() < 2e-3 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("R,C_,ld,off", [(7208, 1024, 1024, 0), (901, 513, 520, 0), (3333, 96, 96, 3), (130, 8, 8, 1), (60000, 256, 256, 0)])
+@pytest.mark.parametrize("det", [False, True])
+def test_column_sums_atomic_and_deterministic(lib, dtype, R, C_, ld, off, det):
+    """The bias-gradient column sum (lseg_op_colsum) against fp64, ragged R / C, a leading dimension above C, an output that is not 16-byte
+    aligned (`off` floats into its buffer) -- on the fp32-atomics path and on the DETERMINISTIC path (partial rows + fixed-order reduction:
+    lseg_config.flags bit 3, what the training step runs by default), which must also repeat bit for bit and honour `accumulate`."""
+    x = rnd((R, ld), dtype, 41)
+    ref = x[:, :C_].double().sum(0)
+    scale = x[:, :C_].double().abs().sum(0).max().item()
+    ws = torch.empty(1 << 20, dtype=torch.float32, device="cuda") if det else None
+    buf = torch.full((C_ + 8,), 7.0, dtype=torch.float32, device="cuda")
+    out = buf[off:off + C_]
+    outs = []
+    for rep in range(2):
+        _lib.check(lib.lseg_op_colsum(P(x), DT[dtype], P(out), R, C_, ld, 0, P(ws), ws.numel() if det else 0, stream()))
+        torch.cuda.synchronize()
+        outs.append(out.clone())
+    assert (outs[0].double() - ref).abs().max().item() <= 2e-6 * scale + 1e-6, (outs[0].double() - ref).abs().max().item()
+    assert (buf[:off] == 7).all() and (buf[off + C_:] == 7).all()          # nothing outside the C columns is touched
+    if det:
+        assert torch.equal(outs[0], outs[1])                                 # fixed summation order
+    _lib.check(lib.lseg_op_colsum(P(x), DT[dtype], P(out), R, C_, ld, 1, P(ws), ws.numel() if det else 0, stream()))
+    torch.cuda.synchronize()
+    assert (out.double() - 2 * ref).abs().max().item() <= 4e-6 * scale + 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,H,W,C_", [(2, 30, 30, 256), (1, 15, 17, 64), (8, 60, 60, 256)])
+@pytest.mark.parametrize("det", [False, True])
+def test_batchnorm_batch_sums_atomic_and_deterministic(lib, dtype, B, H, W, C_, det):
+    """BatchNorm batch statistics (sum, sum of squares) and the two sums of its backward over padded NHWC maps (train-mode
+    ResidualConvUnit_custom, lseg_blocks.py:276-283) against fp64, atomics and deterministic form; the deterministic form repeats bit for bit."""
+    xi = torch.randn((B, C_, H, W), generator=torch.Generator().manual_seed(51)) * 2 + 0.5
+    dyi = torch.randn((B, C_, H, W), generator=torch.Generator().manual_seed(52))
+    x, dy = _pad_nhwc(xi.cuda(), dtype), _pad_nhwc(dyi.cuda(), dtype)
+    xr = x[:, 1:-1, 1:-1, :].double().reshape(-1, C_)
+    dr = dy[:, 1:-1, 1:-1, :].double().reshape(-1, C_)
+    n = xr.shape[0]
+    ws = torch.empty(1 << 20, dtype=torch.float32, device="cuda") if det else None
+    cap = ws.numel() if det else 0
+    stats = torch.empty(2 * C_, dtype=torch.float32, device="cuda")
+    bst = torch.empty(2 * C_, dtype=torch.float32, device="cuda")
+    runs = []
+    for rep in range(2):
+        _lib.check(lib.lseg_op_bn_stats(P(x), P(stats), B, H, W, C_, DT[dtype], P(ws), cap, stream()))
+        _lib.check(lib.lseg_op_bn_bwd_stats(P(dy), P(x), P(stats), P(bst), B, H, W, C_, 1e-5, DT[dtype], P(ws), cap, stream()))
+        torch.cuda.synchronize()
+        runs.append((stats.clone(), bst.clone()))
+    s1, s2 = xr.sum(0), (xr * xr).sum(0)
+    assert (runs[0][0][:C_].double() - s1).abs().max().item() <= 2e-6 * xr.abs().sum(0).max().item()
+    assert (runs[0][0][C_:].double() - s2).abs().max().item() <= 2e-6 * s2.max().item()
+    mean = s1 / n
+    rstd = ((s2 / n - mean * mean).clamp_min(0) + 1e-5).rsqrt()
+    b1, b2 = dr.sum(0), (dr * (xr - mean) * rstd).sum(0)
+    assert (runs[0][1][:C_].double() - b1).abs().max().item() <= 2e-6 * dr.abs().sum(0).max().item()
+    assert (runs[0][1][C_:].double() - b2).abs().max().item() <= 2e-5 * (dr.abs() * ((xr - mean) * rstd).abs()).sum(0).max().item()
+    if det:
+        assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+
+
 def test_gemm_transpose_detecting(lib):
     """A = I (padded), asymmetric W: catches a swapped C layout (cdna guide G9)."""
     M = N = K = 64

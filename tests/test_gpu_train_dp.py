@@ -95,8 +95,11 @@ def _dp_worker_body(rank, world, port, sync_bn, q):
     mine = {k: v.clone() for k, v in eng.grads.items()}
     eng.sgd_step(lr, 10 * lr, 0.9, 1e-4)
     # a second step on the updated weights must run (buckets re-armed, callbacks fire again)
+    tr.exchange.timing = True                          # bench.py --gpus N: per-bucket all-reduce events on the exchange stream
     loss2 = tr.step(x.cuda(), t.cuda(), lr, 10 * lr)
     torch.cuda.synchronize()
+    bt = tr.exchange.bucket_times_ms()
+    assert sorted(bt) == list(range(len(tr.exchange))) and all(v >= 0.0 for v in bt.values()), bt
     w_after = {k: eng.bound[k].clone() for k in mine}
     if rank == 0:
         rel = lambda a, b: ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20)).item()
