@@ -80,7 +80,7 @@ def run_ref_train_case(spec):
 def main():
     gd = os.path.join(ROOT, "tests", "golden")
     cases = TRAIN_FULL_CASES if "--full" in sys.argv else TRAIN_FULL8_CASES if "--full8" in sys.argv else TRAIN_CASES
-    n_sample = 1024 if "--full8" in sys.argv else N_SAMPLE
+    n_sample = 1024 if ("--full8" in sys.argv or "--full" in sys.argv) else N_SAMPLE      # round 6: the B = 1 / 2 fixtures carry 1024 samples too
     if "--full8" in sys.argv:
         os.environ["LSEG_STUB_CHECKPOINT"] = "1"
     for name, spec in cases.items():

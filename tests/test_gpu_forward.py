@@ -113,6 +113,7 @@ def check_case(spec, image_dtype="bf16", stage_tol=0.10):
     return report
 
 
+@pytest.mark.gpu_fast
 @pytest.mark.parametrize("name", sorted(MG.CASES))
 def test_tiny_forward_matches_oracle(name):
     check_case(MG.CASES[name])
@@ -212,6 +213,7 @@ def test_text_cache_is_exact():
     assert torch.equal(again, logits)
 
 
+@pytest.mark.gpu_fast
 def test_errors_are_loud():
     from lseg_hip import _lib
     cfg = get_config("tiny16")
@@ -330,6 +332,7 @@ def assert_argmax_mismatches_are_ties(out_low_or_logits, ref_argmax, ref_margin,
     return frac
 
 
+@pytest.mark.gpu_fast
 @pytest.mark.parametrize("dtype", ["bf16", "fp16", "strict"])
 @pytest.mark.parametrize("name", _REF)
 def test_engine_matches_fixtures_made_by_the_reference_code(name, dtype, golden_dir):
@@ -588,6 +591,7 @@ def test_masks_and_metrics_without_the_full_resolution_logits():
     assert abs(res[0][1][0] - res[1][1][0]).item() <= 1e-6 * abs(res[0][1][0]).item() and res[0][1][1] == res[1][1][1]
 
 
+@pytest.mark.gpu_fast
 def test_one_pass_x4_upsample_equals_its_two_stages():
     """Production schedule: the logits come out of ONE pass over the quarter-resolution label planes (x2 bilinear * per-pixel 1/||.||,
     fp16 rounding, then output_conv's x2 bilinear, lseg_net.py:191-203) and the (h/2, w/2) logits stay in LDS.  They must equal
@@ -684,6 +688,7 @@ def test_text_features_handed_in_replace_the_text_tower():
     assert torch.equal(eng2.forward(x.cuda()), logits)
 
 
+@pytest.mark.gpu_fast
 def test_dedicated_correlation_kernel_equals_the_generic_pair(tmp_path):
     """The engine's correlation on the commuted schedule runs as ONE kernel (csrc/corr.hip: T resident in LDS, g streamed once, label planes
     + cell dot products) where round 4 ran the generic GEMM + pixel_gram_kernel (LSEG_CORR_GENERIC=1, read once per process -> a second

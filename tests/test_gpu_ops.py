@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.gpu_fast]
 
 from lseg_hip import _lib  # noqa: E402
 

@@ -33,31 +33,14 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TRAIN_REF = sorted((f[:-3] for f in os.listdir(GOLD) if f.startswith("ref_train_")), key=lambda n: ("_full_" not in n, n))
 
 
-# cosine between the engine's and the reference-autograd gradient over the stored elements, measured (profiles/r04_train_parity_table.txt):
-# medians 0.985-0.998 (B = 8 at 480 x 480, 1040 elements per tensor: 0.9977), worst tensor 0.86-0.90 (80-element samples of early-block
-# tensors: bf16 ReLU-mask flips + the fp16-subnormal head gradient land on other elements than in the fp32 reference)
-COS_MEDIAN, COS_WORST = 0.98, 0.80
-
-
 def _sample_index(numel, n=64):                       # == oracle/make_ref_train_golden.sample_index
     n = min(n, numel)
     return (torch.arange(n, dtype=torch.int64) * (numel - 1)) // max(n - 1, 1)
 
 
-@pytest.mark.parametrize("name", TRAIN_REF)
-def test_training_step_matches_fixtures_made_by_reference_autograd(name):
-    """The engine's training step against loss + gradients of the REFERENCE'S OWN network under torch autograd
-    (oracle/make_ref_train_golden.py).  `ref_train_full_*` = BASELINE configs[3] at its own shape (ViT-L/16, 480x480, K = 150;
-    B = 1 and B = 2 for the train-mode BatchNorm statistics): loss, every gradient's norm, its sum, its first 16 and 64 evenly
-    strided elements.  Full-size bar: median gradient-norm error <= 2 %."""
-    g = torch.load(os.path.join(GOLD, name + ".pt"))
-    bb, H, W, B, K, seed = g["spec"]
-    full = "_full_" in name
-    cfg = get_config(bb)
-    sd = synthetic_state_dict(cfg, seed=seed)
-    x = synthetic_images(B, H, W, seed=seed)
-    eng, out, loss, _ = _engine_step(cfg, sd, x, _target(B, H, W, K, seed), g["tokens"])
-    assert abs(loss.item() - g["loss"]) <= 1e-2 * abs(g["loss"]), (loss.item(), g["loss"])
+def _compare_with_fixture(eng, g):
+    """per-tensor metrics of the engine's gradients against a reference-autograd fixture: norm error, first-16 and strided-sample element
+    errors (relative to the tensor's scale), sum error, cosine over the stored elements"""
     names = {n for n in g["grads"] if not n.startswith("clip_pretrained.")}
     assert set(eng.grads) == names, sorted(set(eng.grads) ^ names)[:10]
     nerr, herr, serr, sumerr, cosv = {}, {}, {}, {}, {}
@@ -73,38 +56,100 @@ def test_training_step_matches_fixtures_made_by_reference_autograd(name):
             got = mine.flatten()[_sample_index(mine.numel(), r["sample"].numel())]
             serr[n] = (got - r["sample"]).abs().max().item() / sscale
             sumerr[n] = abs(float(mine.double().sum()) - r["sum"]) / max(r["norm"] * mine.numel() ** 0.5, 1e-20)
-            # direction: cosine between the engine's and the reference's gradient over the stored elements (first 16 + the strided
-            # sample: 80 per tensor in the B = 1 / 2 fixtures, 1040 in the B = 8 one) -- a permuted or mis-signed gradient with the
+            # direction: cosine between the engine's and the reference's gradient over the stored elements (first 16 + the strided sample:
+            # 1040 per tensor in the 480 x 480 fixtures since round 6, 80 in the small ones) -- a permuted or mis-signed gradient with the
             # right norm has cosine ~ 0
             a, b = torch.cat([mine.flatten()[:16], got]).double(), torch.cat([r["head"], r["sample"]]).double()
             if float(b.norm()) > 0 and b.numel() >= 32:
                 cosv[n] = float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-300))
+    return {"nerr": nerr, "herr": herr, "serr": serr, "sumerr": sumerr, "cos": cosv}
+
+
+# Bars (round 6), from the measured tables profiles/r05_train_parity_table.txt / r06_train_parity_table.txt: worst
+# gradient-norm error 3.5-6.5 % (bar 10 %), median 0.3-1.2 % at 480 x 480 (bar 2 %), 0.6-3.2 % on the small cases (bar 5 %); element errors
+# relative to the tensor's scale: medians 0.06-0.18 (bar 0.25, was 0.35), single elements up to 1.23 (bar 1.5); cosine median 0.984-0.998
+# (bar 0.98), worst single tensor 0.873-0.905 (bar 0.85, was 0.80).  The worst cosines do NOT come from small samples: the B = 8 fixture
+# holds 1040 elements per tensor and its worst is 0.896 (patch_embed.proj.weight) -- early-layer gradients behind 24 blocks of bf16
+# ReLU / softmax roundings and the reference's fp16-subnormal head gradient (DESIGN par. 3.6).  What the bars DO catch is pinned by
+# test_the_fixture_bars_catch_a_dropped_residual_branch below.
+COS_MEDIAN, COS_WORST = 0.98, 0.85
+ELEM_MEDIAN, ELEM_WORST = 0.25, 1.5
+
+
+def _violations(m, full):
+    med = lambda d: sorted(d.values())[len(d) // 2]
+    v = []
+    if max(m["nerr"].values()) > 0.10: v.append(("worst gradient-norm error", max(m["nerr"].values())))
+    if med(m["nerr"]) > (0.02 if full else 0.05): v.append(("median gradient-norm error", med(m["nerr"])))
+    if max(m["herr"].values()) > ELEM_WORST: v.append(("worst first-16 element error", max(m["herr"].values())))
+    if med(m["herr"]) > ELEM_MEDIAN: v.append(("median first-16 element error", med(m["herr"])))
+    if m["serr"]:
+        if max(m["serr"].values()) > ELEM_WORST: v.append(("worst strided element error", max(m["serr"].values())))
+        if med(m["serr"]) > ELEM_MEDIAN: v.append(("median strided element error", med(m["serr"])))
+        if max(m["sumerr"].values()) > 0.25: v.append(("worst sum error", max(m["sumerr"].values())))
+    if m["cos"]:
+        if med(m["cos"]) < COS_MEDIAN: v.append(("median cosine", med(m["cos"])))
+        if min(m["cos"].values()) < COS_WORST: v.append(("worst cosine", min(m["cos"].values())))
+    return v
+
+
+@pytest.mark.parametrize("name", [pytest.param(n, marks=pytest.mark.gpu_fast) if "_full_" not in n else n for n in TRAIN_REF])
+def test_training_step_matches_fixtures_made_by_reference_autograd(name):
+    """The engine's training step against loss + gradients of the REFERENCE'S OWN network under torch autograd
+    (oracle/make_ref_train_golden.py).  `ref_train_full_*` = BASELINE configs[3] at its own shape (ViT-L/16, 480x480, K = 150;
+    B = 1, 2 and the per-GPU batch 8): loss, every gradient's norm, its sum, its first 16 and 1024 evenly strided elements."""
+    g = torch.load(os.path.join(GOLD, name + ".pt"))
+    bb, H, W, B, K, seed = g["spec"]
+    full = "_full_" in name
+    cfg = get_config(bb)
+    sd = synthetic_state_dict(cfg, seed=seed)
+    x = synthetic_images(B, H, W, seed=seed)
+    eng, out, loss, _ = _engine_step(cfg, sd, x, _target(B, H, W, K, seed), g["tokens"])
+    assert abs(loss.item() - g["loss"]) <= 1e-2 * abs(g["loss"]), (loss.item(), g["loss"])
+    m = _compare_with_fixture(eng, g)
+    nerr, herr, serr, sumerr, cosv = m["nerr"], m["herr"], m["serr"], m["sumerr"], m["cos"]
     med = lambda d: sorted(d.values())[len(d) // 2]
     wn = sorted(nerr.items(), key=lambda kv: -kv[1])[:5]
     wh = sorted(herr.items(), key=lambda kv: -kv[1])[:5]
     ws = sorted(serr.items(), key=lambda kv: -kv[1])[:5]
     line = (f"{name}: loss {loss.item():.5f} vs {g['loss']:.5f}; gradient-norm error median {med(nerr):.4f} worst "
             f"{[(k, round(v, 4)) for k, v in wn[:3]]}; first-16 error median {med(herr):.3f} worst {wh[0][1]:.3f}; "
-            f"strided-64 error median {med(serr) if serr else -1:.3f} worst {ws[0][1] if ws else -1:.3f}; "
+            f"strided-sample error median {med(serr) if serr else -1:.3f} worst {ws[0][1] if ws else -1:.3f}; "
             f"sum error worst {max(sumerr.values()) if sumerr else -1:.4f}")
     if cosv:
         wc = sorted(cosv.items(), key=lambda kv: kv[1])[:3]
-        line += f"; cosine over the stored elements median {med(cosv):.4f} worst {[(k, round(v, 3)) for k, v in wc]}"
+        n_el = 16 + next(iter(g["grads"].values()))["sample"].numel()
+        line += f"; cosine over the stored elements (<= {n_el} per tensor) median {med(cosv):.4f} worst {[(k, round(v, 3)) for k, v in wc]}"
     print(line)
     out_dir = os.path.join(os.path.dirname(GOLD), "..", "gpurun_out")
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "train_parity_table.txt"), "a") as f:
             f.write(line + "\n")
-    # measured (small cases): ViT-L/16 median norm error 0.6 %, worst 3.6 % (2x2-pixel refinenet4 maps of the 64x64 case); ViT-B/32 3.2 % / 6.4 %
-    # element-wise (first-16 / strided-64, relative to the tensor's scale): medians 0.12-0.18, single elements up to ~1.2 -- bf16 ReLU-mask
-    # flips and, at 480x480, the fp16 subnormal quantisation of the head gradient land differently than in the fp32 reference; a wiring
-    # error shows in the norms (bars above) and moves the medians towards 1
-    assert wn[0][1] <= 0.10 and med(nerr) <= (0.02 if full else 0.05) and wh[0][1] <= 1.5 and med(herr) <= 0.35, (wn, wh)
-    if serr:
-        assert ws[0][1] <= 1.5 and med(serr) <= 0.35 and max(sumerr.values()) <= 0.25, (ws, max(sumerr.values()))
-    if cosv:
-        # per-tensor direction next to the norm bars.  (bars set from the measured run, profiles/r04_train_parity_table.txt)
-        assert med(cosv) >= COS_MEDIAN and min(cosv.values()) >= COS_WORST, (med(cosv), sorted(cosv.items(), key=lambda kv: kv[1])[:5])
+    bad = _violations(m, full)
+    assert not bad, (bad, wn[:3], sorted(cosv.items(), key=lambda kv: kv[1])[:3])
+
+
+@pytest.mark.gpu_fast
+@pytest.mark.parametrize("fault", ["drop_mlp_branch_of_block_5", "scale_layer1_rn_by_1.5", "drop_attention_branch_of_block_20"])
+def test_the_fixture_bars_catch_a_dropped_residual_branch(fault):
+    """Fault injection: the SAME comparison, with one block's residual branch removed from the network the engine runs
+    (or the head mis-scaled by 15 %) -- the bars above must fail.  A bar that passes a network with a missing branch measures nothing."""
+    name = "ref_train_vitl16_64x64_k5_b2"
+    g = torch.load(os.path.join(GOLD, name + ".pt"))
+    bb, H, W, B, K, seed = g["spec"]
+    cfg = get_config(bb)
+    sd = synthetic_state_dict(cfg, seed=seed)
+    if fault == "drop_mlp_branch_of_block_5":
+        sd["pretrained.model.blocks.5.mlp.fc2.weight"].zero_(); sd["pretrained.model.blocks.5.mlp.fc2.bias"].zero_()
+    elif fault == "drop_attention_branch_of_block_20":
+        sd["pretrained.model.blocks.20.attn.proj.weight"].zero_(); sd["pretrained.model.blocks.20.attn.proj.bias"].zero_()
+    else:
+        sd["scratch.layer1_rn.weight"].mul_(1.5)
+    x = synthetic_images(B, H, W, seed=seed)
+    eng, out, loss, _ = _engine_step(cfg, sd, x, _target(B, H, W, K, seed), g["tokens"])
+    bad = _violations(_compare_with_fixture(eng, g), full=False)
+    print(fault, "->", bad)
+    assert bad, f"{fault}: every bar still passes"
 
 
 @pytest.mark.parametrize("bb,H,W,B,K,seed", [("tiny16", 64, 64, 2, 5, 3), ("tiny32", 96, 96, 2, 7, 4)])
@@ -207,16 +252,18 @@ def test_bucket_rule_and_gradient_accumulation():
         assert worst_acc <= 1e-2, worst_acc
 
 
-def test_atomic_sums_stay_within_rounding_of_the_deterministic_ones():
+@pytest.mark.parametrize("bb,H,W,K,seed", [("tiny16", 64, 64, 5, 3), ("clip_vitl16_384", 64, 64, 5, 11)])
+def test_atomic_sums_stay_within_rounding_of_the_deterministic_ones(bb, H, W, K, seed):
     """The column sums on fp32 atomics (deterministic=False; rounds 2-4's only form): same numbers up to the summation order.  A last-bit difference in a BatchNorm
     batch sum flips a bf16 rounding somewhere, which the layers above amplify on the seeded random net: measured median 0.5 %, worst
     1.7 % per tensor (lease A of round 5) -- the run-to-run noise of the atomics path itself (profiles/r05_train_spread.txt: +-0.8 points on the
-    oracle comparison), an order of magnitude below either engine's distance to the fp32 oracle on those tensors."""
-    cfg = get_config("tiny16")
-    sd = synthetic_state_dict(cfg, seed=3)
-    tok = synthetic_tokens(read_labels(MG.LABELS)[:5], cfg.text.vocab, cfg.text.ctx)
-    x = synthetic_images(2, 64, 64, seed=3)
-    target = _target(2, 64, 64, 5, 3)
+    oracle comparison), an order of magnitude below either engine's distance to the fp32 oracle on those tensors.  Round 6: also at
+    ViT-L/16 WIDTH (1024-wide Linears, 256-channel BatchNorms: the column kernels' full-width paths), not only on the 64-wide twin."""
+    cfg = get_config(bb)
+    sd = synthetic_state_dict(cfg, seed=seed)
+    tok = synthetic_tokens(read_labels(MG.LABELS)[:K], cfg.text.vocab, cfg.text.ctx)
+    x = synthetic_images(2, H, W, seed=seed)
+    target = _target(2, H, W, K, seed)
     ea, outa, la, _ = _engine_step(cfg, {k: v.clone() for k, v in sd.items()}, x, target, tok, deterministic=True)
     eb, outb, lb, _ = _engine_step(cfg, {k: v.clone() for k, v in sd.items()}, x, target, tok, deterministic=False)
     assert ea.deterministic and not eb.deterministic

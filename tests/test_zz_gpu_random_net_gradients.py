@@ -28,8 +28,10 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 # bars: ~2x the three tested (case, seed) pairs = the ~80-90th percentile of the 18-pair seed distribution (profiles/r05_train_spread.txt);
 # element-wise on tensors > 1024 elements, norm error and cosine on every tensor, per-case median -- per regime (smooth / rough)
-BARS = {True: dict(big=0.15, norm=0.10, cos=0.985, median=0.04),
-        False: dict(big=0.55, norm=0.28, cos=0.85, median=0.35)}
+# round 6: tensors with <= 1024 elements -- the biases, BatchNorm / LayerNorm parameters whose reductions round 5 rewrote -- keep an
+# ELEMENT-WISE bar in the smooth regime too (no ReLU flips there: their error is the reduction's own); rough regime: norm + cosine as before
+BARS = {True: dict(big=0.15, small=0.15, norm=0.10, cos=0.985, median=0.04),
+        False: dict(big=0.55, small=None, norm=0.28, cos=0.85, median=0.35)}
 
 
 @pytest.mark.parametrize("smooth", [True, False])
@@ -75,6 +77,11 @@ def test_backward_matches_oracle_autograd_gradient_by_gradient(bb, H, W, B, K, s
     cosv = {k: cosine(eng.grads[k].cpu(), ref_grads[k]) for k in ref_grads}
     med = sorted(report.values())[len(report) // 2]
     bad_big = {k: round(v, 4) for k, v in report.items() if ref_grads[k].numel() > 1024 and not v <= bars["big"]}
+    small = {k: v for k, v in report.items() if ref_grads[k].numel() <= 1024}
+    if small:
+        print(f"   worst element-wise error on the <= 1024-element tensors: {max(small.values()):.4f} ({max(small, key=small.get)})")
+    if bars["small"] is not None:
+        bad_big.update({k: round(v, 4) for k, v in small.items() if not v <= bars["small"]})
     bad_norm = {k: round(v, 4) for k, v in nerrs.items() if not v <= bars["norm"]}
     bad_cos = {k: round(v, 4) for k, v in cosv.items() if not v >= bars["cos"]}
     print(f"   min cosine {min(cosv.values()):.4f} ({min(cosv, key=cosv.get)}); bars {bars}")
