@@ -424,11 +424,25 @@ def test_engine_matches_the_reference_at_the_baseline_configs(name, dtype, golde
         mism = low.argmax(1) != g["argmax_lowres"].long()
         worst = g["margin_lowres"].float()[mism].max().item() if mism.any() else 0.0
         with open(os.path.join(out_dir, "parity_table.txt"), "a") as f:
-            f.write(f"{name} {dtype}: max|dlogit| {err:.5f}  argmax mismatch fraction {frac:.6f}  max reference margin at a mismatch {worst:.5f}\n")
+            fl, ftxt = _floor(name, "oracle_vs_reference_240")
+            mult = f" = {frac / fl:.1f} x floor" if fl else ""
+            f.write(f"{name} {dtype}: max|dlogit| {err:.5f}  argmax mismatch fraction {frac:.6f}  max reference margin at a mismatch {worst:.5f}{ftxt}{mult}\n")
     tf = eng.encode_text().float().cpu()
     tr = g["text_features"].float()
     tr = tr / tr.norm(dim=-1, keepdim=True)
     assert (tf - tr).abs().max().item() <= 4e-3
+
+
+
+def _floor(name, key):
+    """the fp32-vs-fp32 noise floor of the mask (tools/parity_floor.py -> profiles/r06_parity_floor.json): argmax flips of the fp32 oracle against
+    the fp32 reference on the same fixture with the same text features.  (value, text for the table); (None, "") when not recorded"""
+    import json
+    try:
+        fl = json.load(open(os.path.join(os.path.dirname(_GOLD), "..", "profiles", "r06_parity_floor.json")))[name][key]["argmax_mismatch_frac"]
+    except (OSError, KeyError, ValueError):
+        return None, ""
+    return fl, f"  fp32-vs-fp32 floor {fl:.6f}"
 
 
 # absolute bars of the 480 x 480 mask test (the "ties" statement above scales with the measured error; these do not): fraction of the
@@ -480,7 +494,9 @@ def test_engine_masks_match_the_reference_at_480x480(name, dtype, golden_dir):
     out_dir = os.path.join(os.path.dirname(golden_dir), "..", "gpurun_out")
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "parity_table.txt"), "a") as f:
-            f.write(f"{name} {dtype} 480x480: max|dlogit| {err:.5f}  argmax mismatch fraction {frac:.6f}  max reference margin at a mismatch {worst:.5f}\n")
+            fl, ftxt = _floor(name, "oracle_vs_reference_480")
+            mult = f" = {frac / fl:.1f} x floor" if fl else ""
+            f.write(f"{name} {dtype} 480x480: max|dlogit| {err:.5f}  argmax mismatch fraction {frac:.6f}  max reference margin at a mismatch {worst:.5f}{ftxt}{mult}\n")
     assert err <= REF_TOL_BY_NAME.get(name, REF_TOL)[dtype], (name, dtype, err)
     assert worst <= 2 * err + 1e-6 and worst <= cap_margin and frac <= cap_frac, (name, dtype, frac, worst, err)
     if K <= 256:
