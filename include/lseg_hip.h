@@ -180,6 +180,12 @@ int lseg_set_profiling(lseg_handle h, int enabled);
  * [1] = finite values with |x| >= 2^15, [2] = the largest finite |x| (fp32 bit pattern), [3] = elements scanned.  Synchronises the
  * stream.  The Python mirror runs it once after every (re)pack of an fp16 engine and falls back to bf16 loudly when [0] > 0. */
 int lseg_check_range(lseg_handle h, uint64_t* host_out4, void* stream);
+/* The always-on companion of lseg_check_range: every inference lseg_forward raises a device flag when the head feature map carries an inf / NaN
+ * (any non-finite value of the 16-bit image tower ends up there) and copies it to pinned host memory behind the forward.  This call never
+ * synchronises: it returns 1 once a COMPLETED forward was flagged (sticky until `reset`), else 0 -- i.e. an overflow on image n is seen at the
+ * latest when image n+1 is submitted.  The Python mirror falls back to bf16 operands loudly on it (fp16 saturates at 65504; the reference's
+ * tower is fp32, lseg_vit.py:196-197). */
+int lseg_overflow_seen(lseg_handle h, int reset);
 int lseg_get_profile(lseg_handle h, const char* family, double* total_ms, int64_t* launches,
                      double* flops_per_launch);
 

@@ -113,6 +113,8 @@ int lseg_check_range(lseg_handle h, uint64_t* out4, void* stream) {
     return r;
 }
 
+int lseg_overflow_seen(lseg_handle h, int reset) { GUARD(h); return h->e->overflow_seen(reset != 0); }
+
 int lseg_set_profiling(lseg_handle h, int enabled) {
     GUARD(h);
     // 1 = the whole forward + the MLP fc1 GEMM (rounds 1-2); otherwise a mask, bit f = family f in lseg_get_profile's order

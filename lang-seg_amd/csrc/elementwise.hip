@@ -583,7 +583,9 @@ __global__ __launch_bounds__(256) void pixel_gram_kernel(const uint16_t* __restr
     }
 }
 // scale[b, Y, X] = s / ||u_P||  on the (2H, 2W) grid, from the 2x2-cell dot products: ||u||^2 = sum_i w_i^2 (g_i.g_i) + 2 sum_{i<j} w_i w_j (g_i.g_j)
-__global__ void norm_scale_plane_kernel(const float* __restrict__ gram, float* __restrict__ scale, int B, int H, int W, float s) {
+// `flag` (optional): set to 1 when a pixel's squared norm is not finite -- an inf / NaN anywhere in the 16-bit image tower (fp16 operands
+// saturate at 65504) has reached the head feature map; the engine's always-on overflow sentinel (Engine::overflow_seen)
+__global__ void norm_scale_plane_kernel(const float* __restrict__ gram, float* __restrict__ scale, int B, int H, int W, float s, unsigned* __restrict__ flag) {
     const int Ho = 2 * H, Wo = 2 * W;
     const size_t n = (size_t)B * Ho * Wo;
     const float ry = (float)(H - 1) / (float)(Ho - 1), rx = (float)(W - 1) / (float)(Wo - 1);
@@ -602,6 +604,7 @@ __global__ void norm_scale_plane_kernel(const float* __restrict__ gram, float* _
         const float n2 = wa * wa * ra[0] + wb * wb * rb[0] + wc * wc * rc[0] + wd * wd * rd[0] +
                          2.f * (wa * wb * ra[1] + wa * wc * ra[2] + wa * wd * ra[3] + wb * wc * ra[4] + wb * wd * rb[2] + wc * wd * rc[1]);
         scale[i] = s * rsqrtf(n2);
+        if (flag && !(fabsf(n2) <= 3.0e38f)) *flag = 1u;        // (benign race: every writer stores the same value)
     }
 }
 // x2 bilinear (align_corners=True) of the label planes R (padded [P, H+2, W+2] fp32, interior read) with the per-pixel factor and the
@@ -2599,8 +2602,8 @@ int launch_pixel_gram(const void* g16, float* gram, int B, int H, int W, int C, 
     CHECK_LAUNCH();
     return 0;
 }
-int launch_norm_scale_plane(const float* gram, float* scale, int B, int H, int W, float s, hipStream_t st) {
-    hipLaunchKernelGGL(norm_scale_plane_kernel, dim3(grid_for((size_t)B * 4 * H * W)), dim3(256), 0, st, gram, scale, B, H, W, s);
+int launch_norm_scale_plane(const float* gram, float* scale, int B, int H, int W, float s, hipStream_t st, unsigned* flag) {
+    hipLaunchKernelGGL(norm_scale_plane_kernel, dim3(grid_for((size_t)B * 4 * H * W)), dim3(256), 0, st, gram, scale, B, H, W, s, flag);
     CHECK_LAUNCH();
     return 0;
 }

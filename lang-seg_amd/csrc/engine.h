@@ -64,6 +64,10 @@ public:
     int get_profile(const char* family, double* ms, int64_t* launches, double* flops);
     // 16-bit range check of the image tower (fp16 operands saturate at 65504): scans every 16-bit activation buffer of the plan
     int check_range(unsigned long long* host_out4, hipStream_t st);
+    // Always-on overflow sentinel of the inference forward: norm_scale_plane_kernel raises a device flag when the head feature map carries an
+    // inf / NaN (anything non-finite in the 16-bit tower ends up there); the flag is copied to pinned host memory behind every forward and
+    // read WITHOUT synchronising: 1 as soon as a COMPLETED forward was flagged (sticky until reset), 0 otherwise.
+    int overflow_seen(bool reset);
     // ---- training step (train.hip; modules/lsegmentation_module.py:66-81) ----
     int set_train(bool on);
     int bind_grad(const char* key, float* dev_ptr);
@@ -124,6 +128,7 @@ private:
     std::vector<void*> allocs_;
     std::vector<std::pair<const uint16_t*, size_t>> act16_;     // every 16-bit image-tower activation buffer (check_range)
     unsigned long long* range_out_ = nullptr;
+    unsigned* ovf_dev_ = nullptr; unsigned* ovf_host_ = nullptr; hipEvent_t ev_ovf_ = nullptr; bool ovf_pending_ = false, ovf_sticky_ = false;
     bool finalized_ = false, inited_ = false;
     int last_B_ = 0, last_kout_ = 0;
     const float* last_low_ = nullptr;

@@ -46,6 +46,8 @@ Engine::~Engine() {
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
     if (ev_text_done_) (void)hipEventDestroy(ev_text_done_);
+    if (ev_ovf_) (void)hipEventDestroy(ev_ovf_);
+    if (ovf_host_) (void)hipHostFree(ovf_host_);
     for (auto e : ev_free_) (void)hipEventDestroy(e);
     for (void* p : allocs_) (void)hipFree(p);
     for (auto e : ev_pool_) (void)hipEventDestroy(e);
@@ -152,6 +154,10 @@ int Engine::init() {
     ALLOC(g16pad_, uint16_t, B * (lh_[0] + 2) * (lw_[0] + 2) * c.out_c);
     act16_.emplace_back(g16pad_, B * (lh_[0] + 2) * (lw_[0] + 2) * c.out_c);       // fp16 whatever the operand type: the correlation's operand
     ALLOC(range_out_, unsigned long long, 4);
+    ALLOC(ovf_dev_, unsigned, 4);
+    LSEG_HIP_TRY(hipHostMalloc((void**)&ovf_host_, 16, hipHostMallocDefault));
+    ovf_host_[0] = 0;
+    LSEG_HIP_TRY(hipEventCreateWithFlags(&ev_ovf_, hipEventDisableTiming));
     ALLOC(rpl_, float, B * c.max_labels * (lh_[0] + 2) * (lw_[0] + 2));
     ALLOC(gram_, float, B * lh_[0] * lw_[0] * 5);
     ALLOC(nscale_, float, B * hw1);
@@ -679,6 +685,20 @@ int Engine::check_range(unsigned long long* host_out4, hipStream_t st) {
     return 0;
 }
 
+int Engine::overflow_seen(bool reset) {
+    if (ovf_pending_ && hipEventQuery(ev_ovf_) == hipSuccess) {
+        ovf_pending_ = false;
+        if (ovf_host_[0]) ovf_sticky_ = true;
+    }
+    const int r = ovf_sticky_ ? 1 : 0;
+    // the DEVICE flag is sticky too: it is cleared only here, after a report -- every later forward keeps copying the 1 until someone has seen it
+    if (reset && r) {
+        ovf_sticky_ = false;
+        (void)hipMemsetAsync(ovf_dev_, 0, sizeof(unsigned), nullptr);      // (rare path: after a reported overflow)
+    }
+    return r;
+}
+
 int Engine::get_profile(const char* family, double* ms, int64_t* launches, double* flops) {
     TRY(flush_events());
     static const char* names[PF_N] = {"forward", "mlp_fc1", "mlp_fc2", "attn_proj", "attn_qkv", "attention", "layernorm", "correlation"};
@@ -909,7 +929,12 @@ int Engine::forward(const float* x_in, int B, float* logits, uint8_t* argmax_out
         else TRY(launch_pixel_gram(g16pad_, gram_, B, lh_[0], lw_[0], c.out_c, st));
         if (corr_fused) prof_end(PF_CORR, pc, (double)B * hp * wp * c.out_c * 2.0 + (double)B * K_ * lh_[0] * lw_[0] * 4.0 + (double)B * lh_[0] * lw_[0] * 20.0 +
                                               (double)K_ * c.out_c * 2.0, st);
-        TRY(launch_norm_scale_plane(gram_, nscale_, B, lh_[0], lw_[0], logit_scale, st));
+        TRY(launch_norm_scale_plane(gram_, nscale_, B, lh_[0], lw_[0], logit_scale, st, ovf_dev_));
+        // the sentinel travels to pinned host memory behind the forward; Engine::overflow_seen reads it once the event has passed (no sync)
+        (void)overflow_seen(false);                      // harvest the previous forward's copy before its event is recorded again
+        LSEG_HIP_TRY(hipMemcpyAsync(ovf_host_, ovf_dev_, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        LSEG_HIP_TRY(hipEventRecord(ev_ovf_, st));
+        ovf_pending_ = true;
         if (corr_fused) {
         } else if (group_k > 0) {
             // lseg_net_zs.py:198-208: image b against its own k text rows -- B small GEMMs [k, out_c] x [out_c, hp*wp]

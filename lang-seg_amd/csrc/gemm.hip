@@ -407,17 +407,34 @@ enum Epi {
 #ifndef GEMM_EPI_ABL
 #define GEMM_EPI_ABL 0
 #endif
+// GEMM_NT (A/B builds, tools): 1 = the specialised epilogues' stores are NON-TEMPORAL (the output streams past L2 instead of evicting the operand
+// panels the XCD's other tiles are about to re-read), 2 = the residual loads of EPI_RES32 as well
+#ifndef GEMM_NT
+#define GEMM_NT 0
+#endif
+typedef unsigned u32x4_nt __attribute__((ext_vector_type(4)));
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_u4(void* p, const uint4 v) {
     if constexpr (GEMM_EPI_ABL == 1) asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(p));
+    else if constexpr (GEMM_NT >= 1) __builtin_nontemporal_store(u32x4_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_nt*>(p));
     else *reinterpret_cast<uint4*>(p) = v;
 }
 __device__ __forceinline__ void st_f4(float* p, const float4 v) {
     if constexpr (GEMM_EPI_ABL == 1) asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w), "v"(p));
+    else if constexpr (GEMM_NT >= 1) __builtin_nontemporal_store(f32x4_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4_nt*>(p));
     else *reinterpret_cast<float4*>(p) = v;
 }
 __device__ __forceinline__ void st_h(uint16_t* p, const uint16_t v) {
     if constexpr (GEMM_EPI_ABL == 1) asm volatile("" ::"v"(v), "v"(p));
     else *p = v;
+}
+__device__ __forceinline__ float4 ld_res4(const float* p) {
+    if constexpr (GEMM_NT >= 2) {
+        const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p));
+        return make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        return *reinterpret_cast<const float4*>(p);
+    }
 }
 
 // two adjacent 16-column sub-tiles (4 columns per lane each) -> 8 contiguous columns (16 bytes) per lane
@@ -507,7 +524,7 @@ __device__ __forceinline__ void fast_epilogue(const GemmArgs& g, const GemmArgs&
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
                     if constexpr (GEMM_EPI_ABL == 3) rv[decltype(jc)::value][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    else rv[decltype(jc)::value][i] = *reinterpret_cast<const float4*>(rp + i * 16);
+                    else rv[decltype(jc)::value][i] = ld_res4(rp + i * 16);
                 }
             });
             static_for<0, JC>([&](auto jc) {

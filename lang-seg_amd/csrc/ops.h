@@ -25,7 +25,7 @@ int launch_upsample2x_planes(const float* in, float* out, int P, int H, int W, h
 int launch_combine_1x1(const float* wh, const float* bh, const float* wo, const float* bo, float* wc, float* bc, int Co, int Cm, int Ci,
                        hipStream_t st);
 int launch_pixel_gram(const void* g16, float* gram, int B, int H, int W, int C, hipStream_t st);
-int launch_norm_scale_plane(const float* gram, float* scale, int B, int H, int W, float s, hipStream_t st);
+int launch_norm_scale_plane(const float* gram, float* scale, int B, int H, int W, float s, hipStream_t st, unsigned* flag = nullptr);
 int launch_upsample2x_planes_scaled(const float* in_padded, const float* scale, float* out, int P, int K, int H, int W, hipStream_t st);
 int launch_upsample4x_planes_scaled(const float* in_padded, const float* scale, float* out, int P, int K, int H, int W, hipStream_t st);
 int launch_upsample_norm_f16(const float* g, void* a, int B, int H, int W, int C, float scale, hipStream_t st);

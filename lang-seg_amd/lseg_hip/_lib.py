@@ -57,6 +57,7 @@ SIGNATURES = {
     "lseg_set_text_cache": (_i, [_vp, _i]),
     "lseg_get_text_features": (_i, [_vp, _vp, _vp]),
     "lseg_set_text_grouping": (_i, [_vp, _i]),
+    "lseg_overflow_seen": (_i, [_vp, _i]),
     "lseg_forward": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "lseg_forward_stats": (_i, [_vp, _vp, _i, _vp, _vp, _vp]),
     "lseg_get_intermediate": (_i, [_vp, C.c_char_p, _vp, _sz, C.POINTER(_sz), _vp]),

@@ -372,6 +372,14 @@ class HipEngine:
         return {"nonfinite": int(out[0]), "near_fp16_limit": int(out[1]),
                 "max_abs": struct.unpack("f", struct.pack("I", int(out[2]) & 0xffffffff))[0], "scanned": int(out[3])}
 
+    def overflow_seen(self, reset: bool = False) -> bool:
+        """True once a COMPLETED inference forward left inf / NaN in the head feature map (lseg_overflow_seen: no synchronisation; an overflow on
+        one call is reported at the latest by the next one).  Sticky until reset."""
+        r = self.lib.lseg_overflow_seen(self._h, int(reset))
+        if r < 0:
+            _lib.check(r)
+        return bool(r)
+
     PROFILE_FAMILIES = ("forward", "mlp_fc1", "mlp_fc2", "attn_proj", "attn_qkv", "attention", "layernorm", "correlation")
 
     def set_profiling(self, enabled):

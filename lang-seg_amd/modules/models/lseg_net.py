@@ -372,16 +372,25 @@ class LSeg(BaseModel):
 
     def _range_guard(self, eng, device):
         """fp16 MFMA operands saturate at 65504 where the reference's fp32 tower cannot (lseg_vit.py:196-197).  Checked on the first
-        forward after every (re)pack of the weights (overflow_fallback="always": on every forward, one synchronising ~1 ms scan; the
-        default leaves an input-dependent overflow on a LATER image of the same weights to that mode): any inf / NaN in a 16-bit
+        forward after every (re)pack of the weights (overflow_fallback="always": on every forward, one synchronising ~1 ms scan); on
+        later forwards the engine's asynchronous sentinel (lseg_overflow_seen) reports an input-dependent overflow one call late, which
+        triggers the same scan: any inf / NaN in a 16-bit
         activation buffer of an fp16 engine -> this network -- every replica sharing `_shared` -- switches to bf16 operands (same
         speed, fp32 range), LOUDLY, and the caller re-runs.  A bf16 engine that still shows non-finite values (the head map g is fp16
         in every mode: DESIGN par. 3.4) raises -- never inf / NaN masks without an error.  Returns True when the caller must re-run.
         Only THIS device's fp16 eval engines are closed, under the shared lock: under DataParallel-style threaded replicas
         (additional_utils/models.py:229-238) another thread may be inside forward() on its own device's engine."""
         mode = getattr(self, "overflow_fallback", True)
-        if not mode or (mode != "always" and getattr(eng, "_range_stamp", None) == eng._stamp):
+        if not mode:
             return False
+        if mode != "always" and getattr(eng, "_range_stamp", None) == eng._stamp:
+            # later forwards of the same weights: the engine's always-on sentinel (lseg_overflow_seen: a device flag raised when the head feature
+            # map carries inf / NaN, read without synchronising).  An input-dependent overflow on image n is caught at the latest when image
+            # n + 1 is submitted: the full scan below then names the damage and the fallback is taken for everything that follows.
+            if not eng.overflow_seen(reset=True):
+                return False
+            warnings.warn("LSeg: a previous forward of this engine left non-finite values in the head feature map (overflow sentinel): its "
+                          "output was not usable; checking the activation ranges now", RuntimeWarning, stacklevel=3)
         eng._range_stamp = eng._stamp
         r = eng.check_range()
         if r["nonfinite"] > 0 and eng.image_dtype == "fp16":

@@ -24,7 +24,7 @@ os.environ.setdefault("LSEG_SYNTHETIC_TOKENS", "1")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu via gpurun)")
-    config.addinivalue_line("markers", "gpu_fast: the <= 2 minute subset of the gpu tests for iteration -- every operator test, one reference-run "
+    config.addinivalue_line("markers", "gpu_fast: the ~4 minute subset of the gpu tests for iteration -- every operator test, one reference-run "
                                        "fixture per network family, one small training fixture (`-m gpu_fast`; the full `-m gpu` suite runs once per "
                                        "final library)")
 

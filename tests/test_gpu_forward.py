@@ -512,6 +512,51 @@ def test_engine_masks_match_the_reference_at_480x480(name, dtype, golden_dir):
 _outlier_state_dict = outlier_state_dict            # (moved to lseg_hip.synth: the reference-run `*_outlier` fixture is made from it too)
 
 
+def test_overflow_sentinel_reports_a_later_image_without_synchronising():
+    """The always-on companion of the range check (lseg_overflow_seen, round 6): the first-forward scan of a weight set cannot see an
+    INPUT-dependent non-finite activation on a later image.  Here batch A keeps the fp16 tower finite and batch B carries a NaN pixel (the
+    cheapest stand-in for an activation that leaves the fp16 range on one input only): the sentinel must stay clear after A, be raised once
+    B's forward has completed, be sticky until reset; the drop-in network reports it on the NEXT call, loudly, and re-scans the ranges."""
+    import warnings
+    from modules.models.lseg_net import LSegNet
+    cfg = get_config("tiny16")
+    labels = read_labels(MG.LABELS)[:5]
+    tok = synthetic_tokens(labels, cfg.text.vocab, cfg.text.ctx)
+    sd = _outlier_state_dict(cfg, 5, 1e2)
+    xa = synthetic_images(2, 64, 64, seed=3).cuda()
+    eng = HipEngine(cfg, 64, 64, max_batch=2, max_labels=5, image_dtype="fp16")
+    eng.load_state_dict(sd)
+    eng.set_tokens(tok)
+    out = eng.forward(xa)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and not eng.overflow_seen()
+    # poison the input instead of hunting for a scale: a NaN pixel is the cheapest "non-finite activation on a later image"
+    xb = xa.clone()
+    xb[1, 0, 10, 10] = float("nan")
+    out_b = eng.forward(xb)
+    torch.cuda.synchronize()
+    assert not torch.isfinite(out_b[1]).all()
+    assert eng.overflow_seen() and eng.overflow_seen(reset=True)          # sticky, then cleared
+    eng.forward(xa)
+    torch.cuda.synchronize()
+    assert not eng.overflow_seen()
+    eng.close()
+    # the drop-in: the call AFTER the poisoned one reports it (warning), scans, and -- the fp16 tower itself being finite on clean input --
+    # carries on; a network whose fp16 tower really saturates takes the bf16 fallback through the same scan (test above)
+    net = LSegNet(labels=labels, backbone="tiny16", features=64, arch_option=0, block_depth=0, activation="lrelu", image_dtype="fp16")
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        net(xa)
+        net(xb)
+        torch.cuda.synchronize()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            o = net(xa)
+        assert any("overflow sentinel" in str(x.message) for x in w), [str(x.message) for x in w]
+        assert torch.isfinite(o).all()
+
+
 def test_fp16_range_check_and_loud_bf16_fallback():
     """VERDICT r3 item 3a / ADVICE: the inference default is fp16 MFMA operands, whose range (65504) the reference's fp32 tower does
     not have.  (1) lseg_check_range counts non-finite 16-bit activations; (2) with outlier statistics at the 1e2 level an fp16 engine

@@ -3,7 +3,7 @@
 #   gpurun --timeout T -- 'bash tools/gpu/lease.sh <name> <task> [<task> ...]'
 # Output goes to gpurun_out/<name>/ (merged back by gpurun); copy what should be judged into profiles/ as rNN_*.
 # Tasks:
-#   fast        pytest -m gpu_fast (<= 2 min: every operator test, one fixture per network family, one training fixture)
+#   fast        pytest -m gpu_fast (~4 min: every operator test, one fixture per network family, one training fixture)
 #   full        the whole GPU suite (pytest -m gpu -x, ~11 min) + smoke
 #   smoke       __graft_entry__.smoke()
 #   bench       the default bench line (python bench.py) -> bench_line.json
