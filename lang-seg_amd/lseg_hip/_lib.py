@@ -134,7 +134,11 @@ def load() -> C.CDLL:
             f"(python -c 'import __graft_entry__ as g; g.build()' or make -C lang-seg_amd/csrc). "
             f"There is no CPU/PyTorch fallback for the LSeg forward path.")
     lib = C.CDLL(LIB_PATH)
+    # tools only: an OLDER build loaded through LSEG_HIP_LIB for a same-box A/B may lack entry points added since (LSEG_HIP_ALLOW_MISSING=1)
+    lenient = "LSEG_HIP_LIB" in os.environ and os.environ.get("LSEG_HIP_ALLOW_MISSING", "") == "1"
     for name, (res, args) in SIGNATURES.items():
+        if lenient and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)          # AttributeError if the .so does not export it
         fn.restype = res
         fn.argtypes = args
