@@ -57,6 +57,13 @@ REF_ZS_CASES = {
 }
 
 
+# the zero-shot network at BASELINE configs[4]'s own size (480 x 480 ViT-L/16, per-image label pairs, B = 4): `--zs480`.  Logits stored at every
+# second pixel in fp16 (0.9 MB).
+REF_ZS_FULL_CASES = {
+    "ref_vitl16_480x480_zs": ("clip_vitl16_384", 480, 480, (4, 0, 9, 2), 17),
+}
+
+
 def reference_models():
     """The reference's modules/models directory as a synthetic package `refmodels` (it has no __init__.py, and our
     own drop-in package is also called `modules`)."""
@@ -163,6 +170,13 @@ def save_full480_case(name, spec, gd):
 def main():
     gd = os.path.join(ROOT, "tests", "golden")
     os.makedirs(gd, exist_ok=True)
+    if "--zs480" in sys.argv[1:]:
+        for name, spec in REF_ZS_FULL_CASES.items():
+            cfg, sd, x, tok, out = run_ref_zs_case(spec)
+            torch.save({"spec": spec, "tokens": tok.clone(), "sub": 2, "logits": out[:, :, ::2, ::2].to(torch.float16).clone(),
+                        "absmax": float(out.abs().max())}, os.path.join(gd, name + ".pt"))
+            print(name, tuple(out.shape), float(out.abs().mean()))
+        return
     if "--full480" in sys.argv[1:]:
         for name, spec in REF_FULL_CASES.items():
             if "--only" in sys.argv[1:] and name not in sys.argv[1:]:

@@ -55,8 +55,11 @@ def test_oracle_zero_shot_matches_reference_code(name):
     x = synthetic_images(len(class_info), H, W, seed=seed)
     with torch.no_grad():
         out = lseg_forward(sd, x, g["tokens"], cfg, labels_per_image=2)
-    assert out.shape == g["logits"].shape == (len(class_info), 2, H, W)
-    assert (out - g["logits"]).abs().max().item() <= 4e-3 * max(1.0, g["logits"].abs().max().item())
+    sub = int(g.get("sub", 1))                 # the 480 x 480 case stores every second pixel in fp16 (oracle/make_ref_golden.py --zs480)
+    ref = g["logits"].float()
+    out = out[:, :, ::sub, ::sub]
+    assert out.shape == ref.shape == (len(class_info), 2, (H + sub - 1) // sub, (W + sub - 1) // sub)
+    assert (out - ref).abs().max().item() <= (4e-3 if sub == 1 else 6e-3) * max(1.0, ref.abs().max().item())
 
 
 REF_FULL = sorted(f[:-3] for f in os.listdir(GOLD) if f.startswith("ref_full_") and not f.endswith("_out480.pt"))
