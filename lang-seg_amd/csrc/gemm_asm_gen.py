@@ -65,7 +65,7 @@ S_LOOP = 58
 S_T = 59                            # s59 .. s63 temporaries
 S_ENT = 64                          # s64 .. s95 tile entries
 S_KRING, S_TMP1 = 31, 99             # NSTAGE * STAGE (ring size); a temporary
-S_WM, S_WN = 100, 101                # the wave's place in the tile (prologue only)
+S_WM, S_WN = 62, 63                  # the wave's place in the tile (prologue only: s62 / s63 are tile_bases temporaries afterwards; s100+ are reserved)
 S_KFWD, S_KBACK = 96, 97            # +STAGE / -(NSTAGE - 1) * STAGE: fragment-address step to the next ring stage
 
 V_LANE = 1
@@ -572,7 +572,7 @@ def main():
             print(f"{dt}: {len(lines)} lines, {n_mfma} MFMAs, fullest MFMA gap {g.max_gap} instructions", file=sys.stderr)
         # registers the bodies own: named as clobbers so that the compiler keeps its operands out of them and the kernel descriptor
         # allocates the whole file (512 registers per lane, one wave per SIMD)
-        cl = [f"v{i}" for i in range(1, 128)] + [f"a{i}" for i in range(2 * ACCSET)] + [f"s{i}" for i in range(16, 102) if i != 32] + ["vcc", "scc", "memory"]
+        cl = [f"v{i}" for i in range(1, 128)] + [f"a{i}" for i in range(2 * ACCSET)] + [f"s{i}" for i in range(16, 100) if i != 32] + ["vcc", "scc", "memory"]
         f.write("#define LSEG_GEMM_ASM_CLOBBERS " + ", ".join('"' + c + '"' for c in cl) + "\n")
         f.write(f"#define LSEG_GEMM_ASM_TILE_SLOTS {TILE_SLOTS}\n#define LSEG_GEMM_ASM_LDS {STAGE * NSTAGE}\n#define LSEG_GEMM_ASM_MIN_KSTEPS {EPI_UNITS + 4}\n"
                 f"#define LSEG_GEMM_ASM_THREADS {64 * NW}\n#define LSEG_GEMM_ASM_WAVES_PER_EU {NW // 4}\n")
