@@ -1478,7 +1478,8 @@ int launch_gemm(const GemmArgs& g_in, int ab_dtype, hipStream_t stream) {
     GemmArgs g = g_in;
     static const int dbg = getenv("LSEG_GEMM_DBG") ? atoi(getenv("LSEG_GEMM_DBG")) : 0;
     g.dbg = dbg;
-    g.group_m = 8;                            // row-blocks per rasterisation group (2 .. 32 measured within noise in round 2)
+    static const int group_env = getenv("LSEG_GEMM_GROUP_M") ? atoi(getenv("LSEG_GEMM_GROUP_M")) : 0;     // tools: A/B of the rasterisation group
+    g.group_m = group_env > 0 ? group_env : 8;   // row-blocks per rasterisation group (2 .. 32 within noise in round 2 and again in round 6)
     static const int grid_cap = getenv("LSEG_GEMM_MAXGRID") ? atoi(getenv("LSEG_GEMM_MAXGRID")) : 0;     // tools: every launch on part of the chip
     if (grid_cap >= 8 && !g.max_grid) g.max_grid = grid_cap;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return set_error(LSEG_ERR_INVALID, "gemm: empty problem %dx%dx%d", g.M, g.N, g.K);
