@@ -447,6 +447,66 @@ __device__ __forceinline__ uint4 widen16(const float (&x)[4], const float (&y)[4
     return make_uint4(s0[0], s1[0], s0[1], s1[1]);
 }
 
+// GEMM_RES_PRELOAD (round 6): EPI_RES32 with the RESIDUAL AS THE ACCUMULATORS' START VALUE.  The epilogue of round 5 loaded the lane's residual
+// sub-tile AFTER the K-loop (the accumulators own the registers it would land in) -- 133 MB per tile round that every CU requests at once and
+// then waits for: the exposed half of the read-modify-write (profiles/r04_epilogue_table.txt).  Here the accumulators of tile i+1 are loaded with
+// its residual by the epilogue of tile i, chunk by chunk right behind the stores that free them: stores and loads are both posted, nothing in
+// the epilogue waits for memory, and the loads land under the epilogue's remaining chunks and the next tile's first fragment reads (the first
+// MFMA that touches a chunk waits for it).  C = (res + A W^T) + bias: the products accumulate ON the residual (fp32, ~1e-6 |res| of rounding)
+// instead of being added to it last -- the same association as the hand-scheduled kernel (gemm_asm.hip).
+// MEASURED (profiles/r06_gemm_asm.txt, same box, interleaved): attn.proj 93.5-94.3 vs 93.6-98.7 us, mlp.fc2 258-261 vs 256-261 us -- NO gain: the
+// read-modify-write of a tile costs a CU ~25 us whether the loads are waited for in the epilogue or at the next tile's first MFMA, on the whole
+// chip or on half of it (r04_epilogue_table.txt "partial") -- it is bound by what one CU can keep in flight against HBM latency (~20 GB/s per
+// CU), not by the wait structure and not by the chip's bandwidth.  Kept as a build switch, OFF (round-5 association of the sums).
+#ifndef GEMM_RES_PRELOAD
+#define GEMM_RES_PRELOAD 0
+#endif
+template <int MI, int NI>
+__device__ __forceinline__ void res_preload(const GemmArgs& g, f32x4_t (&acc)[NI][MI], int mrow0, int ncol0, int lane) {
+    const int r16 = lane >> 4, ml = lane & 15;
+    const float* rbase = (const float*)g.res + ncol0 + r16 * 4;
+    static_for<0, MI>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        int m = mrow0 + j * 16 + ml;
+        if (m > g.M - 1) m = g.M - 1;
+        const float* rp = rbase + (size_t)m * g.ldc;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const float4 v = *reinterpret_cast<const float4*>(rp + i * 16);
+            acc[i][j] = f32x4_t{v.x, v.y, v.z, v.w};
+        }
+    });
+}
+// the epilogue of that form: store (acc + bias) chunk by chunk; `next` = a further tile of this workgroup follows, whose residual (sub-tile at
+// nrow0 / ncol_n) goes into the registers each chunk's stores have just read
+template <int MI, int NI>
+__device__ __forceinline__ void res_store_and_preload(const GemmArgs& g, f32x4_t (&acc)[NI][MI], int mrow0, int ncol0, int lane, const float4 (&bias)[NI],
+                                                      bool next, int nrow0, int ncol_n) {
+    const int r16 = lane >> 4, ml = lane & 15;
+    float* cbase = (float*)g.C + ncol0 + r16 * 4;
+    const float* rbase = (const float*)g.res + ncol_n + r16 * 4;
+    static_for<0, MI>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const int m = mrow0 + j * 16 + ml;
+        float* p = cbase + (size_t)m * g.ldc;
+        if (m < g.M) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                st_f4(p + i * 16, make_float4(acc[i][j][0] + bias[i].x, acc[i][j][1] + bias[i].y, acc[i][j][2] + bias[i].z, acc[i][j][3] + bias[i].w));
+        }
+        if (next) {                               // wave-uniform
+            int mn = nrow0 + j * 16 + ml;
+            if (mn > g.M - 1) mn = g.M - 1;
+            const float* rp = rbase + (size_t)mn * g.ldc;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const float4 v = *reinterpret_cast<const float4*>(rp + i * 16);
+                acc[i][j] = f32x4_t{v.x, v.y, v.z, v.w};
+            }
+        }
+    });
+}
+
 // mrow0 / ncol0: first row / column of this WAVE's sub-tile (wave-uniform).  acc[i][j]: rows
 // mrow0 + j*16 + (lane&15), columns ncol0 + i*16 + (lane>>4)*4 .. +3.
 template <typename T, int EPI, int MI, int NI>
@@ -1179,6 +1239,7 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
 
     constexpr bool BIAS_PREFETCH = MI * NI <= 16;
     float4 biasv[EPI != EPI_GENERIC ? NI : 1];
+    bool res_loaded = false;                   // GEMM_RES_PRELOAD: acc already holds the next tile's residual
     for (; tile < tile_end; tile += wpx) {
         int pm0, pn0;
         {   // this tile's origin and, for the specialised epilogues, its bias (consumed after the K-loop)
@@ -1191,10 +1252,16 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
                     biasv[i] = *reinterpret_cast<const float4*>(g.bias + (EPI == EPI_PIX16 ? (pn0 + wn * WN + i * 16) % g.ps_C : pn0 + wn * WN + i * 16) + (lane >> 4) * 4);
             }
         }
+        constexpr bool RES_PRE = GEMM_RES_PRELOAD && EPI == EPI_RES32 && !CONV && CFG::BN != 512;
+        if constexpr (RES_PRE) {
+            // the accumulators start from the residual: loaded by the previous tile's epilogue, or here for the workgroup's first tile
+            if (!res_loaded) res_preload<MI, NI>(g, acc, pm0 + wm * WM, pn0 + wn * WN, lane);
+        } else {
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int j = 0; j < MI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < MI; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
         for (int kt = (k_end(tile) - k_beg(tile)) * nseg; kt > 0; --kt) step();
         // ---- epilogue: the next tile's first K-step is already in flight / in registers
         unsigned long long te0 = 0;
@@ -1268,6 +1335,12 @@ __global__ __launch_bounds__(CFG::THREADS, CFG::MINW) void lseg_gemm_kernel(cons
                 for (int i = 0; i < NI; ++i)
 #pragma unroll
                     for (int j = 0; j < MI; ++j) asm volatile("" ::"v"(acc[i][j][0]), "v"(acc[i][j][1]), "v"(acc[i][j][2]), "v"(acc[i][j][3]));
+            } else if constexpr (RES_PRE) {
+                const bool next = tile + wpx < tile_end;
+                int nmb = 0, nnb = 0;
+                if (next) tile_coords((tile + wpx) % per_split, tiles_m, tiles_n, nmb, nnb, g.group_m);
+                res_store_and_preload<MI, NI>(g, acc, m0c + wm * WM, n0c + wn * WN, lane, biasv, next, nmb * BM + wm * WM, nnb * BN + wn * WN);
+                res_loaded = next;
             } else {
                 fast_epilogue<T, EPI, MI, NI>(g, gk, acc, m0c + wm * WM, n0c + wn * WN, lane, biasv,
                                               nsplit > 1 ? (size_t)(tile / per_split) * g.c_split_stride : 0);
