@@ -182,7 +182,15 @@ int Engine::init() {
     ALLOC(tpool_, uint16_t, Kl * W);
     ALLOC(tfeat_, uint16_t, Kl * c.out_c);
     ALLOC(tnorm_, uint16_t, Kl * c.out_c);
-    LSEG_HIP_TRY(hipStreamCreateWithFlags(&text_stream_, hipStreamNonBlocking));
+    {   // the text tower's ~90 latency-bound launches run beside the image tower: at the LOWEST stream priority, so that the dispatcher hands
+        // free CUs to the image tower's kernels first (LSEG_TEXT_PRIO=0: default priority, tools A/B)
+        static const int prio_env = getenv("LSEG_TEXT_PRIO") ? atoi(getenv("LSEG_TEXT_PRIO")) : 1;
+        int least = 0, greatest = 0;
+        if (prio_env && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
+            LSEG_HIP_TRY(hipStreamCreateWithPriority(&text_stream_, hipStreamNonBlocking, least));
+        else
+            LSEG_HIP_TRY(hipStreamCreateWithFlags(&text_stream_, hipStreamNonBlocking));
+    }
     LSEG_HIP_TRY(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
     LSEG_HIP_TRY(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
     LSEG_HIP_TRY(hipEventCreateWithFlags(&ev_text_done_, hipEventDisableTiming));
